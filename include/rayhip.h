@@ -1,0 +1,362 @@
+/*
+ * rayhip.h -- C ABI of librayhip: the MI355X (gfx950) path-tracer core loop behind
+ * sergcpp/Ray's RendererBase / SceneBase.
+ *
+ * This is the drop-in boundary.  Everything on the far side of it is
+ * hand-written HIP; everything on the near side is plain C: opaque handles, plain pointers and sizes,
+ * `int` status (0 = ok, see rayhip_last_error), no exceptions, no torch / C++ types.
+ *   - the caller owns all HOST memory it passes in; the library copies what it needs
+ *   - the library owns all DEVICE memory, except buffers the caller hands to the *_device entry points
+ *   - one context per GPU; calls on one context are not re-entrant (the reference's GPU renderers are
+ *     single-caller too: reference RendererBase.cpp:50-62, tests/test_scene.cpp:1124-1148)
+ *
+ * Each entry point names the reference interface it stands in for (file:line under the reference tree).
+ * The reference-side binding (RendererHIP.cpp / SceneHIP.h, a new eRendererType::HIP) is in
+ * ray_amd/host/ and described in INTEGRATION.md.
+ *
+ * The POD structs below are byte-identical to the reference's internal/Core.h structs: the scene
+ * arrays built by the reference's host-side scene code (SceneCPU.cpp) are uploaded verbatim.  The
+ * Vulkan backend makes the same promise about its GLSL structs (reference internal/RendererVK.cpp:31-45).
+ */
+#ifndef RAYHIP_H
+#define RAYHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define RAYHIP_API __attribute__((visibility("default")))
+#else
+#define RAYHIP_API
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Scene POD layouts  (== reference internal/Core.h)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* precomputed 3-plane triangle, reference Core.h:72-77 (tri_accel_t), built by Core.cpp:212-258 */
+typedef struct rayhip_tri_accel {
+    float n_plane[4];
+    float u_plane[4];
+    float v_plane[4];
+} rayhip_tri_accel; /* 48 B */
+
+/* 2-wide BVH node holding its children's boxes, reference Core.h:107-115 (bvh2_node_t).
+ * child word: top 3 bits = (prim_count-1) for leaves (0 => inner node), low 29 bits = index
+ * (Constants.inl:24-25) */
+typedef struct rayhip_bvh2_node {
+    float ch_data0[4]; /* [ ch0.min.x, ch0.max.x, ch0.min.y, ch0.max.y ] */
+    float ch_data1[4]; /* [ ch1.min.x, ch1.max.x, ch1.min.y, ch1.max.y ] */
+    float ch_data2[4]; /* [ ch0.min.z, ch0.max.z, ch1.min.z, ch1.max.z ] */
+    uint32_t left_child, right_child;
+    uint32_t _unused0, _unused1;
+} rayhip_bvh2_node; /* 64 B */
+
+/* reference Core.h:370-373 (vertex_t) */
+typedef struct rayhip_vertex {
+    float p[3], n[3], b[3], t[2];
+} rayhip_vertex; /* 44 B */
+
+/* reference Core.h:384-391 (mesh_instance_t) */
+typedef struct rayhip_mesh_instance {
+    uint32_t mesh_index;
+    uint32_t node_index;
+    uint32_t lights_index;
+    uint32_t ray_visibility; /* low 8 bits: ray-type mask; upper 24 bits: lights_block */
+    float xform[16], inv_xform[16];
+} rayhip_mesh_instance; /* 144 B */
+
+/* reference Core.h:166-168 (tri_mat_data_t) */
+typedef struct rayhip_tri_mat_data {
+    uint16_t front_mi, back_mi;
+} rayhip_tri_mat_data; /* 4 B */
+
+/* reference Core.h:170-195 (material_t); `type` is Ray::eShadingNode (SceneBase.h:46) */
+typedef struct rayhip_material {
+    uint32_t textures[5];
+    float base_color[3];
+    uint32_t flags;
+    uint32_t type;
+    float tangent_rotation_or_strength;
+    uint16_t roughness_unorm;
+    uint16_t anisotropic_unorm;
+    float ior;
+    uint16_t sheen_unorm;
+    uint16_t sheen_tint_unorm;
+    uint16_t tint_unorm;
+    uint16_t metallic_unorm;
+    uint16_t transmission_unorm;
+    uint16_t transmission_roughness_unorm;
+    uint16_t specular_unorm;
+    uint16_t specular_tint_unorm;
+    uint16_t clearcoat_unorm;
+    uint16_t clearcoat_roughness_unorm;
+    uint16_t normal_map_strength_unorm;
+    uint16_t _pad;
+} rayhip_material; /* 76 B */
+
+/* reference Core.h:197-237 (light_t).  Word 0 is the bitfield
+ *   type:3 | doublesided:1 | cast_shadow:1 | visible:1 | sky_portal:1 | ray_visibility:8 | unused:17
+ * followed by col[3] and 12 floats whose meaning depends on `type` (sph/rect/disk/line/tri/dir). */
+typedef struct rayhip_light {
+    uint32_t flags;
+    float col[3];
+    float params[12];
+} rayhip_light; /* 64 B */
+
+/* reference Core.h:139-156 (cwbvh_node_t + light_cwbvh_node_t): 8-wide quantised light-tree node */
+typedef struct rayhip_light_cwbvh_node {
+    float bbox_min[3];
+    float _unused0;
+    float bbox_max[3];
+    float _unused1;
+    uint8_t ch_bbox_min[3][8];
+    uint8_t ch_bbox_max[3][8];
+    uint32_t child[8];
+    float flux[8];
+    uint32_t axis[8];
+    uint32_t cos_omega_ne[8];
+} rayhip_light_cwbvh_node; /* 208 B */
+
+/* One texture = a mip chain of linear RGBA8 images inside the texel pool.  The reference keeps
+ * RGBA8/RGB8/RG8/R8 in swizzled CPU tiles (TextureStorageCPU.h:229-331); that swizzle is a CPU-cache
+ * device, so the boundary hands over plain row-major RGBA8 (missing channels replicated exactly like
+ * TexStorageSwizzled::Fetch does).  Texture handles in materials keep the reference encoding
+ * (storage<<28 | flags<<24 | index, SceneCPU.cpp:192-205); `tex_table[(handle>>28)]` gives the first
+ * entry of that storage in `textures`. */
+typedef struct rayhip_texture {
+    uint32_t width[12], height[12]; /* per mip level; unused levels repeat the last valid one */
+    uint32_t offset[12];            /* texel offset of each level in the texel pool */
+} rayhip_texture;
+
+/* subset of reference Core.h:393-409 (environment_t) that the path reads */
+typedef struct rayhip_environment {
+    float env_col[3];
+    uint32_t env_map;
+    float back_col[3];
+    uint32_t back_map;
+    float env_map_rotation;
+    float back_map_rotation;
+    uint32_t light_index;
+    float sky_map_spread_angle;
+    int32_t qtree_levels; /* importance-sampled HDRI quadtree: not supported yet, must be 0 */
+    uint32_t _pad[3];
+} rayhip_environment;
+
+/* == Ray::camera_t (reference Types.h:96-108), including pass_settings_t (Types.h:82-93) */
+typedef struct rayhip_pass_settings {
+    uint8_t max_diff_depth, max_spec_depth, max_refr_depth, max_transp_depth, max_total_depth;
+    uint8_t min_total_depth, min_transp_depth;
+    uint8_t flags;
+    float clamp_direct, clamp_indirect;
+    int32_t min_samples;
+    float variance_threshold;
+    float regularize_alpha;
+} rayhip_pass_settings; /* 28 B */
+
+typedef struct rayhip_camera {
+    uint8_t type;           /* Ray::eCamType */
+    uint8_t filter;         /* Ray::ePixelFilter */
+    uint8_t view_transform; /* Ray::eViewTransform */
+    uint8_t ltype;          /* Ray::eLensUnits */
+    float filter_width;
+    float fov, exposure, gamma, sensor_height;
+    float focus_distance, focal_length, fstop, lens_rotation, lens_ratio;
+    int32_t lens_blades;
+    float clip_start, clip_end;
+    float origin[3], fwd[3], side[3], up[3], shift[2];
+    uint32_t mi_index, uv_index;
+    rayhip_pass_settings pass_settings;
+} rayhip_camera;
+
+/* Flat scene: what reference RendererCPU.h:390-413 gathers into scene_data_t before every RenderScene.
+ * All pointers are HOST pointers; counts are element counts (capacity of the sparse pools, since the
+ * indices stored in the arrays are pool slots). */
+typedef struct rayhip_scene_desc {
+    const rayhip_bvh2_node *nodes;
+    uint32_t nodes_count;
+    const rayhip_tri_accel *tris;
+    uint32_t tris_count;
+    const uint32_t *tri_indices;
+    uint32_t tri_indices_count;
+    const rayhip_tri_mat_data *tri_materials;
+    uint32_t tri_materials_count;
+    const rayhip_material *materials;
+    uint32_t materials_count;
+    const rayhip_vertex *vertices;
+    uint32_t vertices_count;
+    const uint32_t *vtx_indices;
+    uint32_t vtx_indices_count;
+    const rayhip_mesh_instance *mesh_instances;
+    uint32_t mesh_instances_count;
+    const rayhip_light *lights;
+    uint32_t lights_count;
+    const uint32_t *li_indices;
+    uint32_t li_indices_count;
+    const rayhip_light_cwbvh_node *light_cwnodes;
+    uint32_t light_cwnodes_count;
+    const rayhip_texture *textures;
+    uint32_t textures_count;
+    const uint32_t *texels; /* RGBA8 pool */
+    uint32_t texels_count;
+    uint32_t tex_table[8]; /* first `textures` entry of each reference storage (RGBA,RGB,RG,R,BC1,BC3,BC4,BC5) */
+    rayhip_environment env;
+    uint32_t tlas_root; /* 0xffffffff = empty scene */
+    uint32_t visible_lights_count;
+    uint32_t blocker_lights_count;
+    float bbox_min[3], bbox_max[3]; /* Scene::GetBounds (SceneCPU.cpp:1523), feeds the ray-sort grid only */
+} rayhip_scene_desc;
+
+/* == RendererBase::stats_t (reference RendererBase.h:230-244), microseconds */
+typedef struct rayhip_stats {
+    unsigned long long time_primary_ray_gen_us;
+    unsigned long long time_primary_trace_us;
+    unsigned long long time_primary_shade_us;
+    unsigned long long time_primary_shadow_us;
+    unsigned long long time_secondary_sort_us;
+    unsigned long long time_secondary_trace_us;
+    unsigned long long time_secondary_shade_us;
+    unsigned long long time_secondary_shadow_us;
+    unsigned long long time_denoise_us;
+    unsigned long long time_cache_update_us;
+    unsigned long long time_cache_resolve_us;
+} rayhip_stats;
+
+/* Wavefront ray state as the reference defines it (CoreRef.h:57-105).  Device storage is SoA
+ * (DESIGN.md); these AoS forms exist only at this boundary, for the kernel-level test hooks. */
+typedef struct rayhip_ray {
+    float o[3], d[3], pdf;
+    float c[3];
+    float ior[4];
+    float cone_width, cone_spread;
+    uint32_t xy;
+    uint32_t depth;
+} rayhip_ray; /* 72 B */
+
+typedef struct rayhip_shadow_ray {
+    float o[3];
+    uint32_t depth;
+    float d[3], dist;
+    float c[3];
+    uint32_t xy;
+} rayhip_shadow_ray; /* 48 B */
+
+typedef struct rayhip_hit {
+    int32_t obj_index;
+    int32_t prim_index;
+    float t, u, v;
+} rayhip_hit; /* 20 B */
+
+/* per-launch traversal work counters (instrumented variant of the traversal kernels): the inputs of the
+ * algorithmic-bytes formula of SURVEY.md section 8d */
+typedef struct rayhip_trav_counters {
+    unsigned long long rays;
+    unsigned long long nodes;     /* bvh2 nodes fetched (64 B each) */
+    unsigned long long tris;      /* triangles tested (48 B each) */
+    unsigned long long instances; /* mesh instances entered (144 B each) */
+} rayhip_trav_counters;
+
+typedef struct rayhip_ctx rayhip_ctx;
+
+enum {
+    RAYHIP_BUF_FINAL = 0,        /* tonemapped, RendererBase::get_pixels_ref (RendererBase.h:152) */
+    RAYHIP_BUF_RAW = 1,          /* linear running mean, get_raw_pixels_ref (RendererBase.h:157) */
+    RAYHIP_BUF_BASE_COLOR = 2,   /* get_aux_pixels_ref(eAUXBuffer::BaseColor) */
+    RAYHIP_BUF_DEPTH_NORMALS = 3 /* get_aux_pixels_ref(eAUXBuffer::DepthNormals) */
+};
+
+enum {
+    RAYHIP_FLAG_SORT_RAYS = 1u << 0,     /* ray sort between bounces (RendererVK.cpp:641-652) */
+    RAYHIP_FLAG_COUNT_TRAVERSAL = 1u << 1 /* run the instrumented traversal kernels (slower) */
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * Entry points
+ * ---------------------------------------------------------------------------------------------- */
+
+/* thread-local message for the last non-zero status returned on this thread */
+RAYHIP_API const char *rayhip_last_error(void);
+
+/* Number of usable gfx950 devices.  The reference GPU factories throw when no device is present and
+ * the caller falls back (Ray.cpp:58-63); Hip::CreateRenderer does the same on a 0 here. */
+RAYHIP_API int rayhip_device_count(void);
+
+/* Vk::Renderer::Renderer (RendererVK.cpp:240-325): create context on `device`, own stream */
+RAYHIP_API int rayhip_ctx_create(int device, rayhip_ctx **out_ctx);
+RAYHIP_API void rayhip_ctx_destroy(rayhip_ctx *ctx);
+/* RendererBase::device_name (RendererBase.h:143) */
+RAYHIP_API int rayhip_ctx_device_name(rayhip_ctx *ctx, char *buf, int cap);
+
+/* upload of the 32 x 4096 x 2 PMJ02 table (RendererVK.cpp:299-311; table: Core.h:363-368) */
+RAYHIP_API int rayhip_upload_static(rayhip_ctx *ctx, const uint32_t *pmj02_samples, uint32_t count);
+
+/* RendererBase::Resize / Clear (RendererBase.h:176,181; RendererGPU.h:380-488) */
+RAYHIP_API int rayhip_resize(rayhip_ctx *ctx, int w, int h);
+RAYHIP_API int rayhip_clear(rayhip_ctx *ctx, const float rgba[4]);
+
+/* flat-array upload after SceneBase::Finalize (what SceneVK does buffer by buffer, SceneGPU.h:62-104) */
+RAYHIP_API int rayhip_scene_upload(rayhip_ctx *ctx, const rayhip_scene_desc *desc);
+
+/* Same upload from a serialised scene (ray_amd/csrc/scene_blob.h; written by the reference-side SceneHIP or by
+ * tests/golden/make_fixtures.py): uploads the arrays AND the filter table stored in the blob and returns the
+ * camera stored with it.  `blob` must be 16-byte aligned. */
+RAYHIP_API int rayhip_scene_upload_blob(rayhip_ctx *ctx, const void *blob, size_t size, rayhip_camera *out_cam);
+
+/* 1024-entry inverse filter CDF (RendererCPU.h:1234-1258 UpdateFilterTable; upload RendererVK.cpp:386-424) */
+RAYHIP_API int rayhip_set_filter_table(rayhip_ctx *ctx, const float *table, int count);
+
+/* RendererBase::RenderScene (RendererBase.h:196; schedule RendererVK.cpp:368-791, arithmetic
+ * RendererCPU.h:373-659) for ONE iteration over `rect` = {x,y,w,h}.  `iteration` is 1-based, i.e. the
+ * value of RegionContext::iteration after the increment at RendererCPU.h:384.  `stats` may be NULL; when
+ * given, per-stage GPU times of this call (HIP events on the context stream) are ADDED to it.
+ * The call returns when the work is enqueued unless stats != NULL (then it synchronises). */
+RAYHIP_API int rayhip_render(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int iteration,
+                             uint32_t flags, rayhip_stats *stats);
+
+/* blocking device->host copy, get_pixels_ref & co. (RendererVK.cpp:1698-1757) */
+RAYHIP_API int rayhip_readback(rayhip_ctx *ctx, int which, float *dst_rgba, int pitch_px);
+/* same, into DEVICE memory the caller owns (e.g. a torch tensor that is then reduced over RCCL);
+ * enqueued on the context stream, followed by a stream synchronise */
+RAYHIP_API int rayhip_readback_device(rayhip_ctx *ctx, int which, void *dst_device_rgba, int pitch_px);
+/* overwrite the running-mean (RAW/"full") buffer from DEVICE memory and re-run the tonemap pass; used
+ * after the multi-GPU tile reduce so that rank 0 holds the combined frame */
+RAYHIP_API int rayhip_set_raw_device(rayhip_ctx *ctx, const void *src_device_rgba, int pitch_px,
+                                     const rayhip_camera *cam);
+
+RAYHIP_API int rayhip_sync(rayhip_ctx *ctx);
+
+/* traversal counters accumulated by RAYHIP_FLAG_COUNT_TRAVERSAL renders since the last reset:
+ * [0] closest-hit kernel (K2), [1] shadow any-hit kernel (K3) */
+RAYHIP_API int rayhip_get_trav_counters(rayhip_ctx *ctx, rayhip_trav_counters out[2], int reset);
+/* GPU time (ms, HIP events on the context stream) and launch count of the closest-hit traversal kernel
+ * and the shadow kernel, accumulated over renders that passed stats != NULL; [0]=K2 [1]=K3 */
+RAYHIP_API int rayhip_get_trav_timing(rayhip_ctx *ctx, double out_ms[2], unsigned long long out_launches[2],
+                                      int reset);
+
+/* ---- kernel-level hooks (tests only use these; they run the same kernels RenderScene launches) ---- */
+
+/* Ref::GeneratePrimaryRays (CoreRef.cpp:1429-1553): fills out_rays/out_hits (host, rect.w*rect.h each) */
+RAYHIP_API int rayhip_k_generate_primary_rays(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4],
+                                              int iteration, rayhip_ray *out_rays, rayhip_hit *out_hits,
+                                              int *out_count);
+/* Ref::IntersectScene closest hit (CoreRef.cpp:3041-3158): rays/hits are in-out host arrays */
+RAYHIP_API int rayhip_k_intersect_closest(rayhip_ctx *ctx, const rayhip_camera *cam, rayhip_ray *rays,
+                                          rayhip_hit *hits, int count, int iteration,
+                                          rayhip_trav_counters *out_counters /* may be NULL */);
+/* Ref::IntersectScene(shadow_ray_t) (CoreRef.cpp:3160-3262): out_rc[count][4] visibility * colour */
+RAYHIP_API int rayhip_k_intersect_shadow(rayhip_ctx *ctx, const rayhip_camera *cam,
+                                         const rayhip_shadow_ray *rays, int count, int iteration,
+                                         float *out_rc, rayhip_trav_counters *out_counters /* may be NULL */);
+/* Ref::get_scrambled_2d_rand (CoreRef.cpp:1418-1427) for `count` (dim,seed,sample) triples */
+RAYHIP_API int rayhip_k_scrambled_rand(rayhip_ctx *ctx, const uint32_t *dims, const uint32_t *seeds,
+                                       const int32_t *samples, int count, float *out_xy);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RAYHIP_H */

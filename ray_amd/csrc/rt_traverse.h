@@ -1,0 +1,493 @@
+// rt_traverse.h -- BVH2 traversal with an explicit stack and the reference's precomputed 3-plane triangle test.
+//
+// Restates, operation for operation:
+//   IntersectTri                         reference internal/CoreRef.cpp:24-50
+//   bbox_test                            CoreRef.cpp:171-210
+//   IntersectTris_ClosestHit / _AnyHit   CoreRef.cpp:1798-1817 / 1840-1863
+//   Traverse_TLAS/BLAS_WithStack_ClosestHit (bvh2)   CoreRef.cpp:1943-2025 / 2428-2493
+//   Traverse_TLAS/BLAS_WithStack_AnyHit (bvh2)       CoreRef.cpp:2193-2280 / 2619-2693
+//   IntersectScene (closest, transparency loop)      CoreRef.cpp:3041-3158
+//   IntersectScene (shadow_ray_t)                    CoreRef.cpp:3160-3262
+//
+// The Stack policy is what differs between builds: kernels.hip passes a per-wavefront LDS stack
+// (depth-major, 64 lanes wide -> bank = lane, conflict free at any mix of depths), tests/hostsim a plain
+// array.  BLAS traversal runs on the same stack above the TLAS entries (the GLSL shader does the same,
+// reference shaders/intersect_scene.comp.glsl:89-94,215); `base` plays the role of the reference's separate
+// `stack_size == 0`.
+#pragma once
+
+#include "rt_rng.h"
+#include "rt_texture.h"
+#include "rt_types.h"
+
+namespace rt {
+
+// plain array stack (host simulation, and the spill fallback)
+struct ArrayStack {
+    uint32_t data[2 * MAX_STACK_SIZE];
+    uint32_t size = 0;
+    RT_HD void push(uint32_t v) { data[size++] = v; }
+    RT_HD uint32_t pop() { return data[--size]; }
+};
+
+#define RT_SIGN_OF(f) (((f) >= 0) ? 1 : -1)
+
+// CoreRef.cpp:24-50
+RT_HD void intersect_tri(const f3 ro, const f3 rd, const rayhip_tri_accel &tri, const uint32_t prim_index, Hit &inter) {
+    const float det = rd.x * tri.n_plane[0] + rd.y * tri.n_plane[1] + rd.z * tri.n_plane[2];
+    const float dett = tri.n_plane[3] - (ro.x * tri.n_plane[0] + ro.y * tri.n_plane[1] + ro.z * tri.n_plane[2]);
+    if (det == 0.0f || RT_SIGN_OF(dett) != RT_SIGN_OF(det * inter.t - dett)) {
+        return;
+    }
+    const float p0 = det * ro.x + dett * rd.x, p1 = det * ro.y + dett * rd.y, p2 = det * ro.z + dett * rd.z;
+
+    const float detu = (p0 * tri.u_plane[0] + p1 * tri.u_plane[1] + p2 * tri.u_plane[2]) + det * tri.u_plane[3];
+    if (RT_SIGN_OF(detu) != RT_SIGN_OF(det - detu)) {
+        return;
+    }
+    const float detv = (p0 * tri.v_plane[0] + p1 * tri.v_plane[1] + p2 * tri.v_plane[2]) + det * tri.v_plane[3];
+    if (RT_SIGN_OF(detv) != RT_SIGN_OF(det - detu - detv)) {
+        return;
+    }
+    const float rdet = (1.0f / det);
+
+    inter.prim_index = (det < 0.0f) ? int(prim_index) : -int(prim_index) - 1;
+    inter.t = dett * rdet;
+    inter.u = detu * rdet;
+    inter.v = detv * rdet;
+}
+#undef RT_SIGN_OF
+
+// CoreRef.cpp:171-210
+RT_HD bool bbox_test(const f3 o, const f3 inv_d, const float t, const float mn[3], const float mx[3], float &out_dist) {
+    float lo_x = inv_d.x * (mn[0] - o.x);
+    float hi_x = inv_d.x * (mx[0] - o.x);
+    if (lo_x > hi_x) {
+        const float tmp = lo_x;
+        lo_x = hi_x;
+        hi_x = tmp;
+    }
+    float lo_y = inv_d.y * (mn[1] - o.y);
+    float hi_y = inv_d.y * (mx[1] - o.y);
+    if (lo_y > hi_y) {
+        const float tmp = lo_y;
+        lo_y = hi_y;
+        hi_y = tmp;
+    }
+    float lo_z = inv_d.z * (mn[2] - o.z);
+    float hi_z = inv_d.z * (mx[2] - o.z);
+    if (lo_z > hi_z) {
+        const float tmp = lo_z;
+        lo_z = hi_z;
+        hi_z = tmp;
+    }
+    float tmin = lo_x > lo_y ? lo_x : lo_y;
+    if (lo_z > tmin) {
+        tmin = lo_z;
+    }
+    float tmax = hi_x < hi_y ? hi_x : hi_y;
+    if (hi_z < tmax) {
+        tmax = hi_z;
+    }
+    tmax *= 1.00000024f;
+
+    out_dist = tmin;
+    return tmin <= tmax && tmin <= t && tmax > 0;
+}
+
+// Ordered DFS over the bvh2 pool.  `leaf(word)` handles one leaf word and returns true to stop the whole
+// walk (any-hit early out).  `t_ref` is read at every node so that hits found in earlier leaves prune.
+// Loop structure == CoreRef.cpp:1958-2014 / 2439-2490.
+template <class Stack, class LeafFn>
+RT_HD bool walk_bvh2(const rayhip_bvh2_node *nodes, const uint32_t root_index, const f3 ro, const f3 inv_d,
+                     const float &t_ref, Stack &st, TravCount *cnt, LeafFn &&leaf) {
+    const uint32_t base = st.size;
+    st.push(0x1fffffffu);
+
+    uint32_t cur = root_index;
+    while (st.size > base) {
+        uint32_t leaf_node = 0;
+        while (st.size > base && (cur & BVH2_PRIM_COUNT_BITS) == 0) {
+            const rayhip_bvh2_node &n = nodes[cur];
+            if (cnt) {
+                ++cnt->nodes;
+            }
+            uint32_t children[2] = {n.left_child, n.right_child};
+
+            const float ch0_min[3] = {n.ch_data0[0], n.ch_data0[2], n.ch_data2[0]};
+            const float ch0_max[3] = {n.ch_data0[1], n.ch_data0[3], n.ch_data2[1]};
+            const float ch1_min[3] = {n.ch_data1[0], n.ch_data1[2], n.ch_data2[2]};
+            const float ch1_max[3] = {n.ch_data1[1], n.ch_data1[3], n.ch_data2[3]};
+
+            float ch0_dist, ch1_dist;
+            const bool ch0_res = bbox_test(ro, inv_d, t_ref, ch0_min, ch0_max, ch0_dist);
+            const bool ch1_res = bbox_test(ro, inv_d, t_ref, ch1_min, ch1_max, ch1_dist);
+
+            if (!ch0_res && !ch1_res) {
+                cur = st.pop();
+            } else {
+                cur = ch0_res ? children[0] : children[1];
+                if (ch0_res && ch1_res) {
+                    if (ch1_dist < ch0_dist) {
+                        const uint32_t temp = cur;
+                        cur = children[1];
+                        children[1] = temp;
+                    }
+                    st.push(children[1]);
+                }
+            }
+            if ((cur & BVH2_PRIM_COUNT_BITS) != 0 && (leaf_node & BVH2_PRIM_COUNT_BITS) == 0) {
+                leaf_node = cur;
+                cur = st.pop();
+            }
+            if ((leaf_node & BVH2_PRIM_COUNT_BITS) != 0) {
+                break;
+            }
+        }
+
+        while ((leaf_node & BVH2_PRIM_COUNT_BITS) != 0) {
+            if (leaf(leaf_node)) {
+                st.size = base;
+                return true;
+            }
+            leaf_node = cur;
+            if ((cur & BVH2_PRIM_COUNT_BITS) != 0) {
+                cur = st.pop();
+            }
+        }
+    }
+    st.size = base; // (already true; keeps the invariant explicit)
+    return false;
+}
+
+// CoreRef.cpp:1798-1817
+RT_HD bool intersect_tris_closest(const f3 ro, const f3 rd, const rayhip_tri_accel *tris, const int tri_start,
+                                  const int tri_end, const int obj_index, Hit &out_inter) {
+    Hit inter;
+    inter.obj_index = obj_index;
+    inter.prim_index = 0;
+    inter.t = out_inter.t;
+    inter.u = 0.0f;
+    inter.v = -1.0f;
+    for (int i = tri_start; i < tri_end; ++i) {
+        intersect_tri(ro, rd, tris[i], uint32_t(i), inter);
+    }
+    const bool hit = inter.v >= 0.0f;
+    out_inter.obj_index = hit ? inter.obj_index : out_inter.obj_index;
+    out_inter.prim_index = hit ? inter.prim_index : out_inter.prim_index;
+    out_inter.t = inter.t; // already contains min value
+    out_inter.u = hit ? inter.u : out_inter.u;
+    out_inter.v = hit ? inter.v : out_inter.v;
+    return hit;
+}
+
+// CoreRef.cpp:1840-1863
+RT_HD bool intersect_tris_any(const f3 ro, const f3 rd, const rayhip_tri_accel *tris,
+                              const rayhip_tri_mat_data *materials, const uint32_t *indices, const int tri_start,
+                              const int tri_end, const int obj_index, Hit &out_inter) {
+    Hit inter;
+    inter.obj_index = obj_index;
+    inter.prim_index = 0;
+    inter.t = out_inter.t;
+    inter.u = 0.0f;
+    inter.v = -1.0f;
+    for (int i = tri_start; i < tri_end; ++i) {
+        intersect_tri(ro, rd, tris[i], uint32_t(i), inter);
+        if (inter.v >= 0.0f && ((inter.prim_index > 0 && (materials[indices[i]].front_mi & MATERIAL_SOLID_BIT)) ||
+                                (inter.prim_index < 0 && (materials[indices[i]].back_mi & MATERIAL_SOLID_BIT)))) {
+            break;
+        }
+    }
+    const bool hit = inter.v >= 0.0f;
+    out_inter.obj_index = hit ? inter.obj_index : out_inter.obj_index;
+    out_inter.prim_index = hit ? inter.prim_index : out_inter.prim_index;
+    out_inter.t = inter.t;
+    out_inter.u = hit ? inter.u : out_inter.u;
+    out_inter.v = hit ? inter.v : out_inter.v;
+    return hit;
+}
+
+// Traverse_TLAS_WithStack_ClosestHit(bvh2), CoreRef.cpp:1943-2025 (+ BLAS :2428-2493)
+template <class Stack>
+RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const uint32_t ray_flags,
+                            const uint32_t root_index, Hit &inter, Stack &st, TravCount *cnt) {
+    bool res = false;
+    const f3 inv_d = safe_invert(rd);
+
+    walk_bvh2(sc.nodes, root_index, ro, inv_d, inter.t, st, cnt, [&](const uint32_t leaf_node) {
+        const uint32_t mi_index = (leaf_node & BVH2_PRIM_INDEX_BITS);
+        const rayhip_mesh_instance &mi = sc.mesh_instances[mi_index];
+        if ((mi.ray_visibility & ray_flags) != 0) {
+            if (cnt) {
+                ++cnt->instances;
+            }
+            const f3 _ro = transform_point(ro, mi.inv_xform);
+            const f3 _rd = transform_direction(rd, mi.inv_xform);
+            const f3 _inv_d = safe_invert(_rd);
+            walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, [&](const uint32_t blas_leaf) {
+                const int tri_start = int(blas_leaf & BVH2_PRIM_INDEX_BITS),
+                          tri_end = int(tri_start + ((blas_leaf & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
+                if (cnt) {
+                    cnt->tris += uint32_t(tri_end - tri_start);
+                }
+                res |= intersect_tris_closest(_ro, _rd, sc.tris, tri_start, tri_end, int(mi_index), inter);
+                return false;
+            });
+        }
+        return false;
+    });
+
+    // resolve primitive index indirection (note: runs on misses too, exactly like the reference)
+    if (inter.prim_index < 0) {
+        inter.prim_index = -int(sc.tri_indices[-inter.prim_index - 1]) - 1;
+    } else {
+        inter.prim_index = int(sc.tri_indices[inter.prim_index]);
+    }
+    return res;
+}
+
+// Traverse_TLAS_WithStack_AnyHit(bvh2), CoreRef.cpp:2193-2280 (+ BLAS :2619-2693); returns "solid hit found"
+template <class Stack>
+RT_HD bool traverse_any(const SceneView &sc, const f3 ro, const f3 rd, const int ray_type, const uint32_t root_index,
+                        Hit &inter, Stack &st, TravCount *cnt) {
+    const uint32_t ray_vismask = (1u << ray_type);
+    const f3 inv_d = safe_invert(rd);
+
+    const bool solid = walk_bvh2(sc.nodes, root_index, ro, inv_d, inter.t, st, cnt, [&](const uint32_t leaf_node) {
+        const uint32_t mi_index = (leaf_node & BVH2_PRIM_INDEX_BITS);
+        const rayhip_mesh_instance &mi = sc.mesh_instances[mi_index];
+        if ((mi.ray_visibility & ray_vismask) != 0) {
+            if (cnt) {
+                ++cnt->instances;
+            }
+            const f3 _ro = transform_point(ro, mi.inv_xform);
+            const f3 _rd = transform_direction(rd, mi.inv_xform);
+            const f3 _inv_d = safe_invert(_rd);
+            return walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, [&](const uint32_t blas_leaf) {
+                const int tri_start = int(blas_leaf & BVH2_PRIM_INDEX_BITS),
+                          tri_end = int(tri_start + ((blas_leaf & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
+                if (cnt) {
+                    cnt->tris += uint32_t(tri_end - tri_start);
+                }
+                const bool hit_found = intersect_tris_any(_ro, _rd, sc.tris, sc.tri_materials, sc.tri_indices,
+                                                          tri_start, tri_end, int(mi_index), inter);
+                if (hit_found) {
+                    const bool is_backfacing = inter.prim_index < 0;
+                    const uint32_t prim_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
+                    const rayhip_tri_mat_data md = sc.tri_materials[sc.tri_indices[prim_index]];
+                    if ((!is_backfacing && (md.front_mi & MATERIAL_SOLID_BIT)) ||
+                        (is_backfacing && (md.back_mi & MATERIAL_SOLID_BIT))) {
+                        return true;
+                    }
+                }
+                return false;
+            });
+        }
+        return false;
+    });
+    if (solid) {
+        return true; // reference returns before the index indirection (CoreRef.cpp:2258-2260)
+    }
+    if (inter.prim_index < 0) {
+        inter.prim_index = -int(sc.tri_indices[-inter.prim_index - 1]) - 1;
+    } else {
+        inter.prim_index = int(sc.tri_indices[inter.prim_index]);
+    }
+    return false;
+}
+
+struct TraceParams {
+    int min_transp_depth, max_transp_depth;
+    uint32_t rand_seed;
+    int iteration;
+    uint32_t root_index;
+};
+
+// Ref::IntersectScene, closest hit + transparency/mix resolve loop.  CoreRef.cpp:3041-3158.
+// In: r (o,d,c,depth,xy), inter (t preset by the caller: clip range for primary rays, MAX_DIST otherwise).
+// Out: inter; r.c and r.depth are updated when transparent surfaces are crossed.
+template <class Stack>
+RT_HD void intersect_scene_closest(const SceneView &sc, const TraceParams &tp, Ray &r, Hit &inter, Stack &st,
+                                   TravCount *cnt) {
+    const f3 rd = r.d;
+    f3 ro = r.o;
+
+    const uint32_t ray_flags = (1u << get_ray_type(r.depth));
+
+    const uint32_t px_hash = hash(r.xy);
+    const uint32_t rand_hash = hash_combine(px_hash, tp.rand_seed);
+
+    uint32_t rand_dim = RAND_DIM_BASE_COUNT + get_total_depth(r.depth) * RAND_DIM_BOUNCE_COUNT;
+    while (true) {
+        const float t_val = inter.t;
+
+        const bool hit_found = traverse_closest(sc, ro, rd, ray_flags, tp.root_index, inter, st, cnt);
+        if (!hit_found) {
+            break;
+        }
+
+        const bool is_backfacing = (inter.prim_index < 0);
+        const uint32_t tri_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
+
+        const rayhip_tri_mat_data md = sc.tri_materials[tri_index];
+        if ((!is_backfacing && (md.front_mi & MATERIAL_SOLID_BIT)) || (is_backfacing && (md.back_mi & MATERIAL_SOLID_BIT))) {
+            break; // solid hit found
+        }
+
+        const rayhip_material *mat =
+            is_backfacing ? &sc.materials[md.back_mi & MATERIAL_INDEX_BITS] : &sc.materials[md.front_mi & MATERIAL_INDEX_BITS];
+
+        const rayhip_vertex &v1 = sc.vertices[sc.vtx_indices[tri_index * 3 + 0]];
+        const rayhip_vertex &v2 = sc.vertices[sc.vtx_indices[tri_index * 3 + 1]];
+        const rayhip_vertex &v3 = sc.vertices[sc.vtx_indices[tri_index * 3 + 2]];
+
+        const float w = 1.0f - inter.u - inter.v;
+        const f2 uvs = mk2(v1.t[0], v1.t[1]) * w + mk2(v2.t[0], v2.t[1]) * inter.u + mk2(v3.t[0], v3.t[1]) * inter.v;
+
+        const f2 mix_term_rand = get_scrambled_2d_rand(rand_dim + RAND_DIM_BSDF_PICK, rand_hash, tp.iteration - 1, sc.pmj);
+        const f2 tex_rand = get_scrambled_2d_rand(rand_dim + RAND_DIM_TEX, rand_hash, tp.iteration - 1, sc.pmj);
+
+        float trans_r = mix_term_rand.x;
+
+        // resolve mix material
+        while (mat->type == NODE_MIX) {
+            float mix_val = mat->tangent_rotation_or_strength;
+            const uint32_t base_texture = mat->textures[BASE_TEXTURE];
+            if (base_texture != 0xffffffff) {
+                const f4 tex_color = sample_color(sc, base_texture, uvs, 0, tex_rand);
+                mix_val *= tex_color.x;
+            }
+            if (trans_r > mix_val) {
+                mat = &sc.materials[mat->textures[MIX_MAT1]];
+                trans_r = safe_div_pos(trans_r - mix_val, 1.0f - mix_val);
+            } else {
+                mat = &sc.materials[mat->textures[MIX_MAT2]];
+                trans_r = safe_div_pos(trans_r, mix_val);
+            }
+        }
+
+        if (mat->type != NODE_TRANSPARENT) {
+            break;
+        }
+
+        const bool can_terminate_path = get_transp_depth(r.depth) > tp.min_transp_depth;
+
+        const float lum_ = fmaxf(r.c.x, fmaxf(r.c.y, r.c.z));
+        const float p = mix_term_rand.y;
+        const float q = can_terminate_path ? fmaxf(0.05f, 1.0f - lum_) : 0.0f;
+        if (p < q || lum_ == 0.0f || get_transp_depth(r.depth) + 1 >= tp.max_transp_depth) {
+            // terminate ray
+            r.c = {0.0f, 0.0f, 0.0f};
+            break;
+        }
+
+        r.c.x *= mat->base_color[0] / (1.0f - q);
+        r.c.y *= mat->base_color[1] / (1.0f - q);
+        r.c.z *= mat->base_color[2] / (1.0f - q);
+
+        const float t = inter.t + HIT_BIAS;
+        ro += rd * t;
+
+        // discard current intersection
+        inter.v = -1.0f;
+        inter.t = t_val - inter.t;
+
+        r.depth += pack_ray_depth(0, 0, 0, 1);
+        rand_dim += RAND_DIM_BOUNCE_COUNT;
+    }
+
+    inter.t += length(r.o - ro);
+}
+
+// Ref::IntersectScene(shadow_ray_t): visibility * throughput towards the light.  CoreRef.cpp:3160-3262.
+template <class Stack>
+RT_HD f3 intersect_scene_shadow(const SceneView &sc, const TraceParams &tp, const ShadowRay &r, Stack &st,
+                                TravCount *cnt) {
+    const f3 rd = r.d;
+    f3 ro = r.o;
+    f3 rc = r.c;
+    int depth = get_transp_depth(r.depth);
+
+    const uint32_t px_hash = hash(r.xy);
+    const uint32_t rand_hash = hash_combine(px_hash, tp.rand_seed);
+
+    uint32_t rand_dim = RAND_DIM_BASE_COUNT + get_total_depth(r.depth) * RAND_DIM_BOUNCE_COUNT;
+
+    float dist = r.dist > 0.0f ? r.dist : MAX_DIST;
+    while (dist > HIT_BIAS) {
+        Hit inter = make_hit();
+        inter.t = dist;
+
+        const bool solid_hit = traverse_any(sc, ro, rd, RAY_TYPE_SHADOW, tp.root_index, inter, st, cnt);
+
+        if (solid_hit || depth > tp.max_transp_depth) {
+            rc = {0.0f, 0.0f, 0.0f};
+        }
+        if (solid_hit || depth > tp.max_transp_depth || inter.v < 0.0f) {
+            break;
+        }
+
+        const bool is_backfacing = (inter.prim_index < 0);
+        const uint32_t tri_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
+
+        const uint32_t mat_index = is_backfacing ? (sc.tri_materials[tri_index].back_mi & MATERIAL_INDEX_BITS)
+                                                 : (sc.tri_materials[tri_index].front_mi & MATERIAL_INDEX_BITS);
+
+        const rayhip_vertex &v1 = sc.vertices[sc.vtx_indices[tri_index * 3 + 0]];
+        const rayhip_vertex &v2 = sc.vertices[sc.vtx_indices[tri_index * 3 + 1]];
+        const rayhip_vertex &v3 = sc.vertices[sc.vtx_indices[tri_index * 3 + 2]];
+
+        const float w = 1.0f - inter.u - inter.v;
+        const f2 sh_uvs = mk2(v1.t[0], v1.t[1]) * w + mk2(v2.t[0], v2.t[1]) * inter.u + mk2(v3.t[0], v3.t[1]) * inter.v;
+
+        const f2 tex_rand = get_scrambled_2d_rand(rand_dim + RAND_DIM_TEX, rand_hash, tp.iteration - 1, sc.pmj);
+
+        struct {
+            uint32_t index;
+            float weight;
+        } stack[16];
+        int stack_size = 0;
+
+        stack[stack_size].index = mat_index;
+        stack[stack_size++].weight = 1.0f;
+
+        f3 throughput = {0.0f, 0.0f, 0.0f};
+
+        while (stack_size--) {
+            const rayhip_material *mat = &sc.materials[stack[stack_size].index];
+            const float weight = stack[stack_size].weight;
+
+            // resolve mix material
+            if (mat->type == NODE_MIX) {
+                float mix_val = mat->tangent_rotation_or_strength;
+                const uint32_t base_texture = mat->textures[BASE_TEXTURE];
+                if (base_texture != 0xffffffff) {
+                    const f4 tex_color = sample_color(sc, base_texture, sh_uvs, 0, tex_rand);
+                    mix_val *= tex_color.x;
+                }
+                stack[stack_size].index = mat->textures[MIX_MAT1];
+                stack[stack_size++].weight = weight * (1.0f - mix_val);
+                stack[stack_size].index = mat->textures[MIX_MAT2];
+                stack[stack_size++].weight = weight * mix_val;
+            } else if (mat->type == NODE_TRANSPARENT) {
+                throughput += weight * mk3(mat->base_color);
+            }
+        }
+
+        rc *= throughput;
+        if (lum(rc) < FLT_EPS_) {
+            break;
+        }
+
+        const float t = inter.t + HIT_BIAS;
+        ro += rd * t;
+        dist -= t;
+
+        ++depth;
+        rand_dim += RAND_DIM_BOUNCE_COUNT;
+    }
+
+    return rc;
+}
+
+} // namespace rt

@@ -1,0 +1,243 @@
+"""ctypes binding of include/rayhip.h -- the C-ABI of librayhip.so (hand-written HIP kernels for gfx950).
+
+`Context` is a thin object over the rayhip_* entry points; it takes scenes as serialised blobs
+(ray_amd/csrc/scene_blob.h) or as rayhip_scene_desc and returns numpy arrays.  There is no CPU path: creating a
+Context without a GPU raises.  (`prefix`/`lib_path` exist so that tests can point the same wrapper at
+tests/hostsim, the host-compiled copy of the kernel sources used to debug parity without a GPU.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+RAYHIP_LIB = os.path.join(_HERE, "csrc", "_build", "librayhip.so")
+
+BUF_FINAL, BUF_RAW, BUF_BASE_COLOR, BUF_DEPTH_NORMALS = 0, 1, 2, 3
+FLAG_SORT_RAYS = 1 << 0
+FLAG_COUNT_TRAVERSAL = 1 << 1
+
+
+class PassSettings(C.Structure):
+    _fields_ = [
+        ("max_diff_depth", C.c_uint8), ("max_spec_depth", C.c_uint8), ("max_refr_depth", C.c_uint8),
+        ("max_transp_depth", C.c_uint8), ("max_total_depth", C.c_uint8), ("min_total_depth", C.c_uint8),
+        ("min_transp_depth", C.c_uint8), ("flags", C.c_uint8),
+        ("clamp_direct", C.c_float), ("clamp_indirect", C.c_float), ("min_samples", C.c_int32),
+        ("variance_threshold", C.c_float), ("regularize_alpha", C.c_float),
+    ]
+
+
+class Camera(C.Structure):  # rayhip_camera == Ray::camera_t
+    _fields_ = [
+        ("type", C.c_uint8), ("filter", C.c_uint8), ("view_transform", C.c_uint8), ("ltype", C.c_uint8),
+        ("filter_width", C.c_float),
+        ("fov", C.c_float), ("exposure", C.c_float), ("gamma", C.c_float), ("sensor_height", C.c_float),
+        ("focus_distance", C.c_float), ("focal_length", C.c_float), ("fstop", C.c_float),
+        ("lens_rotation", C.c_float), ("lens_ratio", C.c_float),
+        ("lens_blades", C.c_int32),
+        ("clip_start", C.c_float), ("clip_end", C.c_float),
+        ("origin", C.c_float * 3), ("fwd", C.c_float * 3), ("side", C.c_float * 3), ("up", C.c_float * 3),
+        ("shift", C.c_float * 2),
+        ("mi_index", C.c_uint32), ("uv_index", C.c_uint32),
+        ("pass_settings", PassSettings),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("t", C.c_ulonglong * 11)]
+    NAMES = ("primary_ray_gen", "primary_trace", "primary_shade", "primary_shadow", "secondary_sort",
+             "secondary_trace", "secondary_shade", "secondary_shadow", "denoise", "cache_update", "cache_resolve")
+
+    def as_dict(self):
+        return {n: int(self.t[i]) for i, n in enumerate(self.NAMES)}
+
+
+class TravCounters(C.Structure):
+    _fields_ = [("rays", C.c_ulonglong), ("nodes", C.c_ulonglong), ("tris", C.c_ulonglong), ("instances", C.c_ulonglong)]
+
+    def as_dict(self):
+        return {"rays": int(self.rays), "nodes": int(self.nodes), "tris": int(self.tris), "instances": int(self.instances)}
+
+
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("pdf", "<f4"), ("c", "<f4", 3), ("ior", "<f4", 4),
+                      ("cone_width", "<f4"), ("cone_spread", "<f4"), ("xy", "<u4"), ("depth", "<u4")])
+SHADOW_RAY_DTYPE = np.dtype([("o", "<f4", 3), ("depth", "<u4"), ("d", "<f4", 3), ("dist", "<f4"), ("c", "<f4", 3),
+                             ("xy", "<u4")])
+HIT_DTYPE = np.dtype([("obj_index", "<i4"), ("prim_index", "<i4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYPE.itemsize == 20
+
+# every symbol include/rayhip.h declares (tests check that the built library exports all of them)
+ENTRY_POINTS = (
+    "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
+    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "readback", "readback_device", "set_raw_device",
+    "sync", "get_trav_counters", "get_trav_timing", "k_generate_primary_rays", "k_intersect_closest",
+    "k_intersect_shadow", "k_scrambled_rand",
+)
+
+
+def _aligned_copy(buf: bytes, align: int = 64) -> np.ndarray:
+    raw = np.empty(len(buf) + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    out = raw[off:off + len(buf)]
+    out[:] = np.frombuffer(buf, dtype=np.uint8)
+    return out
+
+
+class Library:
+    def __init__(self, lib_path: str = RAYHIP_LIB, prefix: str = "rayhip_"):
+        if not os.path.exists(lib_path):
+            raise RuntimeError(f"{lib_path} is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        self.lib = C.CDLL(lib_path)
+        self.prefix = prefix
+        vp = C.c_void_p
+        f = self.fn
+        f("last_error").restype = C.c_char_p
+        f("ctx_create").argtypes = [C.c_int, C.POINTER(vp)]
+        f("ctx_destroy").argtypes = [vp]
+        f("ctx_destroy").restype = None
+        f("ctx_device_name").argtypes = [vp, C.c_char_p, C.c_int]
+        f("upload_static").argtypes = [vp, vp, C.c_uint32]
+        f("resize").argtypes = [vp, C.c_int, C.c_int]
+        f("clear").argtypes = [vp, C.POINTER(C.c_float * 4)]
+        f("scene_upload_blob").argtypes = [vp, vp, C.c_size_t, C.POINTER(Camera)]
+        f("set_filter_table").argtypes = [vp, vp, C.c_int]
+        f("render").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_uint32, C.POINTER(Stats)]
+        f("readback").argtypes = [vp, C.c_int, vp, C.c_int]
+        f("sync").argtypes = [vp]
+        f("get_trav_counters").argtypes = [vp, C.POINTER(TravCounters * 2), C.c_int]
+        f("k_generate_primary_rays").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, vp, vp, C.POINTER(C.c_int)]
+        f("k_intersect_closest").argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int, C.c_int, C.POINTER(TravCounters)]
+        f("k_intersect_shadow").argtypes = [vp, C.POINTER(Camera), vp, C.c_int, C.c_int, vp, C.POINTER(TravCounters)]
+        f("k_scrambled_rand").argtypes = [vp, vp, vp, vp, C.c_int, vp]
+        if prefix == "rayhip_":
+            f("readback_device").argtypes = [vp, C.c_int, vp, C.c_int]
+            f("set_raw_device").argtypes = [vp, vp, C.c_int, C.POINTER(Camera)]
+            f("get_trav_timing").argtypes = [vp, C.POINTER(C.c_double * 2), C.POINTER(C.c_ulonglong * 2), C.c_int]
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def device_count(self) -> int:
+        return int(self.fn("device_count")())
+
+    def check(self, status: int):
+        if status != 0:
+            raise RuntimeError(f"{self.prefix}*: " + self.fn("last_error")().decode())
+
+
+class Context:
+    """One rayhip context = one GPU (rayhip.h).  Mirrors what RendererHIP holds on the C++ side."""
+
+    def __init__(self, device: int = 0, library: Library = None):
+        self.L = library or Library()
+        self._ctx = C.c_void_p()
+        self.L.check(self.L.fn("ctx_create")(device, C.byref(self._ctx)))
+        self.w = self.h = 0
+        self.cam = None
+        self._blob = None
+
+    def close(self):
+        if self._ctx:
+            self.L.fn("ctx_destroy")(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self.L.check(self.L.fn("ctx_device_name")(self._ctx, buf, 256))
+        return buf.value.decode()
+
+    def upload_static(self, pmj: np.ndarray):
+        pmj = np.ascontiguousarray(pmj, dtype=np.uint32)
+        self.L.check(self.L.fn("upload_static")(self._ctx, pmj.ctypes.data, pmj.size))
+
+    def resize(self, w: int, h: int):
+        self.L.check(self.L.fn("resize")(self._ctx, w, h))
+        self.w, self.h = w, h
+
+    def clear(self, rgba=(0.0, 0.0, 0.0, 0.0)):
+        v = (C.c_float * 4)(*rgba)
+        self.L.check(self.L.fn("clear")(self._ctx, C.byref(v)))
+
+    def upload_scene_blob(self, blob: bytes) -> Camera:
+        self._blob = _aligned_copy(blob)
+        cam = Camera()
+        self.L.check(self.L.fn("scene_upload_blob")(self._ctx, self._blob.ctypes.data, self._blob.size, C.byref(cam)))
+        self.cam = cam
+        return cam
+
+    def render(self, iteration: int, rect=None, cam: Camera = None, flags: int = 0, stats: Stats = None):
+        rect = (0, 0, self.w, self.h) if rect is None else rect
+        r = (C.c_int * 4)(*rect)
+        cam = cam or self.cam
+        self.L.check(self.L.fn("render")(self._ctx, C.byref(cam), C.byref(r), iteration, flags,
+                                         C.byref(stats) if stats is not None else None))
+
+    def readback(self, which: int = BUF_RAW) -> np.ndarray:
+        out = np.empty((self.h, self.w, 4), dtype=np.float32)
+        self.L.check(self.L.fn("readback")(self._ctx, which, out.ctypes.data, self.w))
+        return out
+
+    def readback_device(self, which: int, device_ptr: int, pitch_px: int = None):
+        self.L.check(self.L.fn("readback_device")(self._ctx, which, C.c_void_p(device_ptr), pitch_px or self.w))
+
+    def set_raw_device(self, device_ptr: int, pitch_px: int = None, cam: Camera = None):
+        cam = cam or self.cam
+        self.L.check(self.L.fn("set_raw_device")(self._ctx, C.c_void_p(device_ptr), pitch_px or self.w, C.byref(cam)))
+
+    def sync(self):
+        self.L.check(self.L.fn("sync")(self._ctx))
+
+    def trav_counters(self, reset=True):
+        out = (TravCounters * 2)()
+        self.L.check(self.L.fn("get_trav_counters")(self._ctx, C.byref(out), int(reset)))
+        return out[0].as_dict(), out[1].as_dict()
+
+    def trav_timing(self, reset=True):
+        ms = (C.c_double * 2)()
+        n = (C.c_ulonglong * 2)()
+        self.L.check(self.L.fn("get_trav_timing")(self._ctx, C.byref(ms), C.byref(n), int(reset)))
+        return (float(ms[0]), int(n[0])), (float(ms[1]), int(n[1]))
+
+    # ---- kernel-level hooks ------------------------------------------------------------------------------
+    def k_generate_primary_rays(self, iteration: int, rect=None, cam: Camera = None):
+        rect = (0, 0, self.w, self.h) if rect is None else rect
+        n = rect[2] * rect[3]
+        rays = np.zeros(n, dtype=RAY_DTYPE)
+        hits = np.zeros(n, dtype=HIT_DTYPE)
+        cnt = C.c_int(0)
+        r = (C.c_int * 4)(*rect)
+        self.L.check(self.L.fn("k_generate_primary_rays")(self._ctx, C.byref(cam or self.cam), C.byref(r), iteration,
+                                                          rays.ctypes.data, hits.ctypes.data, C.byref(cnt)))
+        return rays[:cnt.value], hits[:cnt.value]
+
+    def k_intersect_closest(self, rays: np.ndarray, hits: np.ndarray, iteration: int, cam: Camera = None):
+        rays = np.ascontiguousarray(rays.copy())
+        hits = np.ascontiguousarray(hits.copy())
+        tc = TravCounters()
+        self.L.check(self.L.fn("k_intersect_closest")(self._ctx, C.byref(cam or self.cam), rays.ctypes.data,
+                                                      hits.ctypes.data, len(rays), iteration, C.byref(tc)))
+        return rays, hits, tc.as_dict()
+
+    def k_intersect_shadow(self, rays: np.ndarray, iteration: int, cam: Camera = None):
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros((len(rays), 4), dtype=np.float32)
+        tc = TravCounters()
+        self.L.check(self.L.fn("k_intersect_shadow")(self._ctx, C.byref(cam or self.cam), rays.ctypes.data, len(rays),
+                                                     iteration, out.ctypes.data, C.byref(tc)))
+        return out, tc.as_dict()
+
+    def k_scrambled_rand(self, dims, seeds, samples):
+        dims = np.ascontiguousarray(dims, dtype=np.uint32)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        out = np.zeros((len(dims), 2), dtype=np.float32)
+        self.L.check(self.L.fn("k_scrambled_rand")(self._ctx, dims.ctypes.data, seeds.ctypes.data, samples.ctypes.data,
+                                                   len(dims), out.ctypes.data))
+        return out

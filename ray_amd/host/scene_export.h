@@ -1,0 +1,167 @@
+// scene_export.h -- gathers the flat arrays of a finalized Ray::Cpu::Scene into a rayhip_scene_desc.
+//
+// This is the HIP backend's counterpart of the scene_data_t gathering every CPU RenderScene does
+// (reference internal/RendererCPU.h:390-413) and of SceneVK's buffer uploads (internal/SceneGPU.h:62-104).
+// The reference's host-side scene code (AddMesh -> PreprocessMesh -> ConvertToBVH2, RebuildTLAS,
+// RebuildLightTree: SceneCPU.cpp:342-546,928-1015,1214-1521) is reused unchanged, as SURVEY.md section 2 /
+// section 8(a18) prescribes; SceneHIP derives from Cpu::Scene and calls this after Finalize.
+//
+// Compiles only next to the reference sources (includes internal/SceneCPU.h).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "internal/SceneCPU.h"
+
+#include "../../include/rayhip.h"
+
+namespace Ray {
+namespace Hip {
+
+static_assert(sizeof(rayhip_tri_accel) == sizeof(tri_accel_t), "layout");
+static_assert(sizeof(rayhip_bvh2_node) == sizeof(bvh2_node_t), "layout");
+static_assert(sizeof(rayhip_vertex) == sizeof(vertex_t), "layout");
+static_assert(sizeof(rayhip_mesh_instance) == sizeof(mesh_instance_t), "layout");
+static_assert(sizeof(rayhip_tri_mat_data) == sizeof(tri_mat_data_t), "layout");
+static_assert(sizeof(rayhip_material) == sizeof(material_t), "layout");
+static_assert(offsetof(rayhip_material, ior) == offsetof(material_t, ior), "layout");
+static_assert(offsetof(rayhip_material, normal_map_strength_unorm) == offsetof(material_t, normal_map_strength_unorm), "layout");
+static_assert(sizeof(rayhip_light) == sizeof(light_t), "layout");
+static_assert(offsetof(rayhip_light, params) == offsetof(light_t, sph), "layout");
+static_assert(sizeof(rayhip_light_cwbvh_node) == sizeof(light_cwbvh_node_t), "layout");
+static_assert(offsetof(rayhip_light_cwbvh_node, flux) == offsetof(light_cwbvh_node_t, flux), "layout");
+static_assert(sizeof(rayhip_camera) == sizeof(camera_t), "layout");
+static_assert(offsetof(rayhip_camera, pass_settings) == offsetof(camera_t, pass_settings), "layout");
+static_assert(offsetof(rayhip_camera, origin) == offsetof(camera_t, origin), "layout");
+static_assert(sizeof(rayhip_pass_settings) == sizeof(pass_settings_t), "layout");
+static_assert(sizeof(rayhip_stats) == sizeof(RendererBase::stats_t), "layout");
+
+// Owns the converted texture pool; every other pointer in `desc` aliases the scene's own storage and stays
+// valid until the next scene mutation.
+struct FlatScene {
+    rayhip_scene_desc desc = {};
+    std::vector<rayhip_texture> textures;
+    std::vector<uint32_t> texels;
+};
+
+// Access to Cpu::Scene / SceneCommon protected members through a derived class (legal: the member pointers
+// are formed inside a member of the derived class and have type `T Cpu::Scene::*`).
+class SceneAccess : public Cpu::Scene {
+    SceneAccess() = delete;
+
+    template <typename S, int N> static void export_storage(const S &st, FlatScene &out) {
+        for (int i = 0; i < st.img_count(); ++i) {
+            rayhip_texture t = {};
+            int prev_res[2] = {-1, -1};
+            for (int lod = 0; lod < NUM_MIP_LEVELS; ++lod) {
+                int res[2];
+                st.GetIRes(i, lod, res);
+                t.width[lod] = uint32_t(res[0]), t.height[lod] = uint32_t(res[1]);
+                if (lod && res[0] == prev_res[0] && res[1] == prev_res[1]) {
+                    // the storage aliases missing mip levels to the last real one (TextureStorageCPU.cpp:244-249)
+                    t.offset[lod] = t.offset[lod - 1];
+                    continue;
+                }
+                t.offset[lod] = uint32_t(out.texels.size());
+                for (int y = 0; y < res[1]; ++y) {
+                    for (int x = 0; x < res[0]; ++x) {
+                        const auto c = st.Get(i, x, y, lod);
+                        // same channel replication as TexStorageSwizzled::Fetch (TextureStorageCPU.h:293-305)
+                        uint32_t v[4];
+                        for (int k = 0; k < N; ++k) {
+                            v[k] = c.v[k];
+                        }
+                        for (int k = N; k < 4; ++k) {
+                            v[k] = v[N - 1];
+                        }
+                        out.texels.push_back(v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24));
+                    }
+                }
+                prev_res[0] = res[0], prev_res[1] = res[1];
+            }
+            out.textures.push_back(t);
+        }
+    }
+
+  public:
+    static const camera_t &CurrentCamera(const Cpu::Scene &_s) {
+        const auto &s = static_cast<const SceneAccess &>(_s);
+        return s.cams_[s.current_cam_._index];
+    }
+    static std::shared_timed_mutex &Mutex(const Cpu::Scene &_s) { return static_cast<const SceneAccess &>(_s).mtx_; }
+
+    // Caller must hold at least a shared lock on the scene.
+    static void Export(const Cpu::Scene &_s, FlatScene &out) {
+        // NOTE: the cast never touches SceneAccess-specific state (there is none); it only names the members
+        const auto &s = static_cast<const SceneAccess &>(_s);
+        if (s.use_wide_bvh_) {
+            throw std::runtime_error("SceneHIP needs the 2-wide BVH (create the scene with use_wide_bvh=false)");
+        }
+        rayhip_scene_desc &d = out.desc;
+        d = {};
+#define SPARSE(field, member, type)                                                                                    \
+    d.field = reinterpret_cast<const type *>(s.member.data());                                                        \
+    d.field##_count = s.member.capacity();
+        SPARSE(nodes, nodes_, rayhip_bvh2_node)
+        SPARSE(tris, tris_, rayhip_tri_accel)
+        SPARSE(tri_indices, tri_indices_, uint32_t)
+        SPARSE(tri_materials, tri_materials_, rayhip_tri_mat_data)
+        SPARSE(materials, materials_, rayhip_material)
+        SPARSE(vertices, vertices_, rayhip_vertex)
+        SPARSE(vtx_indices, vtx_indices_, uint32_t)
+        SPARSE(mesh_instances, mesh_instances_, rayhip_mesh_instance)
+        SPARSE(lights, lights_, rayhip_light)
+#undef SPARSE
+        d.li_indices = s.li_indices_.data();
+        d.li_indices_count = uint32_t(s.li_indices_.size());
+        d.light_cwnodes = reinterpret_cast<const rayhip_light_cwbvh_node *>(s.light_cwnodes_.data());
+        d.light_cwnodes_count = uint32_t(s.light_cwnodes_.size());
+
+        out.textures.clear(), out.texels.clear();
+        d.tex_table[0] = uint32_t(out.textures.size());
+        export_storage<Cpu::TexStorageRGBA, 4>(s.tex_storage_rgba_, out);
+        d.tex_table[1] = uint32_t(out.textures.size());
+        export_storage<Cpu::TexStorageRGB, 3>(s.tex_storage_rgb_, out);
+        d.tex_table[2] = uint32_t(out.textures.size());
+        export_storage<Cpu::TexStorageRG, 2>(s.tex_storage_rg_, out);
+        d.tex_table[3] = uint32_t(out.textures.size());
+        export_storage<Cpu::TexStorageR, 1>(s.tex_storage_r_, out);
+        for (int i = 4; i < 8; ++i) {
+            d.tex_table[i] = uint32_t(out.textures.size());
+        }
+        if (s.tex_storage_bc1_.img_count() || s.tex_storage_bc3_.img_count() || s.tex_storage_bc4_.img_count() ||
+            s.tex_storage_bc5_.img_count()) {
+            throw std::runtime_error(
+                "SceneHIP: BCn-compressed textures are not supported (settings_t::use_tex_compression must be false)");
+        }
+        d.textures = out.textures.data();
+        d.textures_count = uint32_t(out.textures.size());
+        d.texels = out.texels.data();
+        d.texels_count = uint32_t(out.texels.size());
+
+        const environment_t &e = s.env_;
+        if (e.qtree_levels != 0) {
+            throw std::runtime_error("SceneHIP: importance-sampled env maps (qtree) are not supported yet");
+        }
+        memcpy(d.env.env_col, e.env_col, 12);
+        d.env.env_map = e.env_map;
+        memcpy(d.env.back_col, e.back_col, 12);
+        d.env.back_map = e.back_map;
+        d.env.env_map_rotation = e.env_map_rotation;
+        d.env.back_map_rotation = e.back_map_rotation;
+        d.env.light_index = e.light_index;
+        d.env.sky_map_spread_angle = e.sky_map_spread_angle;
+        d.env.qtree_levels = 0;
+
+        d.tlas_root = s.tlas_root_;
+        d.visible_lights_count = s.visible_lights_count_;
+        d.blocker_lights_count = s.blocker_lights_count_;
+        s.GetBounds(d.bbox_min, d.bbox_max);
+    }
+};
+
+} // namespace Hip
+} // namespace Ray

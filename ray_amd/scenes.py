@@ -1,0 +1,310 @@
+"""Scene builders for the BASELINE.json configurations, written against the SceneBase mirror (ray_amd.api).
+
+* cornell_basic      -- the scene of reference samples/00_basic (Cornell box, 32 triangles, 2 emissive tris)
+* cornell_principled -- reference samples/03_principled (same box; floor = Principled + 128^2 checker RGBA8)
+* atrium             -- synthetic "Sponza/Bistro-class" scene: no real asset exists offline, so
+                        a deterministic procedural atrium is generated: displaced floor, colonnade of fluted
+                        columns, arches, draped cloth sheets, clutter of noisy spheres/tori, emissive ceiling
+                        strips.  `detail` scales the tessellation; ~0.25 M tris ("sponza") to ~3 M ("bistro").
+
+Every builder takes an object with the SceneBase API, so the same code feeds the HIP backend and the test
+oracle.  Geometry here is data (the classic Cornell measurements / procedural math), not reference code.
+"""
+import math
+from typing import Tuple
+
+import numpy as np
+
+from .api import PrincipledMat, ShadingNode, eShadingNode
+
+# ---- Cornell box ----------------------------------------------------------------------------------------------
+# quad = (4 corners, normal, 4 uvs, index pattern).  Measurements are the classic Cornell data in metres with x
+# negated, as used by the reference samples (samples/00_basic/main.cpp:61-148).
+_Z = (0.0, 0.0)
+_P_A = (0, 2, 1, 0, 3, 2)
+_P_B = (0, 1, 2, 0, 2, 3)
+_P_C = (0, 1, 2, 1, 3, 2)
+_P_D = (0, 1, 2, 2, 1, 3)
+
+_CORNELL_QUADS = [
+    # floor
+    (((0.0, 0.0, -0.5592), (0.0, 0.0, 0.0), (-0.5528, 0.0, 0.0), (-0.5496, 0.0, -0.5592)), (0.0, 1.0, 0.0),
+     ((1.0, 1.0), (1.0, 0.0), (0.0, 0.0), (0.0, 1.0)), _P_A),
+    # back wall
+    (((0.0, 0.0, -0.5592), (-0.5496, 0.0, -0.5592), (-0.556, 0.5488, -0.5592), (0.0, 0.5488, -0.5592)), (0.0, 0.0, 1.0),
+     (_Z, _Z, _Z, _Z), _P_A),
+    # ceiling
+    (((-0.556, 0.5488, -0.5592), (0.0, 0.5488, -0.5592), (0.0, 0.5488, 0.0), (-0.556, 0.5488, 0.0)), (0.0, -1.0, 0.0),
+     (_Z, _Z, _Z, _Z), _P_B),
+    # left wall
+    (((-0.5528, 0.0, 0.0), (-0.5496, 0.0, -0.5592), (-0.556, 0.5488, 0.0), (-0.556, 0.5488, -0.5592)), (1.0, 0.0, 0.0),
+     (_Z, _Z, _Z, _Z), _P_C),
+    # right wall
+    (((0.0, 0.0, -0.5592), (0.0, 0.0, 0.0), (0.0, 0.5488, -0.5592), (0.0, 0.5488, 0.0)), (-1.0, 0.0, 0.0),
+     (_Z, _Z, _Z, _Z), _P_D),
+    # light
+    (((-0.213, 0.5478, -0.227), (-0.343, 0.5478, -0.227), (-0.343, 0.5478, -0.332), (-0.213, 0.5478, -0.332)),
+     (0.0, -1.0, 0.0), (_Z, _Z, _Z, _Z), _P_B),
+]
+
+# blocks: base corners (x, z) a, b, c, d and height; faces listed as in the sample
+_SHORT = dict(a=(-0.240464, -0.271646), b=(-0.082354, -0.224464), c=(-0.129536, -0.066354), d=(-0.287646, -0.113536),
+              h=0.165, n1=(0.285951942, 0.0, -0.958243966), n2=(-0.958243966, 0.0, -0.285951942),
+              n3=(0.958243966, 0.0, 0.285951942), n4=(-0.285951942, 0.0, 0.958243966))
+_TALL = dict(a=(-0.471239, -0.405353), b=(-0.313647, -0.454239), c=(-0.264761, -0.296647), d=(-0.422353, -0.247761),
+             h=0.33, n1=(-0.296278358, 0.0, -0.955101609), n2=(0.955101609, 0.0, -0.296278358),
+             n3=(-0.955101609, 0.0, 0.296278358), n4=(0.296278358, 0.0, 0.955101609))
+
+
+def _block_quads(kind: str):
+    def v(p, y):
+        return (p[0], y, p[1])
+
+    if kind == "short":
+        s = _SHORT
+        a, b, c, d, h = s["a"], s["b"], s["c"], s["d"], s["h"]
+        return [
+            ((v(a, 0.0), v(a, h), v(b, h), v(b, 0.0)), s["n1"], (_Z,) * 4, _P_B),
+            ((v(a, 0.0), v(a, h), v(d, h), v(d, 0.0)), s["n2"], (_Z,) * 4, _P_A),
+            ((v(b, 0.0), v(b, h), v(c, h), v(c, 0.0)), s["n3"], (_Z,) * 4, _P_B),
+            ((v(d, 0.0), v(d, h), v(c, h), v(c, 0.0)), s["n4"], (_Z,) * 4, _P_A),
+            ((v(a, h), v(b, h), v(c, h), v(d, h)), (0.0, 1.0, 0.0), (_Z,) * 4, _P_A),
+        ]
+    s = _TALL
+    a, b, c, d, h = s["a"], s["b"], s["c"], s["d"], s["h"]
+    return [
+        ((v(a, 0.0), v(a, h), v(b, h), v(b, 0.0)), s["n1"], (_Z,) * 4, _P_B),
+        ((v(c, 0.0), v(c, h), v(b, h), v(b, 0.0)), s["n2"], (_Z,) * 4, _P_A),
+        ((v(a, 0.0), v(a, h), v(d, h), v(d, 0.0)), s["n3"], (_Z,) * 4, _P_A),
+        ((v(d, 0.0), v(d, h), v(c, h), v(c, 0.0)), s["n4"], (_Z,) * 4, _P_A),
+        ((v(a, h), v(b, h), v(c, h), v(d, h)), (0.0, 1.0, 0.0), (_Z,) * 4, _P_A),
+    ]
+
+
+def cornell_mesh_arrays() -> Tuple[np.ndarray, np.ndarray]:
+    """(attrs [64, 8] = pos3 nrm3 uv2, indices [96]) of the Cornell box mesh."""
+    quads = _CORNELL_QUADS + _block_quads("short") + _block_quads("tall")
+    attrs, idx = [], []
+    for qi, (corners, n, uvs, pat) in enumerate(quads):
+        for c, uv in zip(corners, uvs):
+            attrs.append((*c, *n, *uv))
+        idx.extend(4 * qi + k for k in pat)
+    return np.asarray(attrs, dtype=np.float32), np.asarray(idx, dtype=np.uint32)
+
+
+def checkerboard(res: int = 128, square: int = 16) -> np.ndarray:
+    """samples/03_principled GenerateCheckerboard: RGBA8, 10/250 grey squares."""
+    i, j = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
+    dark = ((j // square + i // square) % 2) == 0
+    img = np.empty((res, res, 4), dtype=np.uint8)
+    img[..., :3] = np.where(dark, 10, 250)[..., None]
+    img[..., 3] = 255
+    return img
+
+
+def _cornell_camera(scene, **cam_overrides):
+    kw = dict(type=0, origin=(-0.278, 0.273, 0.8), fwd=(0.0, 0.0, -1.0), fov=39.1463)
+    kw.update(cam_overrides)
+    cam = scene.AddCamera(**kw)
+    scene.set_current_cam(cam)
+    return cam
+
+
+def cornell_basic(scene, **cam_overrides):
+    """reference samples/00_basic/main.cpp:30-186"""
+    scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
+    mat1 = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    mat2 = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.0, 0.0)))
+    mat3 = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.0, 0.5, 0.0)))
+    mat4 = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=100.0, importance_sample=True))
+    attrs, idx = cornell_mesh_arrays()
+    # groups exactly as the sample passes them ({mat, vtx_start, vtx_count}); the light has no back material
+    groups = [(mat1, None, 0, 18), (mat2, None, 19, 6), (mat3, None, 25, 6), (mat4, 0xFFFFFFFF, 31, 6), (mat1, None, 37, 60)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
+def cornell_principled(scene, **cam_overrides):
+    """reference samples/03_principled/main.cpp:30-205"""
+    scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
+    tex = scene.AddTexture(checkerboard(128, 16))
+    mat0 = scene.AddMaterial(PrincipledMat(base_texture=tex, roughness=0.25, roughness_texture=tex))
+    mat1 = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    mat2 = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.0, 0.0)))
+    mat3 = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.0, 0.5, 0.0)))
+    mat4 = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=100.0, importance_sample=True))
+    attrs, idx = cornell_mesh_arrays()
+    groups = [(mat0, None, 0, 6), (mat1, None, 6, 12), (mat2, None, 19, 6), (mat3, None, 25, 6),
+              (mat4, 0xFFFFFFFF, 31, 6), (mat1, None, 37, 60)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
+# ---- procedural atrium ("Sponza / Bistro class") ---------------------------------------------------------------
+def _grid(nu: int, nv: int, fn, flip=False):
+    """Tessellated parametric patch.  fn(u, v) -> (P[...,3], N[...,3]); returns attrs [n,8], tri indices."""
+    u, v = np.meshgrid(np.linspace(0.0, 1.0, nu + 1), np.linspace(0.0, 1.0, nv + 1), indexing="ij")
+    P, N = fn(u, v)
+    uv = np.stack([u * 4.0, v * 4.0], axis=-1)
+    attrs = np.concatenate([P, N, uv], axis=-1).reshape(-1, 8).astype(np.float32)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    a = (i * (nv + 1) + j).ravel()
+    b, c, d = a + (nv + 1), a + (nv + 1) + 1, a + 1
+    tris = np.stack([a, b, c, a, c, d], axis=-1) if not flip else np.stack([a, c, b, a, d, c], axis=-1)
+    return attrs, tris.reshape(-1).astype(np.uint32)
+
+
+def _normalize(v):
+    return v / np.maximum(np.linalg.norm(v, axis=-1, keepdims=True), 1e-12)
+
+
+def _noise(p, seed):
+    """cheap deterministic value noise from sines (no RNG state)"""
+    s = np.sin(p[..., 0] * 12.9898 + p[..., 1] * 78.233 + p[..., 2] * 37.719 + seed * 1.618) * 43758.5453
+    return s - np.floor(s)
+
+
+def _finite_normals(fn, eps=1e-3):
+    def wrapped(u, v):
+        P = fn(u, v)
+        Pu = fn(np.clip(u + eps, 0, 1), v) - fn(np.clip(u - eps, 0, 1), v)
+        Pv = fn(u, np.clip(v + eps, 0, 1)) - fn(u, np.clip(v - eps, 0, 1))
+        N = _normalize(np.cross(Pu, Pv))
+        N = np.where(np.isfinite(N), N, np.array([0.0, 1.0, 0.0]))
+        return P, N
+    return wrapped
+
+
+class _MeshBuilder:
+    def __init__(self):
+        self.attrs, self.idx, self.groups, self.nv, self.ni = [], [], [], 0, 0
+
+    def add(self, attrs, idx, mat, back=None):
+        self.attrs.append(attrs)
+        self.idx.append(idx + self.nv)
+        self.groups.append((mat, back, self.ni, len(idx)))
+        self.nv += len(attrs)
+        self.ni += len(idx)
+
+    def finish(self):
+        return np.concatenate(self.attrs), np.concatenate(self.idx), self.groups
+
+
+def atrium(scene, detail: float = 1.0, cam_overrides=None):
+    """Synthetic atrium, 30 x 12 x 18 (SURVEY.md section 8d input 3/4).  Triangle count ~ 250k * detail."""
+    d = max(detail, 0.02)
+    s = math.sqrt(d)
+    scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
+    stone = scene.AddMaterial(PrincipledMat(base_color=(0.62, 0.58, 0.50), roughness=0.7, specular=0.3))
+    floor_m = scene.AddMaterial(PrincipledMat(base_color=(0.35, 0.33, 0.32), roughness=0.35, specular=0.5))
+    cloth_r = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.55, 0.08, 0.07), roughness=0.5))
+    cloth_g = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.10, 0.40, 0.12), roughness=0.5))
+    cloth_b = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.10, 0.15, 0.50), roughness=0.5))
+    metal = scene.AddMaterial(PrincipledMat(base_color=(0.90, 0.75, 0.40), metallic=1.0, roughness=0.25))
+    glossy = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=(0.8, 0.8, 0.85), roughness=0.15))
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=18.0, base_color=(1.0, 0.95, 0.85),
+                                         importance_sample=True))
+    X, Y, Z = 30.0, 12.0, 18.0
+    mb = _MeshBuilder()
+
+    def n(k):
+        return max(2, int(round(k * s)))
+
+    # displaced floor + walls + ceiling (big patches: top of the tree)
+    mb.add(*_grid(n(220), n(140), _finite_normals(lambda u, v: np.stack(
+        [u * X - X / 2, 0.04 * np.sin(u * 70) * np.sin(v * 45) + 0.02 * _noise(np.stack([u, v, u * 0], -1), 1), v * Z - Z / 2], -1))),
+        floor_m)
+    mb.add(*_grid(n(120), n(60), _finite_normals(lambda u, v: np.stack(
+        [u * X - X / 2, v * Y, -Z / 2 + 0.08 * np.sin(u * 60) * np.cos(v * 30)], -1))), stone)
+    mb.add(*_grid(n(120), n(60), _finite_normals(lambda u, v: np.stack(
+        [X / 2 - u * X, v * Y, Z / 2 - 0.08 * np.sin(u * 60) * np.cos(v * 30)], -1))), stone)
+    mb.add(*_grid(n(80), n(60), _finite_normals(lambda u, v: np.stack(
+        [-X / 2 + 0.08 * np.sin(u * 40) * np.cos(v * 30), v * Y, Z / 2 - u * Z], -1))), stone)
+    mb.add(*_grid(n(80), n(60), _finite_normals(lambda u, v: np.stack(
+        [X / 2 - 0.08 * np.sin(u * 40) * np.cos(v * 30), v * Y, u * Z - Z / 2], -1))), stone)
+    mb.add(*_grid(n(100), n(60), _finite_normals(lambda u, v: np.stack(
+        [X / 2 - u * X, Y + 0.3 * np.sin(u * math.pi) * np.sin(v * math.pi), v * Z - Z / 2], -1))), stone)
+
+    # colonnade: two rows of fluted columns + arches between them
+    ncol = 10
+    for row, zc in enumerate((-Z / 4, Z / 4)):
+        for k in range(ncol):
+            xc = -X / 2 + (k + 0.5) * X / ncol
+
+            def column(u, v, xc=xc, zc=zc):
+                ang = u * 2 * math.pi
+                r = 0.45 * (1.0 + 0.06 * np.cos(ang * 20)) * (1.0 - 0.12 * v) + 0.25 * np.exp(-((v - 0.02) * 30) ** 2) \
+                    + 0.25 * np.exp(-((v - 0.98) * 30) ** 2)
+                return np.stack([xc + r * np.cos(ang), v * 8.0, zc + r * np.sin(ang)], -1)
+            mb.add(*_grid(n(96), n(64), _finite_normals(column)), stone)
+            if k + 1 < ncol:
+                def arch(u, v, xc=xc, zc=zc):
+                    ang = u * math.pi
+                    half = X / ncol / 2
+                    cx = xc + half - half * np.cos(ang)
+                    cy = 8.0 + 1.6 * np.sin(ang)
+                    return np.stack([cx, cy + 0.5 * v + 0.03 * np.sin(u * 90), zc + (v - 0.5) * 0.9], -1)
+                mb.add(*_grid(n(64), n(10), _finite_normals(arch)), stone, back=stone)
+
+    # draped cloth sheets hanging between the rows
+    for k, mat in enumerate((cloth_r, cloth_g, cloth_b, cloth_r, cloth_b)):
+        x0 = -X / 2 + 3.0 + k * 5.5
+
+        def cloth(u, v, x0=x0, k=k):
+            sag = 1.4 * np.sin(u * math.pi) + 0.25 * np.sin(v * 14 + k) * np.sin(u * 9)
+            return np.stack([x0 + 0.35 * np.sin(v * 11 + u * 5 + k), 9.5 - sag - 0.1 * v, -Z / 4 + u * Z / 2], -1)
+        mb.add(*_grid(n(150), n(110), _finite_normals(cloth)), mat, back=mat)
+
+    # clutter: noisy spheres and tori on the floor
+    for k in range(14):
+        cx = -X / 2 + 2.0 + (k * 7.3) % (X - 4.0)
+        cz = -Z / 2 + 2.0 + (k * 4.1) % (Z - 4.0)
+        rad = 0.5 + 0.35 * ((k * 37) % 7) / 7.0
+        if k % 2 == 0:
+            def blob(u, v, cx=cx, cz=cz, rad=rad, k=k):
+                th, ph = v * math.pi, u * 2 * math.pi
+                dirv = np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], -1)
+                r = rad * (1.0 + 0.12 * np.sin(6 * ph + k) * np.sin(5 * th))
+                return np.array([cx, rad, cz]) + dirv * r[..., None]
+            mb.add(*_grid(n(90), n(60), _finite_normals(blob)), metal if k % 4 == 0 else glossy)
+        else:
+            def torus(u, v, cx=cx, cz=cz, rad=rad):
+                a, b = u * 2 * math.pi, v * 2 * math.pi
+                R, r = rad, 0.35 * rad
+                return np.stack([cx + (R + r * np.cos(b)) * np.cos(a), r + r * np.sin(b) + 0.02,
+                                 cz + (R + r * np.cos(b)) * np.sin(a)], -1)
+            mb.add(*_grid(n(100), n(48), _finite_normals(torus)), metal if k % 3 == 0 else stone)
+
+    # emissive ceiling strips (TRI lights through MAT_FLAG_IMP_SAMPLE)
+    for k in range(4):
+        x0 = -X / 2 + 4.0 + k * 7.0
+
+        def strip(u, v, x0=x0):
+            return np.stack([x0 + u * 2.5, 0 * u + Y - 0.45, -Z / 2 + 2.0 + v * (Z - 4.0)], -1)
+        a, i = _grid(2, 6, lambda u, v, f=strip: (f(u, v), np.broadcast_to(np.array([0.0, -1.0, 0.0]), (*u.shape, 3))), flip=True)
+        mb.add(a, i, emit, back=0xFFFFFFFF)
+
+    attrs, idx, groups = mb.finish()
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    kw = dict(type=0, origin=(-X / 2 + 2.5, 2.2, 0.6), fwd=_unit((1.0, 0.12, -0.08)), fov=60.0)
+    kw.update(cam_overrides or {})
+    cam = scene.AddCamera(**kw)
+    scene.set_current_cam(cam)
+    scene.Finalize()
+    return int(len(idx) // 3)
+
+
+def _unit(v):
+    v = np.asarray(v, dtype=np.float64)
+    return tuple(float(x) for x in v / np.linalg.norm(v))
+
+
+SCENES = {
+    "cornell_basic": cornell_basic,
+    "cornell_principled": cornell_principled,
+}

@@ -1,0 +1,366 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE.  Compiles the kernel bodies of ray_amd/csrc/rt_*.h with g++ and runs the
+// RenderScene stage schedule as plain loops on the CPU, behind the same C signatures as include/rayhip.h
+// (prefix hostsim_ instead of rayhip_).
+//
+// Purpose: the GPU box is a scarce resource and the integrand is chaotic, so the restatement of the
+// reference's arithmetic is first proven on the CPU, where -- built without fma like the reference
+// (-msse2 -mno-avx, glibc libm) -- it must match RendererRef BIT FOR BIT (tests/test_hostsim_parity.py).
+// What is left for the GPU tests is then only what differs on the device: the device libm, wave-level
+// compaction, the LDS stack and memory layout.
+//
+// This file is never linked into librayhip.so and nothing under ray_amd/ refers to it: the product has no
+// CPU path (rayhip_* fail loudly without a GPU).
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../ray_amd/csrc/rt_params.h"
+#include "../../ray_amd/csrc/rt_pixel.h"
+#include "../../ray_amd/csrc/scene_blob.h"
+
+using namespace rt;
+
+namespace {
+thread_local std::string g_err;
+
+struct HostScene {
+    std::vector<rayhip_bvh2_node> nodes;
+    std::vector<rayhip_tri_accel> tris;
+    std::vector<uint32_t> tri_indices;
+    std::vector<rayhip_tri_mat_data> tri_materials;
+    std::vector<rayhip_material> materials;
+    std::vector<rayhip_vertex> vertices;
+    std::vector<uint32_t> vtx_indices;
+    std::vector<rayhip_mesh_instance> mesh_instances;
+    std::vector<rayhip_light> lights;
+    std::vector<uint32_t> li_indices;
+    std::vector<rayhip_light_cwbvh_node> light_cwnodes;
+    std::vector<rayhip_texture> textures;
+    std::vector<uint32_t> texels;
+};
+} // namespace
+
+struct hostsim_ctx {
+    int w = 0, h = 0;
+    std::vector<uint32_t> pmj;
+    std::vector<float> filter_table;
+    HostScene hs;
+    SceneView sc = {};
+    float bbox_min[3] = {}, bbox_max[3] = {};
+    std::vector<float4> temp, full, half, raw, final_, base_color, depth_normals;
+    std::vector<uint16_t> required_samples;
+    rayhip_trav_counters counters[2] = {};
+};
+
+#define HS_API extern "C" __attribute__((visibility("default")))
+
+HS_API const char *hostsim_last_error(void) { return g_err.c_str(); }
+HS_API int hostsim_device_count(void) { return 1; }
+
+HS_API int hostsim_ctx_create(int, hostsim_ctx **out) {
+    *out = new hostsim_ctx();
+    return 0;
+}
+HS_API void hostsim_ctx_destroy(hostsim_ctx *c) { delete c; }
+HS_API int hostsim_ctx_device_name(hostsim_ctx *, char *buf, int cap) {
+    snprintf(buf, size_t(cap), "hostsim (CPU, test only)");
+    return 0;
+}
+HS_API int hostsim_upload_static(hostsim_ctx *c, const uint32_t *pmj, uint32_t count) {
+    c->pmj.assign(pmj, pmj + count);
+    c->sc.pmj = c->pmj.data();
+    return 0;
+}
+HS_API int hostsim_resize(hostsim_ctx *c, int w, int h) {
+    if (c->w != w || c->h != h) {
+        const size_t n = size_t(w) * size_t(h);
+        const float4 z = {0, 0, 0, 0};
+        c->temp.assign(n, z), c->full.assign(n, z), c->half.assign(n, z), c->raw.assign(n, z), c->final_.assign(n, z);
+        c->base_color.assign(n, z), c->depth_normals.assign(n, z);
+        c->required_samples.assign(n, 0xffff);
+        c->w = w, c->h = h;
+    }
+    return 0;
+}
+HS_API int hostsim_clear(hostsim_ctx *c, const float rgba[4]) { // RendererCPU.h:297-301
+    const float4 v = {rgba[0], rgba[1], rgba[2], rgba[3]};
+    std::fill(c->full.begin(), c->full.end(), v);
+    std::fill(c->half.begin(), c->half.end(), v);
+    std::fill(c->required_samples.begin(), c->required_samples.end(), uint16_t(0xffff));
+    return 0;
+}
+HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d) {
+    HostScene &s = c->hs;
+#define CP(field) s.field.assign(d->field, d->field + d->field##_count)
+    CP(nodes);
+    CP(tris);
+    CP(tri_indices);
+    CP(tri_materials);
+    CP(materials);
+    CP(vertices);
+    CP(vtx_indices);
+    CP(mesh_instances);
+    CP(lights);
+    CP(li_indices);
+    CP(light_cwnodes);
+    CP(textures);
+    CP(texels);
+#undef CP
+    SceneView &v = c->sc;
+    v.nodes = s.nodes.data(), v.tris = s.tris.data(), v.tri_indices = s.tri_indices.data();
+    v.tri_materials = s.tri_materials.data(), v.materials = s.materials.data(), v.vertices = s.vertices.data();
+    v.vtx_indices = s.vtx_indices.data(), v.mesh_instances = s.mesh_instances.data(), v.lights = s.lights.data();
+    v.li_indices = s.li_indices.data(), v.light_cwnodes = s.light_cwnodes.data(), v.textures = s.textures.data();
+    v.texels = s.texels.data();
+    memcpy(v.tex_table, d->tex_table, sizeof(v.tex_table));
+    v.li_indices_count = d->li_indices_count;
+    v.light_cwnodes_count = d->light_cwnodes_count;
+    v.visible_lights_count = d->visible_lights_count;
+    v.blocker_lights_count = d->blocker_lights_count;
+    v.tlas_root = d->tlas_root;
+    v.env = d->env;
+    memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
+    return 0;
+}
+HS_API int hostsim_set_filter_table(hostsim_ctx *c, const float *t, int count) {
+    c->filter_table.assign(t, t + count);
+    return 0;
+}
+
+HS_API int hostsim_scene_upload_blob(hostsim_ctx *c, const void *blob, size_t size, rayhip_camera *out_cam) {
+    rayhip_scene_desc d;
+    const float *ft = nullptr;
+    int ftn = 0;
+    std::string err;
+    if (!rayhip_blob::deserialize(blob, size, d, *out_cam, &ft, &ftn, err)) {
+        g_err = err;
+        return 1;
+    }
+    hostsim_scene_upload(c, &d);
+    if (ft) {
+        hostsim_set_filter_table(c, ft, ftn);
+    }
+    return 0;
+}
+
+static void add_counters(rayhip_trav_counters &dst, const TravCount &tc) {
+    dst.rays += 1, dst.nodes += tc.nodes, dst.tris += tc.tris, dst.instances += tc.instances;
+}
+
+HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration, uint32_t flags,
+                          rayhip_stats *) {
+    const bool count = (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) != 0;
+    const int w = c->w;
+    const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration);
+    const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
+    const float mix_factor = 1.0f / float(iteration);
+
+    std::vector<Ray> rays, next_rays;
+    std::vector<Hit> hits;
+    std::vector<ShadowRay> shadow;
+    // K1: primary rays (CoreRef.cpp:1471-1553), skipping pixels that need no more samples
+    for (int y = rect[1]; y < rect[1] + rect[3]; ++y) {
+        for (int x = rect[0]; x < rect[0] + rect[2]; ++x) {
+            if (c->required_samples[size_t(y) * w + x] < iteration) {
+                continue;
+            }
+            Ray r;
+            Hit h;
+            generate_primary_ray(rg, c->sc.pmj, c->filter_table.data(), x, y, r, h);
+            rays.push_back(r), hits.push_back(h);
+        }
+    }
+    ArrayStack st;
+    // K2: primary trace (RendererCPU.h:455)
+    if (c->sc.tlas_root != 0xffffffff) {
+        for (size_t i = 0; i < rays.size(); ++i) {
+            TravCount tc = {};
+            intersect_scene_closest(c->sc, tp, rays[i], hits[i], st, count ? &tc : nullptr);
+            if (count) {
+                add_counters(c->counters[0], tc);
+            }
+        }
+    }
+    for (int bounce = 0; bounce <= int(cam->pass_settings.max_total_depth); ++bounce) {
+        if (bounce > 0) {
+            if (rays.empty()) {
+                break;
+            }
+            // K2: secondary trace, hits reset to default (RendererCPU.h:533-541).  (No sort: order-free.)
+            hits.assign(rays.size(), make_hit());
+            for (size_t i = 0; i < rays.size(); ++i) {
+                TravCount tc = {};
+                intersect_scene_closest(c->sc, tp, rays[i], hits[i], st, count ? &tc : nullptr);
+                if (count) {
+                    add_counters(c->counters[0], tc);
+                }
+            }
+        }
+        // K5: shade
+        const ShadeParams sp = make_shade_params(*cam, iteration, bounce);
+        next_rays.clear(), shadow.clear();
+        for (size_t i = 0; i < rays.size(); ++i) {
+            Ray nr;
+            ShadowRay sr;
+            const ShadeResult res = shade_surface(c->sc, sp, hits[i], rays[i], nr, sr);
+            if (bounce == 0) {
+                write_primary_pixel(res, rays[i].xy, w, mix_factor, c->temp.data(), c->base_color.data(),
+                                    c->depth_normals.data());
+            } else {
+                add_secondary_pixel(res, rays[i].xy, w, c->temp.data());
+            }
+            if (res.emit_secondary) {
+                next_rays.push_back(nr);
+            }
+            if (res.emit_shadow) {
+                shadow.push_back(sr);
+            }
+        }
+        // K3: shadow rays
+        const float limit = shadow_clamp_limit(*cam, bounce);
+        for (size_t i = 0; i < shadow.size(); ++i) {
+            TravCount tc = {};
+            const f3 rc = intersect_scene_shadow(c->sc, tp, shadow[i], st, count ? &tc : nullptr);
+            if (count) {
+                add_counters(c->counters[1], tc);
+            }
+            add_shadow_pixel(rc, limit, shadow[i].xy, w, c->temp.data());
+        }
+        rays.swap(next_rays);
+    }
+    // K10+K11
+    const AccumParams ap = make_accum_params(*cam, w, rect, iteration);
+    for (int y = rect[1]; y < rect[1] + rect[3]; ++y) {
+        for (int x = rect[0]; x < rect[0] + rect[2]; ++x) {
+            accumulate_pixel(ap, x, y, c->temp.data(), c->full.data(), c->half.data(), c->raw.data(), c->final_.data(),
+                             c->required_samples.data());
+        }
+    }
+    return 0;
+}
+
+HS_API int hostsim_readback(hostsim_ctx *c, int which, float *dst, int pitch_px) {
+    const std::vector<float4> *src = nullptr;
+    switch (which) {
+    case RAYHIP_BUF_FINAL:
+        src = &c->final_;
+        break;
+    case RAYHIP_BUF_RAW:
+        src = &c->raw;
+        break;
+    case RAYHIP_BUF_BASE_COLOR:
+        src = &c->base_color;
+        break;
+    case RAYHIP_BUF_DEPTH_NORMALS:
+        src = &c->depth_normals;
+        break;
+    default:
+        g_err = "bad buffer id";
+        return 1;
+    }
+    for (int y = 0; y < c->h; ++y) {
+        memcpy(dst + size_t(y) * pitch_px * 4, src->data() + size_t(y) * c->w, size_t(c->w) * 16);
+    }
+    return 0;
+}
+HS_API int hostsim_sync(hostsim_ctx *) { return 0; }
+
+HS_API int hostsim_get_trav_counters(hostsim_ctx *c, rayhip_trav_counters out[2], int reset) {
+    out[0] = c->counters[0], out[1] = c->counters[1];
+    if (reset) {
+        c->counters[0] = c->counters[1] = rayhip_trav_counters{};
+    }
+    return 0;
+}
+
+// ---- kernel-level hooks ---------------------------------------------------------------------------------
+static Ray from_abi(const rayhip_ray &a) {
+    Ray r;
+    r.o = mk3(a.o), r.d = mk3(a.d), r.pdf = a.pdf, r.c = mk3(a.c);
+    memcpy(r.ior, a.ior, 16);
+    r.cone_width = a.cone_width, r.cone_spread = a.cone_spread, r.xy = a.xy, r.depth = a.depth;
+    return r;
+}
+static rayhip_ray to_abi(const Ray &r) {
+    rayhip_ray a;
+    a.o[0] = r.o.x, a.o[1] = r.o.y, a.o[2] = r.o.z;
+    a.d[0] = r.d.x, a.d[1] = r.d.y, a.d[2] = r.d.z;
+    a.pdf = r.pdf;
+    a.c[0] = r.c.x, a.c[1] = r.c.y, a.c[2] = r.c.z;
+    memcpy(a.ior, r.ior, 16);
+    a.cone_width = r.cone_width, a.cone_spread = r.cone_spread, a.xy = r.xy, a.depth = r.depth;
+    return a;
+}
+
+HS_API int hostsim_k_generate_primary_rays(hostsim_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration,
+                                           rayhip_ray *out_rays, rayhip_hit *out_hits, int *out_count) {
+    const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration);
+    int n = 0;
+    for (int y = rect[1]; y < rect[1] + rect[3]; ++y) {
+        for (int x = rect[0]; x < rect[0] + rect[2]; ++x) {
+            if (c->required_samples[size_t(y) * c->w + x] < iteration) {
+                continue;
+            }
+            Ray r;
+            Hit h;
+            generate_primary_ray(rg, c->sc.pmj, c->filter_table.data(), x, y, r, h);
+            out_rays[n] = to_abi(r);
+            out_hits[n] = rayhip_hit{h.obj_index, h.prim_index, h.t, h.u, h.v};
+            ++n;
+        }
+    }
+    *out_count = n;
+    return 0;
+}
+
+HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam, rayhip_ray *rays, rayhip_hit *hits,
+                                       int count, int iteration, rayhip_trav_counters *out_counters) {
+    const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
+    ArrayStack st;
+    rayhip_trav_counters acc = {};
+    for (int i = 0; i < count; ++i) {
+        Ray r = from_abi(rays[i]);
+        Hit h = {hits[i].obj_index, hits[i].prim_index, hits[i].t, hits[i].u, hits[i].v};
+        TravCount tc = {};
+        intersect_scene_closest(c->sc, tp, r, h, st, &tc);
+        add_counters(acc, tc);
+        rays[i] = to_abi(r);
+        hits[i] = rayhip_hit{h.obj_index, h.prim_index, h.t, h.u, h.v};
+    }
+    if (out_counters) {
+        *out_counters = acc;
+    }
+    return 0;
+}
+
+HS_API int hostsim_k_intersect_shadow(hostsim_ctx *c, const rayhip_camera *cam, const rayhip_shadow_ray *rays, int count,
+                                      int iteration, float *out_rc, rayhip_trav_counters *out_counters) {
+    const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
+    ArrayStack st;
+    rayhip_trav_counters acc = {};
+    for (int i = 0; i < count; ++i) {
+        ShadowRay r;
+        r.o = mk3(rays[i].o), r.depth = rays[i].depth, r.d = mk3(rays[i].d), r.dist = rays[i].dist;
+        r.c = mk3(rays[i].c), r.xy = rays[i].xy;
+        TravCount tc = {};
+        const f3 rc = intersect_scene_shadow(c->sc, tp, r, st, &tc);
+        add_counters(acc, tc);
+        out_rc[4 * i + 0] = rc.x, out_rc[4 * i + 1] = rc.y, out_rc[4 * i + 2] = rc.z, out_rc[4 * i + 3] = 0.0f;
+    }
+    if (out_counters) {
+        *out_counters = acc;
+    }
+    return 0;
+}
+
+HS_API int hostsim_k_scrambled_rand(hostsim_ctx *c, const uint32_t *dims, const uint32_t *seeds, const int32_t *samples,
+                                    int count, float *out_xy) {
+    for (int i = 0; i < count; ++i) {
+        const f2 r = get_scrambled_2d_rand(dims[i], seeds[i], samples[i], c->sc.pmj);
+        out_xy[2 * i + 0] = r.x, out_xy[2 * i + 1] = r.y;
+    }
+    return 0;
+}
