@@ -317,6 +317,12 @@ RAYHIP_API int rayhip_set_filter_table(rayhip_ctx *ctx, const float *table, int 
 RAYHIP_API int rayhip_render(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int iteration,
                              uint32_t flags, rayhip_stats *stats);
 
+/* Multi-GPU tile sharding (new): this context renders only the pixels of the tile x tile
+ * squares (row-major walk over the frame) whose ordinal % shard_count == shard_index; all other pixels of its
+ * buffers stay zero, so that summing the RAW buffers of all ranks (one RCCL reduce) yields the full frame,
+ * bit-identical to a single-GPU render.  Default is (64, 1, 0) = everything. */
+RAYHIP_API int rayhip_set_shard(rayhip_ctx *ctx, int tile, int shard_count, int shard_index);
+
 /* blocking device->host copy, get_pixels_ref & co. (RendererVK.cpp:1698-1757) */
 RAYHIP_API int rayhip_readback(rayhip_ctx *ctx, int which, float *dst_rgba, int pitch_px);
 /* same, into DEVICE memory the caller owns (e.g. a torch tensor that is then reduced over RCCL);

@@ -1,0 +1,259 @@
+// kernels.hip.h -- the __global__ kernels of librayhip (gfx950 / CDNA4, wave64).
+//
+// Kernel map (reference GLSL kernel -> here; SURVEY.md section 2 kernel table):
+//   K1  primary_ray_gen.comp.glsl            -> k_raygen
+//   K2  intersect_scene.comp.glsl            -> k_trace_closest      (the roofline kernel)
+//   K3  intersect_scene_shadow.comp.glsl     -> k_trace_shadow
+//   K5  shade.comp.glsl (PRIMARY/SECONDARY)  -> k_shade<PRIMARY>
+//   K9  prepare_indir_args.comp.glsl         -> (gone) ray counts stay in HBM; every stage is launched with a
+//                                               fixed grid and grid-strides over the count it reads there, so the
+//                                               bounce loop never returns to the host (RendererVK.cpp:641-712 records
+//                                               all bounces up front for the same reason)
+//   K10 mix_incremental + K11 postprocess    -> k_accumulate (fused: one pass over the rect)
+//
+// Conventions
+//   * one wavefront (64 lanes) per workgroup in the traversal kernels: the traversal stack is a per-wavefront
+//     LDS array laid out depth-major, stack[depth][lane] -> bank == lane for every lane at ANY mix of depths,
+//     i.e. conflict-free by construction (MI355X_MICROARCH.md LDS table: ds_read/write_b32 conflict only
+//     inside a 32-lane half).  48 entries x 64 lanes x 4 B = 12 KiB per wave, the same budget the reference's
+//     shader takes (shaders/intersect_scene.comp.glsl:87).
+//   * ray compaction between stages uses one atomic per wavefront: ballot + mbcnt prefix (wave_alloc) instead of
+//     the reference's per-thread atomicAdd (shaders/shade.comp.glsl:2432,2452).
+//   * all per-ray state is SoA float4 planes (rt_types.h): 16 B per lane per access, 1 KiB per wave instruction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rt_params.h"
+#include "rt_pixel.h"
+
+namespace rt {
+
+constexpr int WAVE = 64;
+constexpr int LDS_STACK_DEPTH = MAX_STACK_SIZE; // entries per lane, TLAS + BLAS levels share it
+
+// depth-major per-wavefront stack in LDS
+struct LdsStack {
+    uint32_t *lane_base; // &lds[wave_slot][0][lane]
+    uint32_t size;
+    __device__ __forceinline__ void push(uint32_t v) {
+        if (size < uint32_t(LDS_STACK_DEPTH)) { // never write outside the wave's slice
+            lane_base[size * WAVE] = v;
+        }
+        ++size;
+    }
+    __device__ __forceinline__ uint32_t pop() {
+        --size;
+        return size < uint32_t(LDS_STACK_DEPTH) ? lane_base[size * WAVE] : 0x1fffffffu;
+    }
+};
+
+// Reserve one output slot per lane with `pred` set: one atomicAdd per wavefront.
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter, const bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) {
+        return 0u;
+    }
+    const uint32_t lane = __lane_id();
+    const uint32_t prefix = uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (int(lane) == leader) {
+        base = atomicAdd(counter, uint32_t(__popcll(mask)));
+    }
+    base = uint32_t(__shfl(int(base), leader));
+    return base + prefix;
+}
+
+struct PixelBuffers {
+    float4 *temp, *full, *half, *raw, *final_, *base_color, *depth_normals;
+    uint16_t *required_samples;
+};
+
+// ---- K1 ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint32_t *__restrict__ pmj,
+                                               const float *__restrict__ filter_table,
+                                               const uint16_t *__restrict__ required_samples, const RaySoA rays,
+                                               const HitSoA hits, uint32_t *__restrict__ out_count) {
+    const int n = p.rect[2] * p.rect[3];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((n + WAVE - 1) / WAVE) * WAVE; i += gridDim.x * blockDim.x) {
+        const bool in_rect = i < n;
+        const int x = p.rect[0] + (in_rect ? i % p.rect[2] : 0), y = p.rect[1] + (in_rect ? i / p.rect[2] : 0);
+        const bool live = in_rect && pixel_owned(p.shard, p.w, x, y) && !(required_samples[y * p.w + x] < p.iteration);
+        const uint32_t slot = wave_alloc(out_count, live);
+        if (live) {
+            Ray r;
+            Hit h;
+            generate_primary_ray(p, pmj, filter_table, x, y, r, h);
+            store_ray(rays, slot, r);
+            store_hit(hits, slot, h);
+        }
+    }
+}
+
+// ---- K2 ---------------------------------------------------------------------------------------------------
+// One ray per lane; grid-stride over the device-resident ray count.
+template <bool COUNT>
+__global__ void __launch_bounds__(WAVE) k_trace_closest(const SceneView sc, const TraceParams tp, const RaySoA rays,
+                                                       const HitSoA hits, const uint32_t *__restrict__ ray_count,
+                                                       const int init_hits, unsigned long long *__restrict__ counters) {
+    __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
+    const uint32_t n = *ray_count;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = blockIdx.x * WAVE + lane; i < n; i += gridDim.x * WAVE) {
+        Ray r;
+        load_ray_od(rays, i, r);
+        {
+            const float4 c = rays.c_cs[i];
+            const uint2 xd = rays.xy_depth[i];
+            r.c = {c.x, c.y, c.z};
+            r.cone_spread = c.w;
+            r.xy = xd.x, r.depth = xd.y;
+        }
+        Hit h = init_hits ? make_hit() : load_hit(hits, i);
+        const uint32_t depth_in = r.depth;
+        const f3 c_in = r.c;
+
+        LdsStack st;
+        st.lane_base = &lds_stack[lane];
+        st.size = 0;
+        TravCount tc = {0, 0, 0};
+        intersect_scene_closest(sc, tp, r, h, st, COUNT ? &tc : nullptr);
+
+        store_hit(hits, i, h);
+        // only rays that crossed (or died on) a transparent surface changed throughput / depth
+        if (r.depth != depth_in || r.c.x != c_in.x || r.c.y != c_in.y || r.c.z != c_in.z) {
+            rays.c_cs[i] = mkfloat4(r.c.x, r.c.y, r.c.z, r.cone_spread);
+            uint2 xd;
+            xd.x = r.xy, xd.y = r.depth;
+            rays.xy_depth[i] = xd;
+        }
+        if (COUNT) {
+            atomicAdd(&counters[0], 1ull);
+            atomicAdd(&counters[1], (unsigned long long)tc.nodes);
+            atomicAdd(&counters[2], (unsigned long long)tc.tris);
+            atomicAdd(&counters[3], (unsigned long long)tc.instances);
+        }
+    }
+}
+
+// ---- K3 ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(WAVE) k_trace_shadow(const SceneView sc, const TraceParams tp, const ShadowSoA shadow,
+                                                      const uint32_t *__restrict__ ray_count, const float limit,
+                                                      const int img_w, float4 *__restrict__ temp_buf,
+                                                      float4 *__restrict__ out_rc, /* test hook, may be null */
+                                                      unsigned long long *__restrict__ counters) {
+    __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
+    const uint32_t n = *ray_count;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = blockIdx.x * WAVE + lane; i < n; i += gridDim.x * WAVE) {
+        const ShadowRay r = load_shadow(shadow, i);
+        LdsStack st;
+        st.lane_base = &lds_stack[lane];
+        st.size = 0;
+        TravCount tc = {0, 0, 0};
+        const f3 rc = intersect_scene_shadow(sc, tp, r, st, COUNT ? &tc : nullptr);
+        if (out_rc) {
+            out_rc[i] = mkfloat4(rc.x, rc.y, rc.z, 0.0f);
+        } else {
+            add_shadow_pixel(rc, limit, r.xy, img_w, temp_buf);
+        }
+        if (COUNT) {
+            atomicAdd(&counters[0], 1ull);
+            atomicAdd(&counters[1], (unsigned long long)tc.nodes);
+            atomicAdd(&counters[2], (unsigned long long)tc.tris);
+            atomicAdd(&counters[3], (unsigned long long)tc.instances);
+        }
+    }
+}
+
+// ---- K5 ---------------------------------------------------------------------------------------------------
+template <bool PRIMARY>
+__global__ void __launch_bounds__(WAVE) k_shade(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
+                                               const HitSoA hits, const uint32_t *__restrict__ ray_count,
+                                               const RaySoA rays_out, uint32_t *__restrict__ out_ray_count,
+                                               const ShadowSoA shadow_out, uint32_t *__restrict__ out_shadow_count,
+                                               const PixelBuffers px, const int img_w, const float mix_factor) {
+    const uint32_t n = *ray_count;
+    const uint32_t n_pad = ((n + WAVE - 1) / WAVE) * WAVE; // whole waves stay in the loop for the ballots
+    for (uint32_t i = blockIdx.x * WAVE + threadIdx.x; i < n_pad; i += gridDim.x * WAVE) {
+        const bool active = i < n;
+        Ray new_ray;
+        ShadowRay sh_r;
+        ShadeResult res;
+        res.emit_secondary = res.emit_shadow = false;
+        uint32_t xy = 0;
+        if (active) {
+            const Ray ray = load_ray(rays_in, i);
+            const Hit inter = load_hit(hits, i);
+            xy = ray.xy;
+            res = shade_surface(sc, sp, inter, ray, new_ray, sh_r);
+            if (PRIMARY) {
+                write_primary_pixel(res, xy, img_w, mix_factor, px.temp, px.base_color, px.depth_normals);
+            } else {
+                add_secondary_pixel(res, xy, img_w, px.temp);
+            }
+        }
+        const uint32_t ray_slot = wave_alloc(out_ray_count, res.emit_secondary);
+        if (res.emit_secondary) {
+            store_ray(rays_out, ray_slot, new_ray);
+        }
+        const uint32_t sh_slot = wave_alloc(out_shadow_count, res.emit_shadow);
+        if (res.emit_shadow) {
+            store_shadow(shadow_out, sh_slot, sh_r);
+        }
+    }
+}
+
+// ---- K10 + K11 ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_accumulate(const AccumParams p, const PixelBuffers px) {
+    const int n = p.rect[2] * p.rect[3];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int x = p.rect[0] + i % p.rect[2], y = p.rect[1] + i / p.rect[2];
+        if (!pixel_owned(p.shard, p.w, x, y)) {
+            continue; // another rank's pixel: stays zero here, filled in by the frame reduce
+        }
+        accumulate_pixel(p, x, y, px.temp, px.full, px.half, px.raw, px.final_, px.required_samples);
+    }
+}
+
+// tonemap-only pass used after the multi-GPU frame reduce (raw/full already hold the combined image)
+__global__ void __launch_bounds__(256) k_retonemap(const AccumParams p, const PixelBuffers px, const int h) {
+    const int n = p.w * h;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 ff = px.full[i];
+        px.raw[i] = ff;
+        f4 c = {ff.x, ff.y, ff.z, ff.w};
+        c.x = tonemap_standard(c.x), c.y = tonemap_standard(c.y), c.z = tonemap_standard(c.z);
+        if (p.inv_gamma != 1.0f) {
+            c.x = powf(c.x, p.inv_gamma), c.y = powf(c.y, p.inv_gamma), c.z = powf(c.z, p.inv_gamma);
+        }
+        c.x = sse_max(0.0f, sse_min(c.x, 1.0f)), c.y = sse_max(0.0f, sse_min(c.y, 1.0f));
+        c.z = sse_max(0.0f, sse_min(c.z, 1.0f)), c.w = sse_max(0.0f, sse_min(c.w, 1.0f));
+        px.final_[i] = mkfloat4(c.x, c.y, c.z, c.w);
+    }
+}
+
+__global__ void k_fill_u16(uint16_t *p, const uint16_t v, const size_t n) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        p[i] = v;
+    }
+}
+__global__ void k_fill_f4(float4 *p, const float4 v, const size_t n) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        p[i] = v;
+    }
+}
+
+// test hook: get_scrambled_2d_rand on the device
+__global__ void k_scrambled_rand(const uint32_t *dims, const uint32_t *seeds, const int32_t *samples, const int n,
+                                 const uint32_t *__restrict__ pmj, float2 *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const f2 r = get_scrambled_2d_rand(dims[i], seeds[i], samples[i], pmj);
+        out[i] = make_float2(r.x, r.y);
+    }
+}
+
+} // namespace rt

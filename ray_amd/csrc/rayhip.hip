@@ -1,0 +1,832 @@
+// rayhip.hip -- implementation of the librayhip C ABI (include/rayhip.h): device memory, stage schedule, readback.
+//
+// Stage schedule of one rayhip_render == one RenderScene iteration, restating the control flow of
+// reference internal/RendererCPU.h:373-659 with the GPU-side bookkeeping of internal/RendererVK.cpp:368-791
+// (everything on one stream, ray counts never leave HBM).
+//
+// There is NO host fallback in this library: without a gfx950 device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rayhip.h"
+#include "kernels.hip.h"
+#include "scene_blob.h"
+
+using namespace rt;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list vl;
+    va_start(vl, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, vl);
+    va_end(vl);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        const hipError_t _e = (expr);                                                                                  \
+        if (_e != hipSuccess) {                                                                                        \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);                    \
+        }                                                                                                              \
+    } while (0)
+
+constexpr int MAX_BOUNCE_SLOTS = 130; // max_total_depth is a uint8 but bounded by MAX_BOUNCES = 128 (Constants.inl:5)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        if (n <= bytes && p) {
+            return 0;
+        }
+        release();
+        if (n == 0) {
+            n = 16;
+        }
+        HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
+        return 0;
+    }
+    void release() {
+        if (p) {
+            (void)hipFree(p);
+        }
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+} // namespace
+
+struct rayhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t props = {};
+    int grid_waves = 0; // resident-ish grid for the wave-per-block kernels
+
+    DevBuf pmj, filter_table;
+    // scene
+    DevBuf nodes, tris, tri_indices, tri_materials, materials, vertices, vtx_indices, mesh_instances, lights, li_indices,
+        light_cwnodes, textures, texels;
+    SceneView sc = {};
+    float bbox_min[3] = {}, bbox_max[3] = {};
+    bool have_scene = false;
+    Shard shard = {64, 1, 0};
+
+    // frame
+    int w = 0, h = 0;
+    DevBuf px_temp, px_full, px_half, px_raw, px_final, px_base, px_dn, px_req;
+    PixelBuffers px = {};
+
+    // wavefront state, sized w*h
+    DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3];
+    RaySoA rays[2] = {};
+    HitSoA hits = {};
+    ShadowSoA shadow = {};
+    DevBuf counters;      // uint32: ray_count[MAX_BOUNCE_SLOTS], shadow_count[MAX_BOUNCE_SLOTS]
+    DevBuf trav_counters; // u64 [2][4]
+
+    // timing
+    std::vector<hipEvent_t> events;
+    double trav_ms[2] = {0.0, 0.0};
+    unsigned long long trav_launches[2] = {0, 0};
+
+    uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + b; }
+    uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + MAX_BOUNCE_SLOTS + b; }
+};
+
+namespace {
+
+int upload(rayhip_ctx *c, DevBuf &b, const void *src, size_t bytes) {
+    if (b.alloc(bytes)) {
+        return 1;
+    }
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    return 0;
+}
+
+int use_device(rayhip_ctx *c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+int alloc_frame(rayhip_ctx *c, int w, int h) {
+    const size_t n = size_t(w) * size_t(h);
+    if (c->px_temp.alloc(n * 16) || c->px_full.alloc(n * 16) || c->px_half.alloc(n * 16) || c->px_raw.alloc(n * 16) ||
+        c->px_final.alloc(n * 16) || c->px_base.alloc(n * 16) || c->px_dn.alloc(n * 16) || c->px_req.alloc(n * 2)) {
+        return 1;
+    }
+    c->px.temp = c->px_temp.as<float4>(), c->px.full = c->px_full.as<float4>(), c->px.half = c->px_half.as<float4>();
+    c->px.raw = c->px_raw.as<float4>(), c->px.final_ = c->px_final.as<float4>();
+    c->px.base_color = c->px_base.as<float4>(), c->px.depth_normals = c->px_dn.as<float4>();
+    c->px.required_samples = c->px_req.as<uint16_t>();
+
+    for (int k = 0; k < 2; ++k) {
+        for (int pl = 0; pl < 5; ++pl) {
+            if (c->ray_planes[k][pl].alloc(n * (pl == 4 ? 8 : 16))) {
+                return 1;
+            }
+        }
+        c->rays[k].o_pdf = c->ray_planes[k][0].as<float4>(), c->rays[k].d_cw = c->ray_planes[k][1].as<float4>();
+        c->rays[k].c_cs = c->ray_planes[k][2].as<float4>(), c->rays[k].ior = c->ray_planes[k][3].as<float4>();
+        c->rays[k].xy_depth = c->ray_planes[k][4].as<uint2>();
+    }
+    if (c->hit_planes[0].alloc(n * 16) || c->hit_planes[1].alloc(n * 4)) {
+        return 1;
+    }
+    c->hits.oi_pi_t_u = c->hit_planes[0].as<float4>(), c->hits.v = c->hit_planes[1].as<float>();
+    for (int pl = 0; pl < 3; ++pl) {
+        if (c->shadow_planes[pl].alloc(n * 16)) {
+            return 1;
+        }
+    }
+    c->shadow.o_depth = c->shadow_planes[0].as<float4>(), c->shadow.d_dist = c->shadow_planes[1].as<float4>();
+    c->shadow.c_xy = c->shadow_planes[2].as<float4>();
+    return 0;
+}
+
+int grid_for(const rayhip_ctx *c, size_t items, int block) {
+    const size_t need = (items + size_t(block) - 1) / size_t(block);
+    const size_t cap = size_t(c->props.multiProcessorCount) * 8u * (256u / unsigned(block) > 0 ? 256u / unsigned(block) : 1u);
+    size_t g = need < cap ? need : cap;
+    return int(g ? g : 1);
+}
+
+// HIP-event stopwatch over the context stream; only active when the caller asked for stats
+struct StageTimer {
+    rayhip_ctx *c;
+    bool on;
+    size_t used = 0;
+    struct Mark {
+        size_t ev;
+        int stage; // index into rayhip_stats, or -1
+        int trav;  // 0 = closest kernel, 1 = shadow kernel, -1 = none
+    };
+    std::vector<Mark> marks;
+    StageTimer(rayhip_ctx *ctx, bool enabled) : c(ctx), on(enabled) {}
+    int mark(int stage, int trav) {
+        if (!on) {
+            return 0;
+        }
+        if (used == c->events.size()) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            c->events.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(c->events[used], c->stream));
+        marks.push_back({used, stage, trav});
+        ++used;
+        return 0;
+    }
+    // mark k carries the label of the interval [k, k+1)
+    int finish(rayhip_stats *st) {
+        if (!on) {
+            return 0;
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        unsigned long long *slots = reinterpret_cast<unsigned long long *>(st);
+        double acc_us[11] = {};
+        for (size_t k = 0; k + 1 < marks.size(); ++k) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, c->events[marks[k].ev], c->events[marks[k + 1].ev]));
+            if (marks[k].stage >= 0) {
+                acc_us[marks[k].stage] += double(ms) * 1000.0;
+            }
+            if (marks[k].trav >= 0) {
+                c->trav_ms[marks[k].trav] += double(ms);
+                c->trav_launches[marks[k].trav] += 1;
+            }
+        }
+        for (int i = 0; i < 11; ++i) {
+            slots[i] += (unsigned long long)(acc_us[i]);
+        }
+        return 0;
+    }
+};
+
+enum { ST_GEN = 0, ST_PTRACE, ST_PSHADE, ST_PSHADOW, ST_SORT, ST_STRACE, ST_SSHADE, ST_SSHADOW };
+
+void rays_to_soa(const rayhip_ray *in, int n, std::vector<float4> pl[4], std::vector<uint2> &xd) {
+    for (int k = 0; k < 4; ++k) {
+        pl[k].resize(size_t(n));
+    }
+    xd.resize(size_t(n));
+    for (int i = 0; i < n; ++i) {
+        const rayhip_ray &r = in[i];
+        pl[0][i] = make_float4(r.o[0], r.o[1], r.o[2], r.pdf);
+        pl[1][i] = make_float4(r.d[0], r.d[1], r.d[2], r.cone_width);
+        pl[2][i] = make_float4(r.c[0], r.c[1], r.c[2], r.cone_spread);
+        pl[3][i] = make_float4(r.ior[0], r.ior[1], r.ior[2], r.ior[3]);
+        xd[i] = make_uint2(r.xy, r.depth);
+    }
+}
+} // namespace
+
+extern "C" {
+
+const char *rayhip_last_error(void) { return g_err.c_str(); }
+
+int rayhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        return 0;
+    }
+    return n;
+}
+
+int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        return fail("no HIP device available (librayhip has no CPU path)");
+    }
+    if (device < 0 || device >= n) {
+        return fail("device %d out of range (have %d)", device, n);
+    }
+    rayhip_ctx *c = new rayhip_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->props, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail("failed to initialise HIP device %d", device);
+    }
+    // 12 KiB of LDS per traversal wave -> 13 waves per CU; use that many blocks per CU as the persistent grid
+    c->grid_waves = c->props.multiProcessorCount * 13;
+    if (c->counters.alloc(sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS) || c->trav_counters.alloc(sizeof(unsigned long long) * 8)) {
+        delete c;
+        return 1;
+    }
+    (void)hipMemsetAsync(c->trav_counters.p, 0, 64, c->stream);
+    *out_ctx = c;
+    return 0;
+}
+
+void rayhip_ctx_destroy(rayhip_ctx *c) {
+    if (!c) {
+        return;
+    }
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->events) {
+        (void)hipEventDestroy(e);
+    }
+    DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
+                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes,
+                     &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
+                     &c->px_dn, &c->px_req, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
+                     &c->shadow_planes[2], &c->counters, &c->trav_counters};
+    for (DevBuf *b : all) {
+        b->release();
+    }
+    for (int k = 0; k < 2; ++k) {
+        for (int pl = 0; pl < 5; ++pl) {
+            c->ray_planes[k][pl].release();
+        }
+    }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rayhip_ctx_device_name(rayhip_ctx *c, char *buf, int cap) {
+    snprintf(buf, size_t(cap), "%s (%s, %d CUs)", c->props.name, c->props.gcnArchName, c->props.multiProcessorCount);
+    return 0;
+}
+
+int rayhip_upload_static(rayhip_ctx *c, const uint32_t *pmj02_samples, uint32_t count) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (count != uint32_t(RAND_DIMS_COUNT) * 2u * uint32_t(RAND_SAMPLES_COUNT)) {
+        return fail("PMJ02 table must hold %u entries, got %u", RAND_DIMS_COUNT * 2 * RAND_SAMPLES_COUNT, count);
+    }
+    if (upload(c, c->pmj, pmj02_samples, size_t(count) * 4)) {
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->sc.pmj = c->pmj.as<uint32_t>();
+    return 0;
+}
+
+int rayhip_resize(rayhip_ctx *c, int w, int h) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) {
+        return fail("bad frame size %dx%d (pixel coordinates are 16-bit)", w, h);
+    }
+    if (c->w == w && c->h == h) {
+        return 0;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (alloc_frame(c, w, h)) {
+        return 1;
+    }
+    c->w = w, c->h = h;
+    const size_t n = size_t(w) * size_t(h);
+    // Resize zero-fills every buffer and arms required_samples (RendererCPU.h:266-295)
+    float4 *bufs[] = {c->px.temp, c->px.full, c->px.half, c->px.raw, c->px.final_, c->px.base_color, c->px.depth_normals};
+    for (float4 *b : bufs) {
+        HIP_TRY(hipMemsetAsync(b, 0, n * 16, c->stream));
+    }
+    k_fill_u16<<<grid_for(c, n, 256), 256, 0, c->stream>>>(c->px.required_samples, uint16_t(0xffff), n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rayhip_clear(rayhip_ctx *c, const float rgba[4]) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->w) {
+        return fail("rayhip_clear before rayhip_resize");
+    }
+    const size_t n = size_t(c->w) * size_t(c->h);
+    const float4 v = make_float4(rgba[0], rgba[1], rgba[2], rgba[3]);
+    // RendererCPU.h:297-301: full, half <- c ; required_samples <- 0xffff
+    k_fill_f4<<<grid_for(c, n, 256), 256, 0, c->stream>>>(c->px.full, v, n);
+    k_fill_f4<<<grid_for(c, n, 256), 256, 0, c->stream>>>(c->px.half, v, n);
+    k_fill_u16<<<grid_for(c, n, 256), 256, 0, c->stream>>>(c->px.required_samples, uint16_t(0xffff), n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (d->env.qtree_levels != 0) {
+        return fail("env-map quadtree importance sampling is not supported (qtree_levels must be 0)");
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+#define UP(field)                                                                                                      \
+    if (upload(c, c->field, d->field, size_t(d->field##_count) * sizeof(*d->field))) {                                 \
+        return 1;                                                                                                      \
+    }
+    UP(nodes)
+    UP(tris)
+    UP(tri_indices)
+    UP(tri_materials)
+    UP(materials)
+    UP(vertices)
+    UP(vtx_indices)
+    UP(mesh_instances)
+    UP(lights)
+    UP(li_indices)
+    UP(light_cwnodes)
+    UP(textures)
+    UP(texels)
+#undef UP
+    HIP_TRY(hipStreamSynchronize(c->stream)); // host arrays may go away after this call
+    SceneView &v = c->sc;
+    v.nodes = c->nodes.as<rayhip_bvh2_node>(), v.tris = c->tris.as<rayhip_tri_accel>();
+    v.tri_indices = c->tri_indices.as<uint32_t>(), v.tri_materials = c->tri_materials.as<rayhip_tri_mat_data>();
+    v.materials = c->materials.as<rayhip_material>(), v.vertices = c->vertices.as<rayhip_vertex>();
+    v.vtx_indices = c->vtx_indices.as<uint32_t>(), v.mesh_instances = c->mesh_instances.as<rayhip_mesh_instance>();
+    v.lights = c->lights.as<rayhip_light>(), v.li_indices = c->li_indices.as<uint32_t>();
+    v.light_cwnodes = c->light_cwnodes.as<rayhip_light_cwbvh_node>(), v.textures = c->textures.as<rayhip_texture>();
+    v.texels = c->texels.as<uint32_t>();
+    memcpy(v.tex_table, d->tex_table, sizeof(v.tex_table));
+    v.li_indices_count = d->li_indices_count;
+    v.light_cwnodes_count = d->light_cwnodes_count;
+    v.visible_lights_count = d->visible_lights_count;
+    v.blocker_lights_count = d->blocker_lights_count;
+    v.tlas_root = d->tlas_root;
+    v.env = d->env;
+    memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
+    c->have_scene = true;
+    return 0;
+}
+
+int rayhip_set_filter_table(rayhip_ctx *c, const float *table, int count) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (count != FILTER_TABLE_SIZE) {
+        return fail("filter table must have %d entries", FILTER_TABLE_SIZE);
+    }
+    if (upload(c, c->filter_table, table, size_t(count) * 4)) {
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rayhip_scene_upload_blob(rayhip_ctx *c, const void *blob, size_t size, rayhip_camera *out_cam) {
+    rayhip_scene_desc d;
+    const float *ft = nullptr;
+    int ftn = 0;
+    std::string err;
+    if (!rayhip_blob::deserialize(blob, size, d, *out_cam, &ft, &ftn, err)) {
+        return fail("%s", err.c_str());
+    }
+    if (rayhip_scene_upload(c, &d)) {
+        return 1;
+    }
+    if (ft && rayhip_set_filter_table(c, ft, ftn)) {
+        return 1;
+    }
+    return 0;
+}
+
+int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration, uint32_t flags,
+                  rayhip_stats *stats) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->w || !c->have_scene || !c->pmj.p || !c->filter_table.p) {
+        return fail("rayhip_render needs resize + upload_static + scene_upload + set_filter_table first");
+    }
+    if (iteration < 1) {
+        return fail("iteration is 1-based");
+    }
+    if (cam->type != 0 /* eCamType::Persp */) {
+        return fail("only perspective cameras are supported");
+    }
+    if (cam->view_transform != 0 /* eViewTransform::Standard */) {
+        return fail("only the Standard view transform is supported");
+    }
+    if (rect[0] < 0 || rect[1] < 0 || rect[2] <= 0 || rect[3] <= 0 || rect[0] + rect[2] > c->w || rect[1] + rect[3] > c->h) {
+        return fail("rect outside the frame");
+    }
+    if (c->sc.visible_lights_count != 0 || c->sc.blocker_lights_count != 0) {
+        return fail("visible / blocker analytic lights (IntersectAreaLights) are not supported yet");
+    }
+    const int max_depth = cam->pass_settings.max_total_depth;
+    if (max_depth + 2 > MAX_BOUNCE_SLOTS) {
+        return fail("max_total_depth too large");
+    }
+    const bool count = (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) != 0;
+    hipStream_t s = c->stream;
+    const size_t npix = size_t(rect[2]) * size_t(rect[3]);
+    const int gw = c->grid_waves;
+    const int gtrace = int(std::min<size_t>(size_t(gw), (npix + WAVE - 1) / WAVE));
+    unsigned long long *tc = c->trav_counters.as<unsigned long long>();
+
+    StageTimer tm(c, stats != nullptr);
+
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS, s));
+
+    const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
+    const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
+    const float mix_factor = 1.0f / float(iteration);
+
+    if (tm.mark(ST_GEN, -1)) {
+        return 1;
+    }
+    k_raygen<<<grid_for(c, npix, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
+                                                    c->rays[0], c->hits, c->ray_count(0));
+    if (tm.mark(ST_PTRACE, 0)) {
+        return 1;
+    }
+    if (c->sc.tlas_root != 0xffffffffu) {
+        if (count) {
+            k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0, tc);
+        } else {
+            k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0, tc);
+        }
+    }
+    int cur = 0;
+    for (int bounce = 0; bounce <= max_depth; ++bounce) {
+        if (bounce > 0) {
+            if (tm.mark(ST_STRACE, 0)) {
+                return 1;
+            }
+            if (count) {
+                k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->rays[cur], c->hits, c->ray_count(bounce), 1, tc);
+            } else {
+                k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->rays[cur], c->hits, c->ray_count(bounce), 1, tc);
+            }
+        }
+        if (tm.mark(bounce == 0 ? ST_PSHADE : ST_SSHADE, -1)) {
+            return 1;
+        }
+        const ShadeParams sp = make_shade_params(*cam, iteration, bounce);
+        if (bounce == 0) {
+            k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_count(bounce), c->rays[cur ^ 1],
+                                                  c->ray_count(bounce + 1), c->shadow, c->shadow_count(bounce), c->px, c->w,
+                                                  mix_factor);
+        } else {
+            k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_count(bounce), c->rays[cur ^ 1],
+                                                   c->ray_count(bounce + 1), c->shadow, c->shadow_count(bounce), c->px, c->w,
+                                                   mix_factor);
+        }
+        if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
+            return 1;
+        }
+        const float limit = shadow_clamp_limit(*cam, bounce);
+        if (count) {
+            k_trace_shadow<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_count(bounce), limit, c->w, c->px.temp,
+                                                         nullptr, tc + 4);
+        } else {
+            k_trace_shadow<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_count(bounce), limit, c->w,
+                                                          c->px.temp, nullptr, tc + 4);
+        }
+        cur ^= 1;
+    }
+    if (tm.mark(-1, -1)) {
+        return 1;
+    }
+    const AccumParams ap = make_accum_params(*cam, c->w, rect, iteration, c->shard);
+    k_accumulate<<<grid_for(c, npix, 256), 256, 0, s>>>(ap, c->px);
+    HIP_TRY(hipGetLastError());
+    if (tm.mark(-1, -1)) {
+        return 1;
+    }
+    if (stats) {
+        if (tm.finish(stats)) {
+            return 1;
+        }
+    }
+    return 0;
+}
+
+int rayhip_set_shard(rayhip_ctx *c, int tile, int shard_count, int shard_index) {
+    if (tile <= 0 || shard_count <= 0 || shard_index < 0 || shard_index >= shard_count) {
+        return fail("bad shard (tile %d, %d of %d)", tile, shard_index, shard_count);
+    }
+    c->shard = Shard{tile, shard_count, shard_index};
+    return 0;
+}
+
+static float4 *pick_buffer(rayhip_ctx *c, int which) {
+    switch (which) {
+    case RAYHIP_BUF_FINAL:
+        return c->px.final_;
+    case RAYHIP_BUF_RAW:
+        return c->px.raw;
+    case RAYHIP_BUF_BASE_COLOR:
+        return c->px.base_color;
+    case RAYHIP_BUF_DEPTH_NORMALS:
+        return c->px.depth_normals;
+    default:
+        return nullptr;
+    }
+}
+
+int rayhip_readback(rayhip_ctx *c, int which, float *dst_rgba, int pitch_px) {
+    if (use_device(c)) {
+        return 1;
+    }
+    float4 *src = pick_buffer(c, which);
+    if (!src) {
+        return fail("bad buffer id %d", which);
+    }
+    HIP_TRY(hipMemcpy2DAsync(dst_rgba, size_t(pitch_px) * 16, src, size_t(c->w) * 16, size_t(c->w) * 16, size_t(c->h),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rayhip_readback_device(rayhip_ctx *c, int which, void *dst_device_rgba, int pitch_px) {
+    if (use_device(c)) {
+        return 1;
+    }
+    float4 *src = pick_buffer(c, which);
+    if (!src) {
+        return fail("bad buffer id %d", which);
+    }
+    HIP_TRY(hipMemcpy2DAsync(dst_device_rgba, size_t(pitch_px) * 16, src, size_t(c->w) * 16, size_t(c->w) * 16, size_t(c->h),
+                             hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rayhip_set_raw_device(rayhip_ctx *c, const void *src_device_rgba, int pitch_px, const rayhip_camera *cam) {
+    if (use_device(c)) {
+        return 1;
+    }
+    HIP_TRY(hipMemcpy2DAsync(c->px.full, size_t(c->w) * 16, src_device_rgba, size_t(pitch_px) * 16, size_t(c->w) * 16,
+                             size_t(c->h), hipMemcpyDeviceToDevice, c->stream));
+    const int rect[4] = {0, 0, c->w, c->h};
+    const AccumParams ap = make_accum_params(*cam, c->w, rect, 1);
+    k_retonemap<<<grid_for(c, size_t(c->w) * c->h, 256), 256, 0, c->stream>>>(ap, c->px, c->h);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rayhip_sync(rayhip_ctx *c) {
+    if (use_device(c)) {
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rayhip_get_trav_counters(rayhip_ctx *c, rayhip_trav_counters out[2], int reset) {
+    if (use_device(c)) {
+        return 1;
+    }
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, c->trav_counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; ++k) {
+        out[k].rays = h[4 * k + 0], out[k].nodes = h[4 * k + 1], out[k].tris = h[4 * k + 2], out[k].instances = h[4 * k + 3];
+    }
+    if (reset) {
+        HIP_TRY(hipMemsetAsync(c->trav_counters.p, 0, sizeof(h), c->stream));
+    }
+    return 0;
+}
+
+int rayhip_get_trav_timing(rayhip_ctx *c, double out_ms[2], unsigned long long out_launches[2], int reset) {
+    for (int k = 0; k < 2; ++k) {
+        out_ms[k] = c->trav_ms[k];
+        out_launches[k] = c->trav_launches[k];
+        if (reset) {
+            c->trav_ms[k] = 0.0, c->trav_launches[k] = 0;
+        }
+    }
+    return 0;
+}
+
+// ---- kernel-level hooks ---------------------------------------------------------------------------------------
+
+int rayhip_k_generate_primary_rays(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration,
+                                   rayhip_ray *out_rays, rayhip_hit *out_hits, int *out_count) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->w || !c->pmj.p || !c->filter_table.p) {
+        return fail("k_generate_primary_rays needs resize + upload_static + set_filter_table first");
+    }
+    hipStream_t s = c->stream;
+    const size_t npix = size_t(rect[2]) * size_t(rect[3]);
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS, s));
+    const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
+    k_raygen<<<grid_for(c, npix, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
+                                                    c->rays[0], c->hits, c->ray_count(0));
+    HIP_TRY(hipGetLastError());
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, c->ray_count(0), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<float4> pl[4], hp(n);
+    std::vector<uint2> xd(n);
+    std::vector<float> hv(n);
+    for (int k = 0; k < 4; ++k) {
+        pl[k].resize(n);
+        HIP_TRY(hipMemcpy(pl[k].data(), c->ray_planes[0][k].p, size_t(n) * 16, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipMemcpy(xd.data(), c->ray_planes[0][4].p, size_t(n) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hp.data(), c->hit_planes[0].p, size_t(n) * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hv.data(), c->hit_planes[1].p, size_t(n) * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {
+        rayhip_ray &r = out_rays[i];
+        r.o[0] = pl[0][i].x, r.o[1] = pl[0][i].y, r.o[2] = pl[0][i].z, r.pdf = pl[0][i].w;
+        r.d[0] = pl[1][i].x, r.d[1] = pl[1][i].y, r.d[2] = pl[1][i].z, r.cone_width = pl[1][i].w;
+        r.c[0] = pl[2][i].x, r.c[1] = pl[2][i].y, r.c[2] = pl[2][i].z, r.cone_spread = pl[2][i].w;
+        r.ior[0] = pl[3][i].x, r.ior[1] = pl[3][i].y, r.ior[2] = pl[3][i].z, r.ior[3] = pl[3][i].w;
+        r.xy = xd[i].x, r.depth = xd[i].y;
+        rayhip_hit &h = out_hits[i];
+        memcpy(&h.obj_index, &hp[i].x, 4), memcpy(&h.prim_index, &hp[i].y, 4);
+        h.t = hp[i].z, h.u = hp[i].w, h.v = hv[i];
+    }
+    *out_count = int(n);
+    return 0;
+}
+
+int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_ray *rays, rayhip_hit *hits, int count,
+                               int iteration, rayhip_trav_counters *out_counters) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->have_scene || !c->pmj.p) {
+        return fail("k_intersect_closest needs a scene and the PMJ table");
+    }
+    if (size_t(count) > size_t(c->w) * size_t(c->h)) {
+        return fail("ray count exceeds the wavefront buffers (w*h)");
+    }
+    hipStream_t s = c->stream;
+    std::vector<float4> pl[4], hp;
+    hp.resize(size_t(count));
+    std::vector<uint2> xd;
+    std::vector<float> hv{};
+    hv.resize(size_t(count));
+    rays_to_soa(rays, count, pl, xd);
+    for (int i = 0; i < count; ++i) {
+        float oi, pi;
+        memcpy(&oi, &hits[i].obj_index, 4), memcpy(&pi, &hits[i].prim_index, 4);
+        hp[i] = make_float4(oi, pi, hits[i].t, hits[i].u);
+        hv[i] = hits[i].v;
+    }
+    for (int k = 0; k < 4; ++k) {
+        HIP_TRY(hipMemcpy(c->ray_planes[0][k].p, pl[k].data(), size_t(count) * 16, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(c->ray_planes[0][4].p, xd.data(), size_t(count) * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->hit_planes[0].p, hp.data(), size_t(count) * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->hit_planes[1].p, hv.data(), size_t(count) * 4, hipMemcpyHostToDevice));
+    const uint32_t n = uint32_t(count);
+    HIP_TRY(hipMemcpy(c->ray_count(0), &n, 4, hipMemcpyHostToDevice));
+    unsigned long long *tc = c->trav_counters.as<unsigned long long>();
+    unsigned long long before[4], after[4];
+    HIP_TRY(hipMemcpy(before, tc, sizeof(before), hipMemcpyDeviceToHost));
+    const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
+    const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
+    k_trace_closest<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0, tc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(after, tc, sizeof(after), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tc, before, sizeof(before), hipMemcpyHostToDevice));
+    if (out_counters) {
+        out_counters->rays = after[0] - before[0], out_counters->nodes = after[1] - before[1];
+        out_counters->tris = after[2] - before[2], out_counters->instances = after[3] - before[3];
+    }
+    HIP_TRY(hipMemcpy(pl[2].data(), c->ray_planes[0][2].p, size_t(count) * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(xd.data(), c->ray_planes[0][4].p, size_t(count) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hp.data(), c->hit_planes[0].p, size_t(count) * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hv.data(), c->hit_planes[1].p, size_t(count) * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; ++i) {
+        rays[i].c[0] = pl[2][i].x, rays[i].c[1] = pl[2][i].y, rays[i].c[2] = pl[2][i].z;
+        rays[i].depth = xd[i].y;
+        memcpy(&hits[i].obj_index, &hp[i].x, 4), memcpy(&hits[i].prim_index, &hp[i].y, 4);
+        hits[i].t = hp[i].z, hits[i].u = hp[i].w, hits[i].v = hv[i];
+    }
+    return 0;
+}
+
+int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const rayhip_shadow_ray *rays, int count,
+                              int iteration, float *out_rc, rayhip_trav_counters *out_counters) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->have_scene || !c->pmj.p) {
+        return fail("k_intersect_shadow needs a scene and the PMJ table");
+    }
+    if (size_t(count) > size_t(c->w) * size_t(c->h)) {
+        return fail("ray count exceeds the wavefront buffers (w*h)");
+    }
+    hipStream_t s = c->stream;
+    std::vector<float4> pl[3];
+    for (int k = 0; k < 3; ++k) {
+        pl[k].resize(size_t(count));
+    }
+    for (int i = 0; i < count; ++i) {
+        float depth_f, xy_f;
+        memcpy(&depth_f, &rays[i].depth, 4), memcpy(&xy_f, &rays[i].xy, 4);
+        pl[0][i] = make_float4(rays[i].o[0], rays[i].o[1], rays[i].o[2], depth_f);
+        pl[1][i] = make_float4(rays[i].d[0], rays[i].d[1], rays[i].d[2], rays[i].dist);
+        pl[2][i] = make_float4(rays[i].c[0], rays[i].c[1], rays[i].c[2], xy_f);
+    }
+    for (int k = 0; k < 3; ++k) {
+        HIP_TRY(hipMemcpy(c->shadow_planes[k].p, pl[k].data(), size_t(count) * 16, hipMemcpyHostToDevice));
+    }
+    const uint32_t n = uint32_t(count);
+    HIP_TRY(hipMemcpy(c->shadow_count(0), &n, 4, hipMemcpyHostToDevice));
+    unsigned long long *tc = c->trav_counters.as<unsigned long long>() + 4;
+    unsigned long long before[4], after[4];
+    HIP_TRY(hipMemcpy(before, tc, sizeof(before), hipMemcpyDeviceToHost));
+    const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
+    const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
+    // results land in the (otherwise idle) hit plane
+    k_trace_shadow<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_count(0), FLT_MAX, c->w, c->px.temp,
+                                                    c->hit_planes[0].as<float4>(), tc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(after, tc, sizeof(after), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tc, before, sizeof(before), hipMemcpyHostToDevice));
+    if (out_counters) {
+        out_counters->rays = after[0] - before[0], out_counters->nodes = after[1] - before[1];
+        out_counters->tris = after[2] - before[2], out_counters->instances = after[3] - before[3];
+    }
+    HIP_TRY(hipMemcpy(out_rc, c->hit_planes[0].p, size_t(count) * 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rayhip_k_scrambled_rand(rayhip_ctx *c, const uint32_t *dims, const uint32_t *seeds, const int32_t *samples, int count,
+                            float *out_xy) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->pmj.p) {
+        return fail("k_scrambled_rand needs the PMJ table");
+    }
+    DevBuf d, sd, sm, o;
+    if (d.alloc(size_t(count) * 4) || sd.alloc(size_t(count) * 4) || sm.alloc(size_t(count) * 4) || o.alloc(size_t(count) * 8)) {
+        return 1;
+    }
+    HIP_TRY(hipMemcpy(d.p, dims, size_t(count) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sd.p, seeds, size_t(count) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sm.p, samples, size_t(count) * 4, hipMemcpyHostToDevice));
+    k_scrambled_rand<<<(count + 255) / 256, 256, 0, c->stream>>>(d.as<uint32_t>(), sd.as<uint32_t>(), sm.as<int32_t>(), count,
+                                                                 c->sc.pmj, o.as<float2>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out_xy, o.p, size_t(count) * 8, hipMemcpyDeviceToHost));
+    d.release(), sd.release(), sm.release(), o.release();
+    return 0;
+}
+
+} // extern "C"

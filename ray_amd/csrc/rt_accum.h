@@ -18,6 +18,7 @@ struct AccumParams {
     int view_transform;    // only Standard (0) is supported
     float inv_gamma;
     float variance_threshold;
+    Shard shard;
 };
 
 // TonemapRef.h:19-28

@@ -285,4 +285,19 @@ RT_HD f3 transform_normal(f3 n, const float *im) {
 RT_HD f3 world_from_tangent(f3 T, f3 B, f3 N, f3 V) { return V.x * T + V.y * B + V.z * N; } // CoreRef.h:296
 RT_HD f3 tangent_from_world(f3 T, f3 B, f3 N, f3 V) { return f3{dot(V, T), dot(V, B), dot(V, N)}; }
 
+// ---- multi-GPU tile sharding ---------------------------------------------------------
+// The frame is cut into `tile` x `tile` squares walked row-major and dealt round-robin to `count` ranks; every
+// rank owns the pixels of its tiles for the whole render.  Pixels are independent (RNG is keyed by x,y,iteration:
+// CoreRef.cpp:1477-1478), so the union of the ranks' images is bit-identical to a single-GPU render.
+struct Shard {
+    int tile, count, index;
+};
+RT_HD bool pixel_owned(const Shard &sh, const int img_w, const int x, const int y) {
+    if (sh.count <= 1) {
+        return true;
+    }
+    const int tiles_x = (img_w + sh.tile - 1) / sh.tile;
+    return ((y / sh.tile) * tiles_x + (x / sh.tile)) % sh.count == sh.index;
+}
+
 } // namespace rt

@@ -16,7 +16,8 @@ inline uint32_t iteration_rand_seed(int iteration) { // RendererCPU.h:446
     return hash(uint32_t((iteration - 1) / RAND_SAMPLES_COUNT));
 }
 
-inline RayGenParams make_raygen_params(const rayhip_camera &cam, int w, int h, const int rect[4], int iteration) {
+inline RayGenParams make_raygen_params(const rayhip_camera &cam, int w, int h, const int rect[4], int iteration,
+                                       const Shard shard = Shard{64, 1, 0}) {
     RayGenParams p;
     p.origin = mk3(cam.origin), p.fwd = mk3(cam.fwd), p.side = mk3(cam.side), p.up = mk3(cam.up);
     p.focus_distance = cam.focus_distance;
@@ -36,6 +37,7 @@ inline RayGenParams make_raygen_params(const rayhip_camera &cam, int w, int h, c
     }
     p.iteration = iteration;
     p.rand_seed = iteration_rand_seed(iteration);
+    p.shard = shard;
     return p;
 }
 
@@ -91,7 +93,8 @@ inline int popcount32(uint32_t x) {
     return c;
 }
 
-inline AccumParams make_accum_params(const rayhip_camera &cam, int w, const int rect[4], int iteration) {
+inline AccumParams make_accum_params(const rayhip_camera &cam, int w, const int rect[4], int iteration,
+                                     const Shard shard = Shard{64, 1, 0}) {
     AccumParams p;
     p.w = w;
     for (int i = 0; i < 4; ++i) {
@@ -107,6 +110,7 @@ inline AccumParams make_accum_params(const rayhip_camera &cam, int w, const int 
     p.variance_threshold = iteration > cam.pass_settings.min_samples
                                ? 0.5f * cam.pass_settings.variance_threshold * cam.pass_settings.variance_threshold
                                : 0.0f; // :583-586
+    p.shard = shard;
     return p;
 }
 

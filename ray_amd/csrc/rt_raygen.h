@@ -24,6 +24,7 @@ struct RayGenParams {
     int rect[4];
     int iteration;
     uint32_t rand_seed;
+    Shard shard;
 };
 
 // CoreRef.cpp:1452-1467

@@ -71,7 +71,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 ENTRY_POINTS = (
     "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
     "scene_upload", "scene_upload_blob", "set_filter_table", "render", "readback", "readback_device", "set_raw_device",
-    "sync", "get_trav_counters", "get_trav_timing", "k_generate_primary_rays", "k_intersect_closest",
+    "sync", "set_shard", "get_trav_counters", "get_trav_timing", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand",
 )
 
@@ -105,6 +105,7 @@ class Library:
         f("render").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_uint32, C.POINTER(Stats)]
         f("readback").argtypes = [vp, C.c_int, vp, C.c_int]
         f("sync").argtypes = [vp]
+        f("set_shard").argtypes = [vp, C.c_int, C.c_int, C.c_int]
         f("get_trav_counters").argtypes = [vp, C.POINTER(TravCounters * 2), C.c_int]
         f("k_generate_primary_rays").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, vp, vp, C.POINTER(C.c_int)]
         f("k_intersect_closest").argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int, C.c_int, C.POINTER(TravCounters)]
@@ -190,6 +191,10 @@ class Context:
     def set_raw_device(self, device_ptr: int, pitch_px: int = None, cam: Camera = None):
         cam = cam or self.cam
         self.L.check(self.L.fn("set_raw_device")(self._ctx, C.c_void_p(device_ptr), pitch_px or self.w, C.byref(cam)))
+
+    def set_shard(self, tile: int, shard_count: int, shard_index: int):
+        """multi-GPU tile sharding: render only the tiles whose ordinal % shard_count == shard_index"""
+        self.L.check(self.L.fn("set_shard")(self._ctx, tile, shard_count, shard_index))
 
     def sync(self):
         self.L.check(self.L.fn("sync")(self._ctx))

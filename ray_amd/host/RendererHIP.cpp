@@ -1,0 +1,275 @@
+// RendererHIP.cpp -- Ray::RendererBase / Ray::SceneBase implementation on top of the librayhip C ABI.
+//
+// This is the reference-side half of the drop-in: it would live in the reference tree as
+// internal/RendererHIP.{h,cpp} + internal/SceneHIP.h next to RendererVK.cpp / SceneVK.h, and like them it
+// contains no kernel code -- only the RendererBase plumbing (RendererBase.h:138-252).  It includes no HIP
+// header: everything device-side happens behind include/rayhip.h.
+//
+// SceneHIP reuses the reference's host-side scene code as is ("host side reused as-is by
+// SceneHIP"): it IS a Cpu::Scene built with the 2-wide BVH (use_wide_bvh = false, like the Reference backend,
+// RendererCPU.h:368-371) whose flat arrays are uploaded after every mutation.
+#include "RendererHIP.h"
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <shared_mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "Log.h"
+#include "internal/CDFUtils.h"
+#include "internal/Core.h"
+#include "internal/SceneCPU.h"
+
+#include "../../include/rayhip.h"
+#include "scene_export.h"
+
+namespace Ray {
+namespace Hip {
+
+class Scene final : public Cpu::Scene {
+    std::atomic<uint64_t> version_{1};
+
+  public:
+    explicit Scene(ILog *log) : Cpu::Scene(log, false /* use_wide_bvh */, false /* use_tex_compression */, false) {}
+
+    uint64_t version() const { return version_.load(); }
+
+// every mutator that changes an uploaded array bumps the version (cameras are passed per RenderScene call)
+#define BUMP(ret, name, params, args)                                                                                  \
+    ret name params override {                                                                                        \
+        ++version_;                                                                                                    \
+        return Cpu::Scene::name args;                                                                                  \
+    }
+    BUMP(void, SetEnvironment, (const environment_desc_t &env), (env))
+    BUMP(TextureHandle, AddTexture, (const tex_desc_t &t), (t))
+    BUMP(void, RemoveTexture, (const TextureHandle t), (t))
+    BUMP(MaterialHandle, AddMaterial, (const shading_node_desc_t &m), (m))
+    BUMP(MaterialHandle, AddMaterial, (const principled_mat_desc_t &m), (m))
+    BUMP(void, RemoveMaterial, (const MaterialHandle m), (m))
+    BUMP(MeshHandle, AddMesh, (const mesh_desc_t &m), (m))
+    BUMP(void, RemoveMesh, (MeshHandle m), (m))
+    BUMP(LightHandle, AddLight, (const directional_light_desc_t &l), (l))
+    BUMP(LightHandle, AddLight, (const sphere_light_desc_t &l), (l))
+    BUMP(LightHandle, AddLight, (const spot_light_desc_t &l), (l))
+    BUMP(LightHandle, AddLight, (const rect_light_desc_t &l, const float *xform), (l, xform))
+    BUMP(LightHandle, AddLight, (const disk_light_desc_t &l, const float *xform), (l, xform))
+    BUMP(LightHandle, AddLight, (const line_light_desc_t &l, const float *xform), (l, xform))
+    BUMP(void, RemoveLight, (LightHandle l), (l))
+    BUMP(MeshInstanceHandle, AddMeshInstance, (const mesh_instance_desc_t &mi), (mi))
+    BUMP(void, SetMeshInstanceTransform, (MeshInstanceHandle mi, const float *xform), (mi, xform))
+    BUMP(void, RemoveMeshInstance, (MeshInstanceHandle mi), (mi))
+    BUMP(void, Finalize, (const std::function<void(int, int, ParallelForFunction &&)> &parallel_for), (parallel_for))
+#undef BUMP
+};
+
+class Renderer final : public RendererBase {
+    ILog *log_;
+    rayhip_ctx *ctx_ = nullptr;
+    std::string device_name_;
+    int w_ = 0, h_ = 0;
+
+    const Scene *uploaded_scene_ = nullptr;
+    uint64_t uploaded_version_ = 0;
+
+    ePixelFilter filter_table_filter_ = ePixelFilter(-1);
+    float filter_table_width_ = 0.0f;
+
+    bool collect_stats_ = false;
+    stats_t stats_ = {};
+    std::mutex mtx_;
+
+    // host mirrors handed out by get_*_pixels_ref (valid until the next mutating call, like RendererVK.cpp:1698-1757)
+    mutable std::vector<color_rgba_t> host_[4];
+    mutable bool host_dirty_[4] = {true, true, true, true};
+
+    void check(const int status, const char *what) const {
+        if (status != 0) {
+            log_->Error("RendererHIP: %s failed: %s", what, rayhip_last_error());
+        }
+    }
+
+    color_data_rgba_t fetch(const int which) const {
+        if (host_dirty_[which]) {
+            host_[which].resize(size_t(w_) * h_);
+            check(rayhip_readback(ctx_, which, &host_[which][0].v[0], w_), "rayhip_readback");
+            host_dirty_[which] = false;
+        }
+        return {host_[which].data(), w_};
+    }
+
+    void UpdateFilterTable(ePixelFilter filter, float filter_width) {
+        // same construction as Cpu::Renderer::UpdateFilterTable, RendererCPU.h:1234-1258
+        float (*filter_func)(float v, float width) = nullptr;
+        switch (filter) {
+        case ePixelFilter::Box:
+            filter_func = filter_box;
+            filter_width = 1.0f;
+            break;
+        case ePixelFilter::Gaussian:
+            filter_func = filter_gaussian;
+            filter_width *= 3.0f;
+            break;
+        case ePixelFilter::BlackmanHarris:
+            filter_func = filter_blackman_harris;
+            filter_width *= 2.0f;
+            break;
+        default:
+            log_->Error("RendererHIP: unknown pixel filter");
+            return;
+        }
+        const std::vector<float> table = Ray::CDFInverted(FILTER_TABLE_SIZE, 0.0f, filter_width * 0.5f,
+                                                          std::bind(filter_func, std::placeholders::_1, filter_width), true);
+        check(rayhip_set_filter_table(ctx_, table.data(), int(table.size())), "rayhip_set_filter_table");
+    }
+
+  public:
+    Renderer(const settings_t &s, ILog *log) : log_(log) {
+        if (rayhip_device_count() <= 0) {
+            throw std::runtime_error("no HIP device found");
+        }
+        int device = 0;
+        if (const char *e = getenv("RAY_HIP_DEVICE")) {
+            device = atoi(e);
+        }
+        if (!s.preferred_device.empty()) {
+            // settings_t::preferred_device (RendererBase.h:54): a plain device ordinal for this backend
+            device = atoi(std::string(s.preferred_device).c_str());
+        }
+        if (rayhip_ctx_create(device, &ctx_) != 0) {
+            throw std::runtime_error(std::string("rayhip_ctx_create: ") + rayhip_last_error());
+        }
+        char name[256] = {};
+        rayhip_ctx_device_name(ctx_, name, sizeof(name));
+        device_name_ = name;
+        collect_stats_ = getenv("RAY_HIP_STATS") != nullptr;
+
+        log->Info("============================================================================");
+        log->Info("Device       is %s", device_name_.c_str());
+        log->Info("Wavefront    is 64 lanes, traversal stack %i entries/lane in LDS", MAX_STACK_SIZE);
+        log->Info("============================================================================");
+
+        // PMJ02 table upload, RendererVK.cpp:299-311
+        if (rayhip_upload_static(ctx_, __pmj02_samples, uint32_t(__pmj02_dims_count) * 2u * uint32_t(__pmj02_sample_count)) != 0) {
+            const std::string err = rayhip_last_error();
+            rayhip_ctx_destroy(ctx_);
+            throw std::runtime_error("rayhip_upload_static: " + err);
+        }
+        Resize(s.w, s.h);
+    }
+    ~Renderer() override { rayhip_ctx_destroy(ctx_); }
+
+    eRendererType type() const override { return RendererTypeHIP; }
+    ILog *log() const override { return log_; }
+    std::string_view device_name() const override { return device_name_; }
+    std::pair<int, int> size() const override { return std::pair{w_, h_}; }
+
+    color_data_rgba_t get_pixels_ref() const override { return fetch(RAYHIP_BUF_FINAL); }
+    color_data_rgba_t get_raw_pixels_ref() const override { return fetch(RAYHIP_BUF_RAW); }
+    color_data_rgba_t get_aux_pixels_ref(const eAUXBuffer buf) const override {
+        if (buf == eAUXBuffer::BaseColor) {
+            return fetch(RAYHIP_BUF_BASE_COLOR);
+        } else if (buf == eAUXBuffer::DepthNormals) {
+            return fetch(RAYHIP_BUF_DEPTH_NORMALS);
+        }
+        return {};
+    }
+    const shl1_data_t *get_sh_data_ref() const override { return nullptr; }
+
+    void Resize(const int w, const int h) override {
+        if (w_ != w || h_ != h) {
+            check(rayhip_resize(ctx_, w, h), "rayhip_resize");
+            w_ = w, h_ = h;
+            for (bool &d : host_dirty_) {
+                d = true;
+            }
+        }
+    }
+    void Clear(const color_rgba_t &c) override {
+        check(rayhip_clear(ctx_, c.v), "rayhip_clear");
+        for (bool &d : host_dirty_) {
+            d = true;
+        }
+    }
+
+    SceneBase *CreateScene() override { return new Scene(log_); }
+
+    void RenderScene(const SceneBase &scene, RegionContext &region) override {
+        const auto *s = dynamic_cast<const Scene *>(&scene);
+        if (!s) {
+            log_->Error("RendererHIP: scene was not created by this backend");
+            return;
+        }
+        std::shared_lock<std::shared_timed_mutex> scene_lock(SceneAccess::Mutex(*s));
+
+        if (uploaded_scene_ != s || uploaded_version_ != s->version()) {
+            try {
+                FlatScene flat;
+                SceneAccess::Export(*s, flat);
+                check(rayhip_scene_upload(ctx_, &flat.desc), "rayhip_scene_upload");
+            } catch (std::exception &e) {
+                log_->Error("RendererHIP: %s", e.what());
+                return;
+            }
+            uploaded_scene_ = s;
+            uploaded_version_ = s->version();
+        }
+
+        const camera_t &cam = SceneAccess::CurrentCamera(*s);
+        if (cam.filter != filter_table_filter_ || cam.filter_width != filter_table_width_) {
+            UpdateFilterTable(cam.filter, cam.filter_width);
+            filter_table_filter_ = cam.filter;
+            filter_table_width_ = cam.filter_width;
+        }
+
+        ++region.iteration; // RendererCPU.h:384
+
+        rayhip_camera rc;
+        memcpy(&rc, &cam, sizeof(rc));
+        const rect_t &rect = region.rect();
+        const int r[4] = {rect.x, rect.y, rect.w, rect.h};
+        rayhip_stats st = {};
+        check(rayhip_render(ctx_, &rc, r, region.iteration, 0u, collect_stats_ ? &st : nullptr), "rayhip_render");
+        if (collect_stats_) {
+            std::lock_guard<std::mutex> _(mtx_);
+            const auto *src = reinterpret_cast<const unsigned long long *>(&st);
+            auto *dst = reinterpret_cast<unsigned long long *>(&stats_);
+            for (int i = 0; i < 11; ++i) {
+                dst[i] += src[i];
+            }
+        }
+        for (bool &d : host_dirty_) {
+            d = true;
+        }
+    }
+
+    // post-processing / caching stages are outside the hot path (OUT OF SCOPE)
+    void DenoiseImage(const RegionContext &) override { log_->Warning("RendererHIP: NLM denoiser is not implemented"); }
+    void DenoiseImage(int, const RegionContext &) override { log_->Warning("RendererHIP: UNet denoiser is not implemented"); }
+    void UpdateSpatialCache(const SceneBase &, RegionContext &) override {}
+    void ResolveSpatialCache(const SceneBase &, const std::function<void(int, int, ParallelForFunction &&)> &) override {}
+    void ResetSpatialCache(const SceneBase &, const std::function<void(int, int, ParallelForFunction &&)> &) override {}
+
+    void GetStats(stats_t &st) override {
+        std::lock_guard<std::mutex> _(mtx_);
+        st = stats_;
+    }
+    void ResetStats() override {
+        std::lock_guard<std::mutex> _(mtx_);
+        stats_ = {};
+    }
+
+    unet_filter_properties_t InitUNetFilter(bool, const std::function<void(int, int, ParallelForFunction &&)> &) override {
+        log_->Warning("RendererHIP: UNet denoiser is not implemented");
+        return {};
+    }
+};
+
+RendererBase *CreateRenderer(const settings_t &s, ILog *log) { return new Renderer(s, log); }
+
+} // namespace Hip
+} // namespace Ray

@@ -1,0 +1,24 @@
+// RendererHIP.h -- the new backend's factory, in the style of the reference's internal/RendererVK.h:9-10.
+//
+// Drop-in recipe (INTEGRATION.md has the full patch):
+//   RendererBase.h:22-34   enum class eRendererType { ..., Vulkan, DirectX12, HIP };   // + RendererGPU mask :41
+//   RendererBase.cpp:6-48  "HIP" <-> eRendererType::HIP in RendererTypeName / RendererTypeFromName
+//   Ray.cpp:53-73          if (enabled_types & eRendererType::HIP) try { return Hip::CreateRenderer(s, log); } catch ...
+//   Config.h.in            #cmakedefine ENABLE_HIP_IMPL
+// This tree cannot edit the (read-only) reference, so the type id is provided here as a constant with the
+// value the enum entry would get.
+#pragma once
+
+#include "RendererBase.h"
+
+namespace Ray {
+class ILog;
+namespace Hip {
+// value of eRendererType::HIP once appended after DirectX12 (RendererBase.h:33)
+constexpr eRendererType RendererTypeHIP = eRendererType(uint32_t(eRendererType::DirectX12) + 1);
+
+// Throws std::runtime_error when no gfx950 device / librayhip is unavailable -- the factory convention of the
+// GPU backends (Ray.cpp:58-63) -- so that Ray::CreateRenderer can fall through to the next enabled type.
+RendererBase *CreateRenderer(const settings_t &s, ILog *log);
+} // namespace Hip
+} // namespace Ray

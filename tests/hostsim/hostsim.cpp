@@ -53,6 +53,7 @@ struct hostsim_ctx {
     std::vector<float4> temp, full, half, raw, final_, base_color, depth_normals;
     std::vector<uint16_t> required_samples;
     rayhip_trav_counters counters[2] = {};
+    Shard shard = {64, 1, 0};
 };
 
 #define HS_API extern "C" __attribute__((visibility("default")))
@@ -154,7 +155,7 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
                           rayhip_stats *) {
     const bool count = (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) != 0;
     const int w = c->w;
-    const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration);
+    const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const float mix_factor = 1.0f / float(iteration);
 
@@ -164,7 +165,7 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
     // K1: primary rays (CoreRef.cpp:1471-1553), skipping pixels that need no more samples
     for (int y = rect[1]; y < rect[1] + rect[3]; ++y) {
         for (int x = rect[0]; x < rect[0] + rect[2]; ++x) {
-            if (c->required_samples[size_t(y) * w + x] < iteration) {
+            if (!pixel_owned(c->shard, w, x, y) || c->required_samples[size_t(y) * w + x] < iteration) {
                 continue;
             }
             Ray r;
@@ -232,9 +233,12 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
         rays.swap(next_rays);
     }
     // K10+K11
-    const AccumParams ap = make_accum_params(*cam, w, rect, iteration);
+    const AccumParams ap = make_accum_params(*cam, w, rect, iteration, c->shard);
     for (int y = rect[1]; y < rect[1] + rect[3]; ++y) {
         for (int x = rect[0]; x < rect[0] + rect[2]; ++x) {
+            if (!pixel_owned(c->shard, w, x, y)) {
+                continue;
+            }
             accumulate_pixel(ap, x, y, c->temp.data(), c->full.data(), c->half.data(), c->raw.data(), c->final_.data(),
                              c->required_samples.data());
         }
@@ -267,6 +271,10 @@ HS_API int hostsim_readback(hostsim_ctx *c, int which, float *dst, int pitch_px)
     return 0;
 }
 HS_API int hostsim_sync(hostsim_ctx *) { return 0; }
+HS_API int hostsim_set_shard(hostsim_ctx *c, int tile, int shard_count, int shard_index) {
+    c->shard = Shard{tile, shard_count, shard_index};
+    return 0;
+}
 
 HS_API int hostsim_get_trav_counters(hostsim_ctx *c, rayhip_trav_counters out[2], int reset) {
     out[0] = c->counters[0], out[1] = c->counters[1];
@@ -297,7 +305,7 @@ static rayhip_ray to_abi(const Ray &r) {
 
 HS_API int hostsim_k_generate_primary_rays(hostsim_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration,
                                            rayhip_ray *out_rays, rayhip_hit *out_hits, int *out_count) {
-    const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration);
+    const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
     int n = 0;
     for (int y = rect[1]; y < rect[1] + rect[3]; ++y) {
         for (int x = rect[0]; x < rect[0] + rect[2]; ++x) {

@@ -1,0 +1,89 @@
+"""CPU gate: the kernel sources (ray_amd/csrc/rt_*.h) compiled for the host must reproduce RendererRef BIT FOR BIT.
+
+tests/hostsim builds the very headers the HIP kernels are made of with g++ -msse2 -mno-avx (no fma, glibc libm --
+the reference's own build flags), so any difference from the reference's golden vectors is a restatement error,
+not a numerics artefact.  This is what lets the GPU tests attribute their (small) differences to the device.
+Runs without a GPU.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import util
+from ray_amd import hip
+
+SCENES = ["cornell_basic", "cornell_principled"]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not O.have_hostsim():
+        pytest.skip("tests/hostsim not built (run __graft_entry__.build())")
+    return hip.Library(O.HOSTSIM_LIB, prefix="hostsim_")
+
+
+def test_rng_known_answers(lib):
+    v = np.load(f"{util.GOLDEN}/rng_vectors.npz")
+    ctx = hip.Context(0, lib)
+    ctx.upload_static(util.pmj())
+    out = ctx.k_scrambled_rand(v["dims"], v["seeds"], v["samples"])
+    assert np.array_equal(out.view(np.uint32), v["xy"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_kernel_level_dumps(lib, name):
+    g = util.golden_ref(name)
+    ctx = util.make_context(lib, name)
+    rays, hits = ctx.k_generate_primary_rays(1)
+    assert rays.tobytes() == g["primary_rays"].tobytes()
+    assert hits.tobytes() == g["primary_hits_in"].tobytes()
+    rays2, hits2, tc = ctx.k_intersect_closest(rays, hits, 1)
+    assert hits2.tobytes() == g["primary_hits"].tobytes()
+    assert tc["rays"] == len(rays)
+    rc, _ = ctx.k_intersect_shadow(g["shadow_rays"], 1)
+    assert np.array_equal(rc, g["shadow_rc"])
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_frames_bit_exact(lib, name):
+    g = util.golden_ref(name)
+    ctx = util.make_context(lib, name)
+    ctx.render(1)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), g["raw_spp1"])
+    for it in range(2, 9):
+        ctx.render(it)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), g["raw_spp8"])
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), g["final_spp8"])
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), g["base_color_spp8"])
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), g["depth_normals_spp8"])
+
+
+def test_tile_sharding_and_rects(lib):
+    name = "cornell_basic"
+    w = h = 96
+    full = util.render_frames(util.make_context(lib, name, w, h), 2)
+    acc = np.zeros_like(full)
+    for r in range(3):
+        ctx = util.make_context(lib, name, w, h)
+        ctx.set_shard(32, 3, r)
+        acc += util.render_frames(ctx, 2)
+    assert np.array_equal(acc, full)
+    ctx = util.make_context(lib, name, w, h)
+    for it in (1, 2):
+        ctx.render(it, rect=(0, 0, w, 40))
+        ctx.render(it, rect=(0, 40, w, h - 40))
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), full)
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,w,h,spp", [("cornell_basic", 160, 96, 5), ("cornell_principled", 96, 160, 5)])
+def test_live_reference_other_sizes(lib, name, w, h, spp):
+    """non-square frames, against the reference run live (not the fixtures)"""
+    from ray_amd import api, scenes
+
+    r, s = O.render_ref(scenes.SCENES[name], w, h, spp)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    img = util.render_frames(ctx, spp)
+    assert np.array_equal(img, r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), r.get_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
