@@ -271,7 +271,9 @@ enum {
 
 enum {
     RAYHIP_FLAG_SORT_RAYS = 1u << 0,     /* ray sort between bounces (RendererVK.cpp:641-652) */
-    RAYHIP_FLAG_COUNT_TRAVERSAL = 1u << 1 /* run the instrumented traversal kernels (slower) */
+    RAYHIP_FLAG_COUNT_TRAVERSAL = 1u << 1, /* run the instrumented traversal kernels (slower) */
+    RAYHIP_FLAG_TIME_STAGES = 1u << 2      /* record HIP events around every stage WITHOUT synchronising; read the
+                                              result later with rayhip_get_stage_times / rayhip_get_trav_timing */
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -338,8 +340,11 @@ RAYHIP_API int rayhip_sync(rayhip_ctx *ctx);
 /* traversal counters accumulated by RAYHIP_FLAG_COUNT_TRAVERSAL renders since the last reset:
  * [0] closest-hit kernel (K2), [1] shadow any-hit kernel (K3) */
 RAYHIP_API int rayhip_get_trav_counters(rayhip_ctx *ctx, rayhip_trav_counters out[2], int reset);
+/* per-stage GPU time (us) accumulated by renders that passed stats != NULL or RAYHIP_FLAG_TIME_STAGES; this is
+ * what RendererBase::GetStats (RendererBase.h:245) returns for the HIP backend.  Synchronises the stream. */
+RAYHIP_API int rayhip_get_stage_times(rayhip_ctx *ctx, rayhip_stats *out, int reset);
 /* GPU time (ms, HIP events on the context stream) and launch count of the closest-hit traversal kernel
- * and the shadow kernel, accumulated over renders that passed stats != NULL; [0]=K2 [1]=K3 */
+ * and the shadow kernel, accumulated over renders that passed stats != NULL or RAYHIP_FLAG_TIME_STAGES; [0]=K2 [1]=K3 */
 RAYHIP_API int rayhip_get_trav_timing(rayhip_ctx *ctx, double out_ms[2], unsigned long long out_launches[2],
                                       int reset);
 

@@ -373,6 +373,47 @@ def create_renderer_from(lib, s: Settings, renderer_type: str) -> RendererBase:
     return RendererBase(lib, ptr)
 
 
+def _hip_lib():
+    lib = load_capi_library(HIP_HOST_LIB)
+    if not hasattr(lib, "_hip_extras"):
+        vp = C.c_void_p
+        lib.ray_hip_create_scene.restype = vp
+        lib.ray_hip_create_scene.argtypes = [C.c_int]
+        lib.ray_hip_export_scene.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+        lib.ray_hip_free.argtypes = [vp]
+        lib.ray_hip_free.restype = None
+        lib.ray_hip_pmj_table.argtypes = [C.POINTER(vp), C.POINTER(C.c_uint32)]
+        lib.ray_hip_pmj_table.restype = None
+        lib._hip_extras = True
+    return lib
+
+
+def CreateSceneHIP(verbose: bool = False) -> SceneBase:
+    """A SceneHIP without a renderer: scene construction (BVH, light tree) is host work and needs no GPU."""
+    lib = _hip_lib()
+    return SceneBase(lib, lib.ray_hip_create_scene(int(verbose)))
+
+
+def export_scene_blob(scene: SceneBase) -> bytes:
+    """Flat arrays + current camera + filter table of a finalized SceneHIP (ray_amd/csrc/scene_blob.h)."""
+    lib = _hip_lib()
+    p, n = C.c_void_p(), C.c_uint64()
+    if lib.ray_hip_export_scene(scene._ptr, C.byref(p), C.byref(n)) != 0:
+        raise RuntimeError(lib.ray_last_error().decode())
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        lib.ray_hip_free(p)
+
+
+def pmj_table() -> np.ndarray:
+    """The PMJ02 sample table the backend renders with (uploaded by RendererHIP at start-up)."""
+    lib = _hip_lib()
+    p, n = C.c_void_p(), C.c_uint32()
+    lib.ray_hip_pmj_table(C.byref(p), C.byref(n))
+    return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+
+
 def CreateRenderer(s: Settings, renderer_type: str = "HIP") -> RendererBase:
     """Ray::CreateRenderer (Ray.h:25-28) for the HIP backend.  No fallback chain: a missing GPU is an error."""
     if renderer_type != "HIP":

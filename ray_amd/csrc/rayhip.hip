@@ -97,10 +97,19 @@ struct rayhip_ctx {
     DevBuf counters;      // uint32: ray_count[MAX_BOUNCE_SLOTS], shadow_count[MAX_BOUNCE_SLOTS]
     DevBuf trav_counters; // u64 [2][4]
 
-    // timing
+    // timing: events are recorded without synchronising; intervals are resolved lazily (resolve_timing)
+    struct Mark {
+        size_t ev;
+        int stage; // index into rayhip_stats, or -1
+        int trav;  // 0 = closest kernel, 1 = shadow kernel, -1 = none
+        bool first; // first mark of a render call (no interval ends here)
+    };
     std::vector<hipEvent_t> events;
+    size_t events_used = 0;
+    std::vector<Mark> pending;
     double trav_ms[2] = {0.0, 0.0};
     unsigned long long trav_launches[2] = {0, 0};
+    double stage_us[11] = {};
 
     uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + b; }
     uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + MAX_BOUNCE_SLOTS + b; }
@@ -165,57 +174,55 @@ int grid_for(const rayhip_ctx *c, size_t items, int block) {
     return int(g ? g : 1);
 }
 
-// HIP-event stopwatch over the context stream; only active when the caller asked for stats
+// HIP-event stopwatch over the context stream.  Marks are only recorded here (no synchronisation, so the stage
+// schedule keeps streaming); resolve_timing() turns them into per-stage and per-kernel times later.
 struct StageTimer {
     rayhip_ctx *c;
     bool on;
-    size_t used = 0;
-    struct Mark {
-        size_t ev;
-        int stage; // index into rayhip_stats, or -1
-        int trav;  // 0 = closest kernel, 1 = shadow kernel, -1 = none
-    };
-    std::vector<Mark> marks;
+    bool first = true;
     StageTimer(rayhip_ctx *ctx, bool enabled) : c(ctx), on(enabled) {}
+    // the mark labels the interval that STARTS at it
     int mark(int stage, int trav) {
         if (!on) {
             return 0;
         }
-        if (used == c->events.size()) {
+        if (c->events_used == c->events.size()) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
             c->events.push_back(e);
         }
-        HIP_TRY(hipEventRecord(c->events[used], c->stream));
-        marks.push_back({used, stage, trav});
-        ++used;
-        return 0;
-    }
-    // mark k carries the label of the interval [k, k+1)
-    int finish(rayhip_stats *st) {
-        if (!on) {
-            return 0;
-        }
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        unsigned long long *slots = reinterpret_cast<unsigned long long *>(st);
-        double acc_us[11] = {};
-        for (size_t k = 0; k + 1 < marks.size(); ++k) {
-            float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, c->events[marks[k].ev], c->events[marks[k + 1].ev]));
-            if (marks[k].stage >= 0) {
-                acc_us[marks[k].stage] += double(ms) * 1000.0;
-            }
-            if (marks[k].trav >= 0) {
-                c->trav_ms[marks[k].trav] += double(ms);
-                c->trav_launches[marks[k].trav] += 1;
-            }
-        }
-        for (int i = 0; i < 11; ++i) {
-            slots[i] += (unsigned long long)(acc_us[i]);
-        }
+        HIP_TRY(hipEventRecord(c->events[c->events_used], c->stream));
+        c->pending.push_back({c->events_used, stage, trav, first});
+        first = false;
+        ++c->events_used;
         return 0;
     }
 };
+
+int resolve_timing(rayhip_ctx *c) {
+    if (c->pending.empty()) {
+        return 0;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k + 1 < c->pending.size(); ++k) {
+        const rayhip_ctx::Mark &a = c->pending[k], &b = c->pending[k + 1];
+        if (b.first) {
+            continue;
+        }
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->events[a.ev], c->events[b.ev]));
+        if (a.stage >= 0) {
+            c->stage_us[a.stage] += double(ms) * 1000.0;
+        }
+        if (a.trav >= 0) {
+            c->trav_ms[a.trav] += double(ms);
+            c->trav_launches[a.trav] += 1;
+        }
+    }
+    c->pending.clear();
+    c->events_used = 0;
+    return 0;
+}
 
 enum { ST_GEN = 0, ST_PTRACE, ST_PSHADE, ST_PSHADOW, ST_SORT, ST_STRACE, ST_SSHADE, ST_SSHADOW };
 
@@ -475,7 +482,7 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
     const int gtrace = int(std::min<size_t>(size_t(gw), (npix + WAVE - 1) / WAVE));
     unsigned long long *tc = c->trav_counters.as<unsigned long long>();
 
-    StageTimer tm(c, stats != nullptr);
+    StageTimer tm(c, stats != nullptr || (flags & RAYHIP_FLAG_TIME_STAGES) != 0);
 
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS, s));
 
@@ -546,8 +553,15 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         return 1;
     }
     if (stats) {
-        if (tm.finish(stats)) {
+        // synchronous mode: resolve now and hand this call's stage times to the caller
+        double before[11];
+        memcpy(before, c->stage_us, sizeof(before));
+        if (resolve_timing(c)) {
             return 1;
+        }
+        unsigned long long *slots = reinterpret_cast<unsigned long long *>(stats);
+        for (int i = 0; i < 11; ++i) {
+            slots[i] += (unsigned long long)(c->stage_us[i] - before[i]);
         }
     }
     return 0;
@@ -642,7 +656,24 @@ int rayhip_get_trav_counters(rayhip_ctx *c, rayhip_trav_counters out[2], int res
     return 0;
 }
 
+int rayhip_get_stage_times(rayhip_ctx *c, rayhip_stats *out, int reset) {
+    if (use_device(c) || resolve_timing(c)) {
+        return 1;
+    }
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(out);
+    for (int i = 0; i < 11; ++i) {
+        slots[i] = (unsigned long long)(c->stage_us[i]);
+        if (reset) {
+            c->stage_us[i] = 0.0;
+        }
+    }
+    return 0;
+}
+
 int rayhip_get_trav_timing(rayhip_ctx *c, double out_ms[2], unsigned long long out_launches[2], int reset) {
+    if (use_device(c) || resolve_timing(c)) {
+        return 1;
+    }
     for (int k = 0; k < 2; ++k) {
         out_ms[k] = c->trav_ms[k];
         out_launches[k] = c->trav_launches[k];

@@ -16,6 +16,7 @@ RAYHIP_LIB = os.path.join(_HERE, "csrc", "_build", "librayhip.so")
 BUF_FINAL, BUF_RAW, BUF_BASE_COLOR, BUF_DEPTH_NORMALS = 0, 1, 2, 3
 FLAG_SORT_RAYS = 1 << 0
 FLAG_COUNT_TRAVERSAL = 1 << 1
+FLAG_TIME_STAGES = 1 << 2
 
 
 class PassSettings(C.Structure):
@@ -71,7 +72,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 ENTRY_POINTS = (
     "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
     "scene_upload", "scene_upload_blob", "set_filter_table", "render", "readback", "readback_device", "set_raw_device",
-    "sync", "set_shard", "get_trav_counters", "get_trav_timing", "k_generate_primary_rays", "k_intersect_closest",
+    "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand",
 )
 
@@ -115,6 +116,7 @@ class Library:
             f("readback_device").argtypes = [vp, C.c_int, vp, C.c_int]
             f("set_raw_device").argtypes = [vp, vp, C.c_int, C.POINTER(Camera)]
             f("get_trav_timing").argtypes = [vp, C.POINTER(C.c_double * 2), C.POINTER(C.c_ulonglong * 2), C.c_int]
+            f("get_stage_times").argtypes = [vp, C.POINTER(Stats), C.c_int]
 
     def fn(self, name):
         return getattr(self.lib, self.prefix + name)
@@ -209,6 +211,11 @@ class Context:
         n = (C.c_ulonglong * 2)()
         self.L.check(self.L.fn("get_trav_timing")(self._ctx, C.byref(ms), C.byref(n), int(reset)))
         return (float(ms[0]), int(n[0])), (float(ms[1]), int(n[1]))
+
+    def stage_times(self, reset=True) -> dict:
+        st = Stats()
+        self.L.check(self.L.fn("get_stage_times")(self._ctx, C.byref(st), int(reset)))
+        return st.as_dict()
 
     # ---- kernel-level hooks ------------------------------------------------------------------------------
     def k_generate_primary_rays(self, iteration: int, rect=None, cam: Camera = None):

@@ -26,6 +26,7 @@
 #include "internal/SceneCPU.h"
 
 #include "../../include/rayhip.h"
+#include "../csrc/scene_blob.h"
 #include "scene_export.h"
 
 namespace Ray {
@@ -79,8 +80,7 @@ class Renderer final : public RendererBase {
     ePixelFilter filter_table_filter_ = ePixelFilter(-1);
     float filter_table_width_ = 0.0f;
 
-    bool collect_stats_ = false;
-    stats_t stats_ = {};
+    bool collect_stats_ = true;
     std::mutex mtx_;
 
     // host mirrors handed out by get_*_pixels_ref (valid until the next mutating call, like RendererVK.cpp:1698-1757)
@@ -146,7 +146,7 @@ class Renderer final : public RendererBase {
         char name[256] = {};
         rayhip_ctx_device_name(ctx_, name, sizeof(name));
         device_name_ = name;
-        collect_stats_ = getenv("RAY_HIP_STATS") != nullptr;
+        collect_stats_ = getenv("RAY_HIP_NO_STATS") == nullptr;
 
         log->Info("============================================================================");
         log->Info("Device       is %s", device_name_.c_str());
@@ -232,16 +232,10 @@ class Renderer final : public RendererBase {
         memcpy(&rc, &cam, sizeof(rc));
         const rect_t &rect = region.rect();
         const int r[4] = {rect.x, rect.y, rect.w, rect.h};
-        rayhip_stats st = {};
-        check(rayhip_render(ctx_, &rc, r, region.iteration, 0u, collect_stats_ ? &st : nullptr), "rayhip_render");
-        if (collect_stats_) {
-            std::lock_guard<std::mutex> _(mtx_);
-            const auto *src = reinterpret_cast<const unsigned long long *>(&st);
-            auto *dst = reinterpret_cast<unsigned long long *>(&stats_);
-            for (int i = 0; i < 11; ++i) {
-                dst[i] += src[i];
-            }
-        }
+        // stage times come from HIP events recorded on the stream and are resolved lazily in GetStats -- the
+        // counterpart of the timestamp queries RendererVK reads back one frame later (RendererVK.cpp:452-487)
+        check(rayhip_render(ctx_, &rc, r, region.iteration, collect_stats_ ? RAYHIP_FLAG_TIME_STAGES : 0u, nullptr),
+              "rayhip_render");
         for (bool &d : host_dirty_) {
             d = true;
         }
@@ -256,11 +250,14 @@ class Renderer final : public RendererBase {
 
     void GetStats(stats_t &st) override {
         std::lock_guard<std::mutex> _(mtx_);
-        st = stats_;
+        rayhip_stats rs = {};
+        check(rayhip_get_stage_times(ctx_, &rs, 0), "rayhip_get_stage_times");
+        memcpy(&st, &rs, sizeof(st));
     }
     void ResetStats() override {
         std::lock_guard<std::mutex> _(mtx_);
-        stats_ = {};
+        rayhip_stats rs = {};
+        check(rayhip_get_stage_times(ctx_, &rs, 1), "rayhip_get_stage_times");
     }
 
     unet_filter_properties_t InitUNetFilter(bool, const std::function<void(int, int, ParallelForFunction &&)> &) override {
@@ -270,6 +267,43 @@ class Renderer final : public RendererBase {
 };
 
 RendererBase *CreateRenderer(const settings_t &s, ILog *log) { return new Renderer(s, log); }
+
+SceneBase *CreateScene(ILog *log) { return new Scene(log); }
+
+std::vector<uint8_t> ExportSceneBlob(const SceneBase &scene) {
+    const auto *s = dynamic_cast<const Cpu::Scene *>(&scene);
+    if (!s) {
+        throw std::runtime_error("ExportSceneBlob: not a CPU-side scene");
+    }
+    std::shared_lock<std::shared_timed_mutex> scene_lock(SceneAccess::Mutex(*s));
+    FlatScene flat;
+    SceneAccess::Export(*s, flat);
+    const camera_t &cam = SceneAccess::CurrentCamera(*s);
+    rayhip_camera rc;
+    memcpy(&rc, &cam, sizeof(rc));
+    // pixel-filter table, same construction as Cpu::Renderer::UpdateFilterTable (RendererCPU.h:1234-1258)
+    float (*filter_func)(float v, float width) = nullptr;
+    float filter_width = cam.filter_width;
+    switch (cam.filter) {
+    case ePixelFilter::Box:
+        filter_func = filter_box;
+        filter_width = 1.0f;
+        break;
+    case ePixelFilter::Gaussian:
+        filter_func = filter_gaussian;
+        filter_width *= 3.0f;
+        break;
+    case ePixelFilter::BlackmanHarris:
+        filter_func = filter_blackman_harris;
+        filter_width *= 2.0f;
+        break;
+    default:
+        throw std::runtime_error("unknown pixel filter");
+    }
+    const std::vector<float> table = Ray::CDFInverted(FILTER_TABLE_SIZE, 0.0f, filter_width * 0.5f,
+                                                      std::bind(filter_func, std::placeholders::_1, filter_width), true);
+    return rayhip_blob::serialize(flat.desc, rc, table.data(), int(table.size()));
+}
 
 } // namespace Hip
 } // namespace Ray

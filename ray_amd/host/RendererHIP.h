@@ -9,6 +9,9 @@
 // value the enum entry would get.
 #pragma once
 
+#include <cstdint>
+#include <vector>
+
 #include "RendererBase.h"
 
 namespace Ray {
@@ -20,5 +23,10 @@ constexpr eRendererType RendererTypeHIP = eRendererType(uint32_t(eRendererType::
 // Throws std::runtime_error when no gfx950 device / librayhip is unavailable -- the factory convention of the
 // GPU backends (Ray.cpp:58-63) -- so that Ray::CreateRenderer can fall through to the next enabled type.
 RendererBase *CreateRenderer(const settings_t &s, ILog *log);
+
+// SceneHIP without a renderer (scene construction is host-only work) and its flat serialisation
+// (ray_amd/csrc/scene_blob.h): what rayhip_scene_upload_blob consumes.
+SceneBase *CreateScene(ILog *log);
+std::vector<uint8_t> ExportSceneBlob(const SceneBase &scene);
 } // namespace Hip
 } // namespace Ray

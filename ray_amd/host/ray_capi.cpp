@@ -13,6 +13,7 @@
 
 #ifdef RAY_CAPI_WITH_HIP
 #include "RendererHIP.h"
+#include "internal/Core.h"
 #endif
 #ifdef RAY_CAPI_WITH_CPU
 #include "internal/RendererAVX.h"
@@ -456,5 +457,36 @@ void ray_scene_set_current_cam(ray_scene *s, ray_handle cam) { s->s->set_current
 void ray_scene_finalize(ray_scene *s) { s->s->Finalize(); }
 uint32_t ray_scene_triangle_count(ray_scene *s) { return s->s->triangle_count(); }
 uint32_t ray_scene_node_count(ray_scene *s) { return s->s->node_count(); }
+
+#ifdef RAY_CAPI_WITH_HIP
+ray_scene *ray_hip_create_scene(int verbose) {
+    static CollectLog quiet(false), loud(true);
+    auto out = std::make_unique<ray_scene>();
+    out->s.reset(Ray::Hip::CreateScene(verbose ? &loud : &quiet));
+    return out.release();
+}
+int ray_hip_export_scene(ray_scene *s, void **out_blob, uint64_t *out_size) {
+    try {
+        const std::vector<uint8_t> blob = Ray::Hip::ExportSceneBlob(*s->s);
+        void *p = nullptr;
+        if (posix_memalign(&p, 64, blob.size() ? blob.size() : 64) != 0) {
+            g_err = "out of memory";
+            return 1;
+        }
+        memcpy(p, blob.data(), blob.size());
+        *out_blob = p;
+        *out_size = blob.size();
+        return 0;
+    } catch (std::exception &e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+void ray_hip_free(void *p) { free(p); }
+void ray_hip_pmj_table(const uint32_t **out_ptr, uint32_t *out_count) {
+    *out_ptr = Ray::__pmj02_samples;
+    *out_count = uint32_t(Ray::__pmj02_dims_count) * 2u * uint32_t(Ray::__pmj02_sample_count);
+}
+#endif
 
 } // extern "C"

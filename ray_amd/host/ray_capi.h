@@ -195,6 +195,17 @@ void ray_scene_finalize(ray_scene *s);                                          
 uint32_t ray_scene_triangle_count(ray_scene *s);
 uint32_t ray_scene_node_count(ray_scene *s);
 
+/* ---- HIP-backend extras (only in libray_hip.so) ----------------------------------------------------------------
+ * A SceneHIP can be created and finalized without a renderer (and therefore without a GPU): scene construction is
+ * host work.  ray_hip_export_scene serialises the flat arrays + current camera + pixel-filter table with
+ * ray_amd/csrc/scene_blob.h; the blob is what rayhip_scene_upload_blob takes.  This is how one scene build is
+ * replicated to the 8 GPUs of a node (one process per GPU) and how big procedural scenes are cached on disk. */
+ray_scene *ray_hip_create_scene(int verbose);
+int ray_hip_export_scene(ray_scene *s, void **out_blob, uint64_t *out_size);
+void ray_hip_free(void *p);
+/* the PMJ02 table RendererHIP uploads at start-up (reference internal/Core.h:363-368) */
+void ray_hip_pmj_table(const uint32_t **out_ptr, uint32_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif
