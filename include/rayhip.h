@@ -39,7 +39,7 @@ extern "C" {
  * ---------------------------------------------------------------------------------------------- */
 
 /* precomputed 3-plane triangle, reference Core.h:72-77 (tri_accel_t), built by Core.cpp:212-258 */
-typedef struct rayhip_tri_accel {
+typedef struct __attribute__((aligned(16))) rayhip_tri_accel {
     float n_plane[4];
     float u_plane[4];
     float v_plane[4];
@@ -48,7 +48,7 @@ typedef struct rayhip_tri_accel {
 /* 2-wide BVH node holding its children's boxes, reference Core.h:107-115 (bvh2_node_t).
  * child word: top 3 bits = (prim_count-1) for leaves (0 => inner node), low 29 bits = index
  * (Constants.inl:24-25) */
-typedef struct rayhip_bvh2_node {
+typedef struct __attribute__((aligned(16))) rayhip_bvh2_node {
     float ch_data0[4]; /* [ ch0.min.x, ch0.max.x, ch0.min.y, ch0.max.y ] */
     float ch_data1[4]; /* [ ch1.min.x, ch1.max.x, ch1.min.y, ch1.max.y ] */
     float ch_data2[4]; /* [ ch0.min.z, ch0.max.z, ch1.min.z, ch1.max.z ] */
@@ -258,6 +258,7 @@ typedef struct rayhip_trav_counters {
     unsigned long long nodes;     /* bvh2 nodes fetched (64 B each) */
     unsigned long long tris;      /* triangles tested (48 B each) */
     unsigned long long instances; /* mesh instances entered (144 B each) */
+    unsigned long long max_stack; /* deepest traversal-stack use seen (entries per ray; not a sum) */
 } rayhip_trav_counters;
 
 typedef struct rayhip_ctx rayhip_ctx;
@@ -272,6 +273,8 @@ enum {
 enum {
     RAYHIP_FLAG_SORT_RAYS = 1u << 0,     /* ray sort between bounces (RendererVK.cpp:641-652) */
     RAYHIP_FLAG_COUNT_TRAVERSAL = 1u << 1, /* run the instrumented traversal kernels (slower) */
+    RAYHIP_FLAG_NO_REFILL = 1u << 3,       /* closest-hit traversal with the plain one-ray-per-lane kernel instead of the
+                                              persistent ray-refill kernel (same results; for A/B measurements) */
     RAYHIP_FLAG_TIME_STAGES = 1u << 2      /* record HIP events around every stage WITHOUT synchronising; read the
                                               result later with rayhip_get_stage_times / rayhip_get_trav_timing */
 };
@@ -356,7 +359,7 @@ RAYHIP_API int rayhip_k_generate_primary_rays(rayhip_ctx *ctx, const rayhip_came
                                               int *out_count);
 /* Ref::IntersectScene closest hit (CoreRef.cpp:3041-3158): rays/hits are in-out host arrays */
 RAYHIP_API int rayhip_k_intersect_closest(rayhip_ctx *ctx, const rayhip_camera *cam, rayhip_ray *rays,
-                                          rayhip_hit *hits, int count, int iteration,
+                                          rayhip_hit *hits, int count, int iteration, uint32_t flags /* NO_REFILL */,
                                           rayhip_trav_counters *out_counters /* may be NULL */);
 /* Ref::IntersectScene(shadow_ray_t) (CoreRef.cpp:3160-3262): out_rc[count][4] visibility * colour */
 RAYHIP_API int rayhip_k_intersect_shadow(rayhip_ctx *ctx, const rayhip_camera *cam,

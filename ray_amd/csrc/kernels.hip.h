@@ -26,25 +26,52 @@
 
 #include "rt_params.h"
 #include "rt_pixel.h"
+#include "rt_sort.h"
+#include "rt_travmachine.h"
 
 namespace rt {
 
+// Build-time knobs (defaults are what ships; tools/variants.py sweeps them):
+//   RT_LDS_STACK_DEPTH   traversal-stack entries per lane kept in LDS (TLAS + BLAS levels share them).  LDS per
+//                        wave = depth * 256 B, so 48 entries (the reference's MAX_STACK_SIZE, Constants.inl:4) cap a
+//                        CU at 13 traversal waves, 32 at 20, 24 at 26, 16 at 40.  Entries beyond the LDS part
+//                        spill to a per-wave slab in HBM (same depth-major layout), so any depth up to
+//                        RT_STACK_TOTAL_DEPTH stays correct; SAH trees of the Bistro-class scene use <= 17.
+//   RT_TRACE_MIN_WAVES   __launch_bounds__ occupancy hint (waves per SIMD) for the traversal kernels
+//   RT_SHADE_MIN_WAVES   same for the shade kernel
+#ifndef RT_LDS_STACK_DEPTH
+#define RT_LDS_STACK_DEPTH 24
+#endif
+#ifndef RT_TRACE_MIN_WAVES
+#define RT_TRACE_MIN_WAVES 6
+#endif
+#ifndef RT_SHADE_MIN_WAVES
+#define RT_SHADE_MIN_WAVES 1
+#endif
 constexpr int WAVE = 64;
-constexpr int LDS_STACK_DEPTH = MAX_STACK_SIZE; // entries per lane, TLAS + BLAS levels share it
+constexpr int LDS_STACK_DEPTH = RT_LDS_STACK_DEPTH;
+constexpr int STACK_TOTAL_DEPTH = 2 * MAX_STACK_SIZE; // TLAS + BLAS, 48 each in the reference
+constexpr int STACK_SPILL_DEPTH = STACK_TOTAL_DEPTH - LDS_STACK_DEPTH;
 
-// depth-major per-wavefront stack in LDS
+// Depth-major per-wavefront stack: entries [0, LDS_STACK_DEPTH) live in LDS, deeper ones in a per-wave HBM slab.
 struct LdsStack {
-    uint32_t *lane_base; // &lds[wave_slot][0][lane]
+    uint32_t *lane_base;  // &lds[0][lane]
+    uint32_t *spill_base; // &slab[wave][0][lane]
     uint32_t size;
     __device__ __forceinline__ void push(uint32_t v) {
-        if (size < uint32_t(LDS_STACK_DEPTH)) { // never write outside the wave's slice
+        if (size < uint32_t(LDS_STACK_DEPTH)) {
             lane_base[size * WAVE] = v;
+        } else if (size < uint32_t(STACK_TOTAL_DEPTH)) {
+            spill_base[(size - LDS_STACK_DEPTH) * WAVE] = v;
         }
         ++size;
     }
     __device__ __forceinline__ uint32_t pop() {
         --size;
-        return size < uint32_t(LDS_STACK_DEPTH) ? lane_base[size * WAVE] : 0x1fffffffu;
+        if (size < uint32_t(LDS_STACK_DEPTH)) {
+            return lane_base[size * WAVE];
+        }
+        return size < uint32_t(STACK_TOTAL_DEPTH) ? spill_base[(size - LDS_STACK_DEPTH) * WAVE] : 0x1fffffffu;
     }
 };
 
@@ -94,9 +121,10 @@ __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint
 // ---- K2 ---------------------------------------------------------------------------------------------------
 // One ray per lane; grid-stride over the device-resident ray count.
 template <bool COUNT>
-__global__ void __launch_bounds__(WAVE) k_trace_closest(const SceneView sc, const TraceParams tp, const RaySoA rays,
+__global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest(const SceneView sc, const TraceParams tp, const RaySoA rays,
                                                        const HitSoA hits, const uint32_t *__restrict__ ray_count,
-                                                       const int init_hits, unsigned long long *__restrict__ counters) {
+                                                       const int init_hits, uint32_t *__restrict__ stack_spill,
+                                                       unsigned long long *__restrict__ counters) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t n = *ray_count;
     const uint32_t lane = threadIdx.x;
@@ -116,8 +144,9 @@ __global__ void __launch_bounds__(WAVE) k_trace_closest(const SceneView sc, cons
 
         LdsStack st;
         st.lane_base = &lds_stack[lane];
+        st.spill_base = stack_spill + size_t(blockIdx.x) * size_t(STACK_SPILL_DEPTH * WAVE) + lane;
         st.size = 0;
-        TravCount tc = {0, 0, 0};
+        TravCount tc = {0, 0, 0, 0};
         intersect_scene_closest(sc, tp, r, h, st, COUNT ? &tc : nullptr);
 
         store_hit(hits, i, h);
@@ -133,16 +162,105 @@ __global__ void __launch_bounds__(WAVE) k_trace_closest(const SceneView sc, cons
             atomicAdd(&counters[1], (unsigned long long)tc.nodes);
             atomicAdd(&counters[2], (unsigned long long)tc.tris);
             atomicAdd(&counters[3], (unsigned long long)tc.instances);
+            atomicMax(&counters[4], (unsigned long long)tc.max_stack);
         }
+    }
+}
+
+// K2, persistent form with ray refill.  Every wavefront owns the 64-ray chunks w, w + gridDim, w + 2*gridDim, ... (no
+// atomics: the hand-out counter is wave-uniform) and runs the resumable state machine of rt_travmachine.h: a lane
+// whose ray is finished takes the next ray of the wave's chunks at the top of the loop while the other lanes keep
+// walking.  Per ray the visiting order -- and therefore hits and work counters -- are those of k_trace_closest.
+template <bool COUNT>
+__global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest_refill(
+    const SceneView sc, const TraceParams tp, const RaySoA rays, const HitSoA hits, const uint32_t *__restrict__ ray_count,
+    const int init_hits, uint32_t *__restrict__ stack_spill, unsigned long long *__restrict__ counters) {
+    __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
+    const uint32_t n = *ray_count;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t num_waves = gridDim.x, w = blockIdx.x;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    LdsStack st;
+    st.lane_base = &lds_stack[lane];
+    st.spill_base = stack_spill + size_t(blockIdx.x) * size_t(STACK_SPILL_DEPTH * WAVE) + lane;
+    st.size = 0;
+
+    ClosestMachine m;
+    m.state = TM_IDLE;
+    uint32_t my_ray = 0;
+    uint32_t consumed = 0; // wave-uniform: how many rays of this wave's chunks have been handed out
+    TravCount tc = {0, 0, 0, 0};
+    uint32_t rays_done = 0;
+
+    for (;;) {
+        // ---- refill: idle lanes take the next rays of this wave's chunks
+        const bool idle = (m.state == TM_IDLE);
+        const unsigned long long idle_mask = __ballot(idle);
+        if (idle_mask != 0ull) {
+            const uint32_t j = consumed + uint32_t(__popcll(idle_mask & lanes_below));
+            const uint32_t g = (w + (j >> 6) * num_waves) * WAVE + (j & 63u);
+            if (idle && g < n) {
+                Ray r;
+                load_ray_od(rays, g, r);
+                const uint2 xd = rays.xy_depth[g];
+                r.xy = xd.x, r.depth = xd.y;
+                const Hit h = init_hits ? make_hit() : load_hit(hits, g);
+                my_ray = g;
+                tm_start(m, tp, r, h, st);
+            }
+            consumed += uint32_t(__popcll(idle_mask));
+        }
+        if (!__any(m.state != TM_IDLE)) {
+            break;
+        }
+        // ---- node phase: walk inner nodes until this lane has a pending leaf (or its level/ray ends)
+        while (m.state == TM_NODE) {
+            tm_node_step(m, sc, st, COUNT ? &tc : nullptr);
+        }
+        // ---- leaf phase: one leaf per lane (instance entry or up to 8 triangle tests)
+        if (m.state == TM_LEAF) {
+            tm_leaf_step(m, sc, st, COUNT ? &tc : nullptr);
+        }
+        // ---- completion: index indirection, transparency round, write-back
+        if (m.state == TM_FINISH) {
+            Ray r;
+            const float4 o = rays.o_pdf[my_ray], c = rays.c_cs[my_ray];
+            const uint2 xd = rays.xy_depth[my_ray];
+            r.o = {o.x, o.y, o.z};
+            r.d = m.rd;
+            r.c = {c.x, c.y, c.z};
+            r.cone_spread = c.w;
+            r.xy = xd.x, r.depth = xd.y;
+            const bool done = tm_finish(m, sc, tp, r, st);
+            if (r.depth != xd.y || r.c.x != c.x || r.c.y != c.y || r.c.z != c.z) {
+                rays.c_cs[my_ray] = mkfloat4(r.c.x, r.c.y, r.c.z, r.cone_spread);
+                uint2 nxd;
+                nxd.x = r.xy, nxd.y = r.depth;
+                rays.xy_depth[my_ray] = nxd;
+            }
+            if (done) {
+                store_hit(hits, my_ray, m.h);
+                ++rays_done;
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters[0], (unsigned long long)rays_done);
+        atomicAdd(&counters[1], (unsigned long long)tc.nodes);
+        atomicAdd(&counters[2], (unsigned long long)tc.tris);
+        atomicAdd(&counters[3], (unsigned long long)tc.instances);
+        atomicMax(&counters[4], (unsigned long long)tc.max_stack);
     }
 }
 
 // ---- K3 ---------------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(WAVE) k_trace_shadow(const SceneView sc, const TraceParams tp, const ShadowSoA shadow,
+__global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const SceneView sc, const TraceParams tp, const ShadowSoA shadow,
                                                       const uint32_t *__restrict__ ray_count, const float limit,
                                                       const int img_w, float4 *__restrict__ temp_buf,
                                                       float4 *__restrict__ out_rc, /* test hook, may be null */
+                                                      uint32_t *__restrict__ stack_spill,
                                                       unsigned long long *__restrict__ counters) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t n = *ray_count;
@@ -151,8 +269,9 @@ __global__ void __launch_bounds__(WAVE) k_trace_shadow(const SceneView sc, const
         const ShadowRay r = load_shadow(shadow, i);
         LdsStack st;
         st.lane_base = &lds_stack[lane];
+        st.spill_base = stack_spill + size_t(blockIdx.x) * size_t(STACK_SPILL_DEPTH * WAVE) + lane;
         st.size = 0;
-        TravCount tc = {0, 0, 0};
+        TravCount tc = {0, 0, 0, 0};
         const f3 rc = intersect_scene_shadow(sc, tp, r, st, COUNT ? &tc : nullptr);
         if (out_rc) {
             out_rc[i] = mkfloat4(rc.x, rc.y, rc.z, 0.0f);
@@ -164,13 +283,14 @@ __global__ void __launch_bounds__(WAVE) k_trace_shadow(const SceneView sc, const
             atomicAdd(&counters[1], (unsigned long long)tc.nodes);
             atomicAdd(&counters[2], (unsigned long long)tc.tris);
             atomicAdd(&counters[3], (unsigned long long)tc.instances);
+            atomicMax(&counters[4], (unsigned long long)tc.max_stack);
         }
     }
 }
 
 // ---- K5 ---------------------------------------------------------------------------------------------------
 template <bool PRIMARY>
-__global__ void __launch_bounds__(WAVE) k_shade(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
+__global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
                                                const HitSoA hits, const uint32_t *__restrict__ ray_count,
                                                const RaySoA rays_out, uint32_t *__restrict__ out_ray_count,
                                                const ShadowSoA shadow_out, uint32_t *__restrict__ out_shadow_count,
@@ -203,6 +323,35 @@ __global__ void __launch_bounds__(WAVE) k_shade(const SceneView sc, const ShadeP
         if (res.emit_shadow) {
             store_shadow(shadow_out, sh_slot, sh_r);
         }
+    }
+}
+
+// ---- K6 / K8: ray sort ----------------------------------------------------------------------------------------
+// K6: one sort key per live secondary ray (slots >= the live count get the DEAD key so a fixed-size sort works)
+__global__ void __launch_bounds__(256) k_ray_keys(const RaySoA rays, const uint32_t *__restrict__ ray_count, const uint32_t cap,
+                                                 const SortGrid grid, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    const uint32_t n = *ray_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
+        uint32_t key = SORT_KEY_DEAD >> (32 - SORT_KEY_BITS);
+        if (i < n) {
+            const float4 o = rays.o_pdf[i], d = rays.d_cw[i];
+            key = ray_sort_key(grid, f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z});
+        }
+        keys[i] = key;
+        idx[i] = i;
+    }
+}
+// K8: gather the rays into sorted order (reference shaders/sort_reorder_rays.comp.glsl:29-36)
+__global__ void __launch_bounds__(256) k_reorder_rays(const RaySoA src, const RaySoA dst, const uint32_t *__restrict__ idx,
+                                                     const uint32_t *__restrict__ ray_count) {
+    const uint32_t n = *ray_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t j = idx[i];
+        dst.o_pdf[i] = src.o_pdf[j];
+        dst.d_cw[i] = src.d_cw[j];
+        dst.c_cs[i] = src.c_cs[j];
+        dst.ior[i] = src.ior[j];
+        dst.xy_depth[i] = src.xy_depth[j];
     }
 }
 

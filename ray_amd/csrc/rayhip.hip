@@ -17,6 +17,7 @@
 #include "../../include/rayhip.h"
 #include "kernels.hip.h"
 #include "scene_blob.h"
+#include "sort.h"
 
 using namespace rt;
 
@@ -95,7 +96,10 @@ struct rayhip_ctx {
     HitSoA hits = {};
     ShadowSoA shadow = {};
     DevBuf counters;      // uint32: ray_count[MAX_BOUNCE_SLOTS], shadow_count[MAX_BOUNCE_SLOTS]
-    DevBuf trav_counters; // u64 [2][4]
+    DevBuf trav_counters; // u64 [2][5]
+    DevBuf stack_spill;   // per-wave overflow slabs of the traversal stack
+    DevBuf sort_keys[2], sort_idx[2], sort_temp;
+    SortGrid sort_grid = {};
 
     // timing: events are recorded without synchronising; intervals are resolved lazily (resolve_timing)
     struct Mark {
@@ -164,6 +168,14 @@ int alloc_frame(rayhip_ctx *c, int w, int h) {
     }
     c->shadow.o_depth = c->shadow_planes[0].as<float4>(), c->shadow.d_dist = c->shadow_planes[1].as<float4>();
     c->shadow.c_xy = c->shadow_planes[2].as<float4>();
+    size_t temp_bytes = 0;
+    if (sort_pairs_temp_bytes(n, SORT_KEY_BITS, &temp_bytes) != hipSuccess) {
+        return fail("rocPRIM temp-size query failed");
+    }
+    if (c->sort_keys[0].alloc(n * 4) || c->sort_keys[1].alloc(n * 4) || c->sort_idx[0].alloc(n * 4) ||
+        c->sort_idx[1].alloc(n * 4) || c->sort_temp.alloc(temp_bytes)) {
+        return 1;
+    }
     return 0;
 }
 
@@ -269,13 +281,21 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         delete c;
         return fail("failed to initialise HIP device %d", device);
     }
-    // 12 KiB of LDS per traversal wave -> 13 waves per CU; use that many blocks per CU as the persistent grid
-    c->grid_waves = c->props.multiProcessorCount * 13;
-    if (c->counters.alloc(sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS) || c->trav_counters.alloc(sizeof(unsigned long long) * 8)) {
+    // persistent grid of the wave-per-block kernels: as many blocks as are resident (LDS stack + VGPR budget)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false>, WAVE, 0) != hipSuccess || per_cu <= 0) {
+        per_cu = 8;
+    }
+    c->grid_waves = c->props.multiProcessorCount * per_cu;
+    if (c->stack_spill.alloc(size_t(c->grid_waves) * STACK_SPILL_DEPTH * WAVE * sizeof(uint32_t))) {
         delete c;
         return 1;
     }
-    (void)hipMemsetAsync(c->trav_counters.p, 0, 64, c->stream);
+    if (c->counters.alloc(sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS) || c->trav_counters.alloc(sizeof(unsigned long long) * 10)) {
+        delete c;
+        return 1;
+    }
+    (void)hipMemsetAsync(c->trav_counters.p, 0, 80, c->stream);
     *out_ctx = c;
     return 0;
 }
@@ -293,7 +313,8 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
                      &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
                      &c->px_dn, &c->px_req, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
-                     &c->shadow_planes[2], &c->counters, &c->trav_counters};
+                     &c->shadow_planes[2], &c->counters, &c->trav_counters, &c->stack_spill,
+                     &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->sort_temp};
     for (DevBuf *b : all) {
         b->release();
     }
@@ -413,6 +434,20 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
     v.tlas_root = d->tlas_root;
     v.env = d->env;
     memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
+    { // ray-sort grid: true bounds of the TLAS root (Scene::GetBounds takes fminf for the max corner, SceneCPU.cpp:1553)
+        float mn[3] = {d->bbox_min[0], d->bbox_min[1], d->bbox_min[2]}, mx[3] = {d->bbox_max[0], d->bbox_max[1], d->bbox_max[2]};
+        if (d->tlas_root != 0xffffffffu && d->tlas_root < d->nodes_count) {
+            const rayhip_bvh2_node &r = d->nodes[d->tlas_root];
+            mn[0] = fminf(r.ch_data0[0], r.ch_data1[0]), mx[0] = fmaxf(r.ch_data0[1], r.ch_data1[1]);
+            mn[1] = fminf(r.ch_data0[2], r.ch_data1[2]), mx[1] = fmaxf(r.ch_data0[3], r.ch_data1[3]);
+            mn[2] = fminf(r.ch_data2[0], r.ch_data2[2]), mx[2] = fmaxf(r.ch_data2[1], r.ch_data2[3]);
+        }
+        for (int i = 0; i < 3; ++i) {
+            const float ext = mx[i] - mn[i];
+            c->sort_grid.root_min[i] = mn[i];
+            c->sort_grid.inv_cell[i] = (ext > 0.0f && ext < 1e30f) ? 256.0f / ext : 0.0f;
+        }
+    }
     c->have_scene = true;
     return 0;
 }
@@ -476,11 +511,32 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         return fail("max_total_depth too large");
     }
     const bool count = (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) != 0;
+    const bool sort_rays = (flags & RAYHIP_FLAG_SORT_RAYS) != 0;
     hipStream_t s = c->stream;
     const size_t npix = size_t(rect[2]) * size_t(rect[3]);
     const int gw = c->grid_waves;
     const int gtrace = int(std::min<size_t>(size_t(gw), (npix + WAVE - 1) / WAVE));
     unsigned long long *tc = c->trav_counters.as<unsigned long long>();
+    uint32_t *spill = c->stack_spill.as<uint32_t>();
+    const TraceParams tp_ = make_trace_params(*cam, c->sc.tlas_root, iteration);
+
+    const bool refill = (flags & RAYHIP_FLAG_NO_REFILL) == 0;
+    // K2 launcher: persistent ray-refill kernel by default, plain kernel on request; instrumented variants on request
+    auto launch_closest = [&](const RaySoA &r, const uint32_t *cnt_ptr, int init_hits) {
+        if (refill) {
+            if (count) {
+                k_trace_closest_refill<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, cnt_ptr, init_hits, spill, tc);
+            } else {
+                k_trace_closest_refill<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, cnt_ptr, init_hits, spill, tc);
+            }
+        } else {
+            if (count) {
+                k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, cnt_ptr, init_hits, spill, tc);
+            } else {
+                k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, cnt_ptr, init_hits, spill, tc);
+            }
+        }
+    };
 
     StageTimer tm(c, stats != nullptr || (flags & RAYHIP_FLAG_TIME_STAGES) != 0);
 
@@ -499,23 +555,29 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         return 1;
     }
     if (c->sc.tlas_root != 0xffffffffu) {
-        if (count) {
-            k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0, tc);
-        } else {
-            k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0, tc);
-        }
+        launch_closest(c->rays[0], c->ray_count(0), 0);
     }
     int cur = 0;
     for (int bounce = 0; bounce <= max_depth; ++bounce) {
         if (bounce > 0) {
+            if (sort_rays) {
+                // K6-K8 (RendererVK.cpp:641-652): key -> radix sort of (key, index) -> gather into the idle ray buffer
+                if (tm.mark(ST_SORT, -1)) {
+                    return 1;
+                }
+                k_ray_keys<<<grid_for(c, npix, 256), 256, 0, s>>>(c->rays[cur], c->ray_count(bounce), uint32_t(npix), c->sort_grid,
+                                                                  c->sort_keys[0].as<uint32_t>(), c->sort_idx[0].as<uint32_t>());
+                HIP_TRY(sort_pairs(c->sort_temp.p, c->sort_temp.bytes, c->sort_keys[0].as<uint32_t>(),
+                                   c->sort_keys[1].as<uint32_t>(), c->sort_idx[0].as<uint32_t>(), c->sort_idx[1].as<uint32_t>(),
+                                   npix, SORT_KEY_BITS, s));
+                k_reorder_rays<<<grid_for(c, npix, 256), 256, 0, s>>>(c->rays[cur], c->rays[cur ^ 1], c->sort_idx[1].as<uint32_t>(),
+                                                                      c->ray_count(bounce));
+                cur ^= 1;
+            }
             if (tm.mark(ST_STRACE, 0)) {
                 return 1;
             }
-            if (count) {
-                k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->rays[cur], c->hits, c->ray_count(bounce), 1, tc);
-            } else {
-                k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->rays[cur], c->hits, c->ray_count(bounce), 1, tc);
-            }
+            launch_closest(c->rays[cur], c->ray_count(bounce), 1);
         }
         if (tm.mark(bounce == 0 ? ST_PSHADE : ST_SSHADE, -1)) {
             return 1;
@@ -536,10 +598,10 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         const float limit = shadow_clamp_limit(*cam, bounce);
         if (count) {
             k_trace_shadow<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_count(bounce), limit, c->w, c->px.temp,
-                                                         nullptr, tc + 4);
+                                                         nullptr, spill, tc + 5);
         } else {
             k_trace_shadow<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_count(bounce), limit, c->w,
-                                                          c->px.temp, nullptr, tc + 4);
+                                                          c->px.temp, nullptr, spill, tc + 5);
         }
         cur ^= 1;
     }
@@ -644,11 +706,12 @@ int rayhip_get_trav_counters(rayhip_ctx *c, rayhip_trav_counters out[2], int res
     if (use_device(c)) {
         return 1;
     }
-    unsigned long long h[8];
+    unsigned long long h[10];
     HIP_TRY(hipMemcpyAsync(h, c->trav_counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 2; ++k) {
-        out[k].rays = h[4 * k + 0], out[k].nodes = h[4 * k + 1], out[k].tris = h[4 * k + 2], out[k].instances = h[4 * k + 3];
+        out[k].rays = h[5 * k + 0], out[k].nodes = h[5 * k + 1], out[k].tris = h[5 * k + 2], out[k].instances = h[5 * k + 3];
+        out[k].max_stack = h[5 * k + 4];
     }
     if (reset) {
         HIP_TRY(hipMemsetAsync(c->trav_counters.p, 0, sizeof(h), c->stream));
@@ -730,7 +793,7 @@ int rayhip_k_generate_primary_rays(rayhip_ctx *c, const rayhip_camera *cam, cons
 }
 
 int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_ray *rays, rayhip_hit *hits, int count,
-                               int iteration, rayhip_trav_counters *out_counters) {
+                               int iteration, uint32_t flags, rayhip_trav_counters *out_counters) {
     if (use_device(c)) {
         return 1;
     }
@@ -762,18 +825,26 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     const uint32_t n = uint32_t(count);
     HIP_TRY(hipMemcpy(c->ray_count(0), &n, 4, hipMemcpyHostToDevice));
     unsigned long long *tc = c->trav_counters.as<unsigned long long>();
-    unsigned long long before[4], after[4];
+    unsigned long long before[5], after[5];
     HIP_TRY(hipMemcpy(before, tc, sizeof(before), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(tc, 0, sizeof(before)));
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
-    k_trace_closest<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0, tc);
+    if (flags & RAYHIP_FLAG_NO_REFILL) {
+        k_trace_closest<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0,
+                                                         c->stack_spill.as<uint32_t>(), tc);
+    } else {
+        k_trace_closest_refill<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0,
+                                                                c->stack_spill.as<uint32_t>(), tc);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpy(after, tc, sizeof(after), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tc, before, sizeof(before), hipMemcpyHostToDevice));
     if (out_counters) {
-        out_counters->rays = after[0] - before[0], out_counters->nodes = after[1] - before[1];
-        out_counters->tris = after[2] - before[2], out_counters->instances = after[3] - before[3];
+        out_counters->rays = after[0], out_counters->nodes = after[1];
+        out_counters->tris = after[2], out_counters->instances = after[3];
+        out_counters->max_stack = after[4];
     }
     HIP_TRY(hipMemcpy(pl[2].data(), c->ray_planes[0][2].p, size_t(count) * 16, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(xd.data(), c->ray_planes[0][4].p, size_t(count) * 8, hipMemcpyDeviceToHost));
@@ -816,21 +887,23 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     }
     const uint32_t n = uint32_t(count);
     HIP_TRY(hipMemcpy(c->shadow_count(0), &n, 4, hipMemcpyHostToDevice));
-    unsigned long long *tc = c->trav_counters.as<unsigned long long>() + 4;
-    unsigned long long before[4], after[4];
+    unsigned long long *tc = c->trav_counters.as<unsigned long long>() + 5;
+    unsigned long long before[5], after[5];
     HIP_TRY(hipMemcpy(before, tc, sizeof(before), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(tc, 0, sizeof(before)));
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     // results land in the (otherwise idle) hit plane
     k_trace_shadow<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_count(0), FLT_MAX, c->w, c->px.temp,
-                                                    c->hit_planes[0].as<float4>(), tc);
+                                                    c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpy(after, tc, sizeof(after), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tc, before, sizeof(before), hipMemcpyHostToDevice));
     if (out_counters) {
-        out_counters->rays = after[0] - before[0], out_counters->nodes = after[1] - before[1];
-        out_counters->tris = after[2] - before[2], out_counters->instances = after[3] - before[3];
+        out_counters->rays = after[0], out_counters->nodes = after[1];
+        out_counters->tris = after[2], out_counters->instances = after[3];
+        out_counters->max_stack = after[4];
     }
     HIP_TRY(hipMemcpy(out_rc, c->hit_planes[0].p, size_t(count) * 16, hipMemcpyDeviceToHost));
     return 0;

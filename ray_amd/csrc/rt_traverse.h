@@ -111,6 +111,7 @@ RT_HD bool walk_bvh2(const rayhip_bvh2_node *nodes, const uint32_t root_index, c
             const rayhip_bvh2_node &n = nodes[cur];
             if (cnt) {
                 ++cnt->nodes;
+                cnt->max_stack = st.size > cnt->max_stack ? st.size : cnt->max_stack;
             }
             uint32_t children[2] = {n.left_child, n.right_child};
 
@@ -303,6 +304,83 @@ struct TraceParams {
     uint32_t root_index;
 };
 
+// Tail of one round of Ref::IntersectScene's closest-hit loop (CoreRef.cpp:3071-3152): decides what a found hit
+// means.  Returns true when the ray crossed a transparent surface and must be traced again from the advanced
+// origin `ro` (inter, r.c, r.depth and rand_dim are updated for the next round); false when the hit is final
+// (solid surface, opaque material after mix resolve, or the path was terminated -> r.c = 0).
+RT_HD bool closest_resolve_transparency(const SceneView &sc, const TraceParams &tp, Ray &r, Hit &inter, const float t_val,
+                                        const f3 rd, f3 &ro, uint32_t &rand_dim, const uint32_t rand_hash) {
+    const bool is_backfacing = (inter.prim_index < 0);
+    const uint32_t tri_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
+
+    const rayhip_tri_mat_data md = sc.tri_materials[tri_index];
+    if ((!is_backfacing && (md.front_mi & MATERIAL_SOLID_BIT)) || (is_backfacing && (md.back_mi & MATERIAL_SOLID_BIT))) {
+        return false; // solid hit found
+    }
+
+    const rayhip_material *mat =
+        is_backfacing ? &sc.materials[md.back_mi & MATERIAL_INDEX_BITS] : &sc.materials[md.front_mi & MATERIAL_INDEX_BITS];
+
+    const rayhip_vertex &v1 = sc.vertices[sc.vtx_indices[tri_index * 3 + 0]];
+    const rayhip_vertex &v2 = sc.vertices[sc.vtx_indices[tri_index * 3 + 1]];
+    const rayhip_vertex &v3 = sc.vertices[sc.vtx_indices[tri_index * 3 + 2]];
+
+    const float w = 1.0f - inter.u - inter.v;
+    const f2 uvs = mk2(v1.t[0], v1.t[1]) * w + mk2(v2.t[0], v2.t[1]) * inter.u + mk2(v3.t[0], v3.t[1]) * inter.v;
+
+    const f2 mix_term_rand = get_scrambled_2d_rand(rand_dim + RAND_DIM_BSDF_PICK, rand_hash, tp.iteration - 1, sc.pmj);
+    const f2 tex_rand = get_scrambled_2d_rand(rand_dim + RAND_DIM_TEX, rand_hash, tp.iteration - 1, sc.pmj);
+
+    float trans_r = mix_term_rand.x;
+
+    // resolve mix material
+    while (mat->type == NODE_MIX) {
+        float mix_val = mat->tangent_rotation_or_strength;
+        const uint32_t base_texture = mat->textures[BASE_TEXTURE];
+        if (base_texture != 0xffffffff) {
+            const f4 tex_color = sample_color(sc, base_texture, uvs, 0, tex_rand);
+            mix_val *= tex_color.x;
+        }
+        if (trans_r > mix_val) {
+            mat = &sc.materials[mat->textures[MIX_MAT1]];
+            trans_r = safe_div_pos(trans_r - mix_val, 1.0f - mix_val);
+        } else {
+            mat = &sc.materials[mat->textures[MIX_MAT2]];
+            trans_r = safe_div_pos(trans_r, mix_val);
+        }
+    }
+
+    if (mat->type != NODE_TRANSPARENT) {
+        return false;
+    }
+
+    const bool can_terminate_path = get_transp_depth(r.depth) > tp.min_transp_depth;
+
+    const float lum_ = fmaxf(r.c.x, fmaxf(r.c.y, r.c.z));
+    const float p = mix_term_rand.y;
+    const float q = can_terminate_path ? fmaxf(0.05f, 1.0f - lum_) : 0.0f;
+    if (p < q || lum_ == 0.0f || get_transp_depth(r.depth) + 1 >= tp.max_transp_depth) {
+        // terminate ray
+        r.c = {0.0f, 0.0f, 0.0f};
+        return false;
+    }
+
+    r.c.x *= mat->base_color[0] / (1.0f - q);
+    r.c.y *= mat->base_color[1] / (1.0f - q);
+    r.c.z *= mat->base_color[2] / (1.0f - q);
+
+    const float t = inter.t + HIT_BIAS;
+    ro += rd * t;
+
+    // discard current intersection
+    inter.v = -1.0f;
+    inter.t = t_val - inter.t;
+
+    r.depth += pack_ray_depth(0, 0, 0, 1);
+    rand_dim += RAND_DIM_BOUNCE_COUNT;
+    return true;
+}
+
 // Ref::IntersectScene, closest hit + transparency/mix resolve loop.  CoreRef.cpp:3041-3158.
 // In: r (o,d,c,depth,xy), inter (t preset by the caller: clip range for primary rays, MAX_DIST otherwise).
 // Out: inter; r.c and r.depth are updated when transparent surfaces are crossed.
@@ -325,75 +403,9 @@ RT_HD void intersect_scene_closest(const SceneView &sc, const TraceParams &tp, R
         if (!hit_found) {
             break;
         }
-
-        const bool is_backfacing = (inter.prim_index < 0);
-        const uint32_t tri_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
-
-        const rayhip_tri_mat_data md = sc.tri_materials[tri_index];
-        if ((!is_backfacing && (md.front_mi & MATERIAL_SOLID_BIT)) || (is_backfacing && (md.back_mi & MATERIAL_SOLID_BIT))) {
-            break; // solid hit found
-        }
-
-        const rayhip_material *mat =
-            is_backfacing ? &sc.materials[md.back_mi & MATERIAL_INDEX_BITS] : &sc.materials[md.front_mi & MATERIAL_INDEX_BITS];
-
-        const rayhip_vertex &v1 = sc.vertices[sc.vtx_indices[tri_index * 3 + 0]];
-        const rayhip_vertex &v2 = sc.vertices[sc.vtx_indices[tri_index * 3 + 1]];
-        const rayhip_vertex &v3 = sc.vertices[sc.vtx_indices[tri_index * 3 + 2]];
-
-        const float w = 1.0f - inter.u - inter.v;
-        const f2 uvs = mk2(v1.t[0], v1.t[1]) * w + mk2(v2.t[0], v2.t[1]) * inter.u + mk2(v3.t[0], v3.t[1]) * inter.v;
-
-        const f2 mix_term_rand = get_scrambled_2d_rand(rand_dim + RAND_DIM_BSDF_PICK, rand_hash, tp.iteration - 1, sc.pmj);
-        const f2 tex_rand = get_scrambled_2d_rand(rand_dim + RAND_DIM_TEX, rand_hash, tp.iteration - 1, sc.pmj);
-
-        float trans_r = mix_term_rand.x;
-
-        // resolve mix material
-        while (mat->type == NODE_MIX) {
-            float mix_val = mat->tangent_rotation_or_strength;
-            const uint32_t base_texture = mat->textures[BASE_TEXTURE];
-            if (base_texture != 0xffffffff) {
-                const f4 tex_color = sample_color(sc, base_texture, uvs, 0, tex_rand);
-                mix_val *= tex_color.x;
-            }
-            if (trans_r > mix_val) {
-                mat = &sc.materials[mat->textures[MIX_MAT1]];
-                trans_r = safe_div_pos(trans_r - mix_val, 1.0f - mix_val);
-            } else {
-                mat = &sc.materials[mat->textures[MIX_MAT2]];
-                trans_r = safe_div_pos(trans_r, mix_val);
-            }
-        }
-
-        if (mat->type != NODE_TRANSPARENT) {
+        if (!closest_resolve_transparency(sc, tp, r, inter, t_val, rd, ro, rand_dim, rand_hash)) {
             break;
         }
-
-        const bool can_terminate_path = get_transp_depth(r.depth) > tp.min_transp_depth;
-
-        const float lum_ = fmaxf(r.c.x, fmaxf(r.c.y, r.c.z));
-        const float p = mix_term_rand.y;
-        const float q = can_terminate_path ? fmaxf(0.05f, 1.0f - lum_) : 0.0f;
-        if (p < q || lum_ == 0.0f || get_transp_depth(r.depth) + 1 >= tp.max_transp_depth) {
-            // terminate ray
-            r.c = {0.0f, 0.0f, 0.0f};
-            break;
-        }
-
-        r.c.x *= mat->base_color[0] / (1.0f - q);
-        r.c.y *= mat->base_color[1] / (1.0f - q);
-        r.c.z *= mat->base_color[2] / (1.0f - q);
-
-        const float t = inter.t + HIT_BIAS;
-        ro += rd * t;
-
-        // discard current intersection
-        inter.v = -1.0f;
-        inter.t = t_val - inter.t;
-
-        r.depth += pack_ray_depth(0, 0, 0, 1);
-        rand_dim += RAND_DIM_BOUNCE_COUNT;
     }
 
     inter.t += length(r.o - ro);

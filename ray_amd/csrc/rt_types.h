@@ -171,6 +171,7 @@ RT_HD void store_hit(const HitSoA &s, uint32_t i, const Hit &h) {
 // Per-launch traversal work counters (instrumented builds only)
 struct TravCount {
     uint32_t nodes, tris, instances;
+    uint32_t max_stack; // deepest stack use (entries), to size the LDS stack
 };
 
 } // namespace rt

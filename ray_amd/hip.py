@@ -17,6 +17,7 @@ BUF_FINAL, BUF_RAW, BUF_BASE_COLOR, BUF_DEPTH_NORMALS = 0, 1, 2, 3
 FLAG_SORT_RAYS = 1 << 0
 FLAG_COUNT_TRAVERSAL = 1 << 1
 FLAG_TIME_STAGES = 1 << 2
+FLAG_NO_REFILL = 1 << 3
 
 
 class PassSettings(C.Structure):
@@ -55,10 +56,12 @@ class Stats(C.Structure):
 
 
 class TravCounters(C.Structure):
-    _fields_ = [("rays", C.c_ulonglong), ("nodes", C.c_ulonglong), ("tris", C.c_ulonglong), ("instances", C.c_ulonglong)]
+    _fields_ = [("rays", C.c_ulonglong), ("nodes", C.c_ulonglong), ("tris", C.c_ulonglong), ("instances", C.c_ulonglong),
+                ("max_stack", C.c_ulonglong)]
 
     def as_dict(self):
-        return {"rays": int(self.rays), "nodes": int(self.nodes), "tris": int(self.tris), "instances": int(self.instances)}
+        return {"rays": int(self.rays), "nodes": int(self.nodes), "tris": int(self.tris), "instances": int(self.instances),
+                "max_stack": int(self.max_stack)}
 
 
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("pdf", "<f4"), ("c", "<f4", 3), ("ior", "<f4", 4),
@@ -109,7 +112,7 @@ class Library:
         f("set_shard").argtypes = [vp, C.c_int, C.c_int, C.c_int]
         f("get_trav_counters").argtypes = [vp, C.POINTER(TravCounters * 2), C.c_int]
         f("k_generate_primary_rays").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, vp, vp, C.POINTER(C.c_int)]
-        f("k_intersect_closest").argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int, C.c_int, C.POINTER(TravCounters)]
+        f("k_intersect_closest").argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int, C.c_int, C.c_uint32, C.POINTER(TravCounters)]
         f("k_intersect_shadow").argtypes = [vp, C.POINTER(Camera), vp, C.c_int, C.c_int, vp, C.POINTER(TravCounters)]
         f("k_scrambled_rand").argtypes = [vp, vp, vp, vp, C.c_int, vp]
         if prefix == "rayhip_":
@@ -229,12 +232,12 @@ class Context:
                                                           rays.ctypes.data, hits.ctypes.data, C.byref(cnt)))
         return rays[:cnt.value], hits[:cnt.value]
 
-    def k_intersect_closest(self, rays: np.ndarray, hits: np.ndarray, iteration: int, cam: Camera = None):
+    def k_intersect_closest(self, rays: np.ndarray, hits: np.ndarray, iteration: int, cam: Camera = None, flags: int = 0):
         rays = np.ascontiguousarray(rays.copy())
         hits = np.ascontiguousarray(hits.copy())
         tc = TravCounters()
         self.L.check(self.L.fn("k_intersect_closest")(self._ctx, C.byref(cam or self.cam), rays.ctypes.data,
-                                                      hits.ctypes.data, len(rays), iteration, C.byref(tc)))
+                                                      hits.ctypes.data, len(rays), iteration, flags, C.byref(tc)))
         return rays, hits, tc.as_dict()
 
     def k_intersect_shadow(self, rays: np.ndarray, iteration: int, cam: Camera = None):

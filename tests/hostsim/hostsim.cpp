@@ -11,6 +11,7 @@
 // This file is never linked into librayhip.so and nothing under ray_amd/ refers to it: the product has no
 // CPU path (rayhip_* fail loudly without a GPU).
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -19,6 +20,7 @@
 
 #include "../../ray_amd/csrc/rt_params.h"
 #include "../../ray_amd/csrc/rt_pixel.h"
+#include "../../ray_amd/csrc/rt_travmachine.h"
 #include "../../ray_amd/csrc/scene_blob.h"
 
 using namespace rt;
@@ -147,8 +149,24 @@ HS_API int hostsim_scene_upload_blob(hostsim_ctx *c, const void *blob, size_t si
     return 0;
 }
 
+// HOSTSIM_MACHINE=1 routes closest-hit tracing through the resumable state machine (rt_travmachine.h) instead of the
+// straight-line loops, so the two can be compared ray by ray on the CPU
+static bool use_machine() {
+    const char *e = getenv("HOSTSIM_MACHINE");
+    return e && e[0] == '1';
+}
+template <class Stack>
+static void trace_closest(const SceneView &sc, const TraceParams &tp, Ray &r, Hit &h, Stack &st, TravCount *cnt) {
+    if (use_machine()) {
+        intersect_scene_closest_machine(sc, tp, r, h, st, cnt);
+    } else {
+        intersect_scene_closest(sc, tp, r, h, st, cnt);
+    }
+}
+
 static void add_counters(rayhip_trav_counters &dst, const TravCount &tc) {
     dst.rays += 1, dst.nodes += tc.nodes, dst.tris += tc.tris, dst.instances += tc.instances;
+    dst.max_stack = tc.max_stack > dst.max_stack ? tc.max_stack : dst.max_stack;
 }
 
 HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration, uint32_t flags,
@@ -179,7 +197,7 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
     if (c->sc.tlas_root != 0xffffffff) {
         for (size_t i = 0; i < rays.size(); ++i) {
             TravCount tc = {};
-            intersect_scene_closest(c->sc, tp, rays[i], hits[i], st, count ? &tc : nullptr);
+            trace_closest(c->sc, tp, rays[i], hits[i], st, count ? &tc : nullptr);
             if (count) {
                 add_counters(c->counters[0], tc);
             }
@@ -194,7 +212,7 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
             hits.assign(rays.size(), make_hit());
             for (size_t i = 0; i < rays.size(); ++i) {
                 TravCount tc = {};
-                intersect_scene_closest(c->sc, tp, rays[i], hits[i], st, count ? &tc : nullptr);
+                trace_closest(c->sc, tp, rays[i], hits[i], st, count ? &tc : nullptr);
                 if (count) {
                     add_counters(c->counters[0], tc);
                 }
@@ -325,7 +343,8 @@ HS_API int hostsim_k_generate_primary_rays(hostsim_ctx *c, const rayhip_camera *
 }
 
 HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam, rayhip_ray *rays, rayhip_hit *hits,
-                                       int count, int iteration, rayhip_trav_counters *out_counters) {
+                                       int count, int iteration, uint32_t flags, rayhip_trav_counters *out_counters) {
+    const bool machine = use_machine() || (flags & RAYHIP_FLAG_NO_REFILL) == 0;
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     ArrayStack st;
     rayhip_trav_counters acc = {};
@@ -333,7 +352,11 @@ HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam,
         Ray r = from_abi(rays[i]);
         Hit h = {hits[i].obj_index, hits[i].prim_index, hits[i].t, hits[i].u, hits[i].v};
         TravCount tc = {};
-        intersect_scene_closest(c->sc, tp, r, h, st, &tc);
+        if (machine) {
+            intersect_scene_closest_machine(c->sc, tp, r, h, st, &tc); // what the refill kernel runs per ray
+        } else {
+            intersect_scene_closest(c->sc, tp, r, h, st, &tc);
+        }
         add_counters(acc, tc);
         rays[i] = to_abi(r);
         hits[i] = rayhip_hit{h.obj_index, h.prim_index, h.t, h.u, h.v};

@@ -66,12 +66,13 @@ def test_primary_rays(gpu_lib, name):
     np.testing.assert_allclose(hits["t"], ref_h["t"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("kernel_flags", [0, hip.FLAG_NO_REFILL], ids=["refill", "plain"])
 @pytest.mark.parametrize("name", SCENES)
-def test_closest_hit_on_reference_rays(gpu_lib, name):
-    """K2 on the reference's own rays: exact (obj_index, prim_index); |dt|,|du|,|dv| <= 1e-5 relative"""
+def test_closest_hit_on_reference_rays(gpu_lib, name, kernel_flags):
+    """K2 (both kernel forms) on the reference's own rays: exact (obj_index, prim_index); |dt|,|du|,|dv| <= 1e-5 rel"""
     g = util.golden_ref(name)
     ctx = util.make_context(gpu_lib, name)
-    rays, hits, tc = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1)
+    rays, hits, tc = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=kernel_flags)
     ref = g["primary_hits"]
     assert np.array_equal(hits["obj_index"], ref["obj_index"])
     assert np.array_equal(hits["prim_index"], ref["prim_index"])
@@ -97,9 +98,11 @@ def test_traversal_work_counters_match_host(gpu_lib, hostsim_lib, name):
     g = util.golden_ref(name)
     gpu = util.make_context(gpu_lib, name)
     host = util.make_context(hostsim_lib, name)
-    _, _, tc_g = gpu.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1)
-    _, _, tc_h = host.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1)
-    assert tc_g == tc_h
+    for fl in (0, hip.FLAG_NO_REFILL):  # persistent ray-refill kernel and plain kernel: same per-ray visiting order
+        _, hg, tc_g = gpu.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=fl)
+        _, hh, tc_h = host.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=fl)
+        assert tc_g == tc_h
+        assert np.array_equal(hg["prim_index"], hh["prim_index"])
     _, sc_g = gpu.k_intersect_shadow(g["shadow_rays"], 1)
     _, sc_h = host.k_intersect_shadow(g["shadow_rays"], 1)
     assert sc_g == sc_h
@@ -149,6 +152,14 @@ def test_instrumented_render_matches_plain(gpu_lib):
     assert np.array_equal(ia, ib)
     c0, c1 = b.trav_counters()
     assert c0["rays"] > 64 * 64 and c1["rays"] > 0 and c0["nodes"] > c0["rays"]
+
+
+def test_refill_kernel_matches_plain_kernel(gpu_lib):
+    """the persistent ray-refill traversal must give the same image as one-ray-per-lane traversal, bit for bit"""
+    name = "cornell_principled"
+    a = util.render_frames(util.make_context(gpu_lib, name, 192, 128), 3)
+    b = util.render_frames(util.make_context(gpu_lib, name, 192, 128), 3, flags=hip.FLAG_NO_REFILL)
+    assert np.array_equal(a, b)
 
 
 def test_render_is_deterministic(gpu_lib):

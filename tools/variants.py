@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Build-time knob sweep for the kernels (tuning tool, not part of the product).
+
+    python tools/variants.py build               # here (no GPU): hipcc every variant into _build/variants/<name>/
+    python tools/variants.py run [workload] [K]  # on the GPU box: time each variant, check images agree
+
+Variants are -D flag sets for ray_amd/csrc/rayhip.hip (see the knob list at the top of kernels.hip.h).
+"""
+import concurrent.futures as cf
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "ray_amd", "csrc")
+VDIR = os.path.join(CSRC, "_build", "variants")
+
+VARIANTS = json.loads(os.environ.get("RT_VARIANTS", "null")) or {
+    "base": [],
+    "stack32": ["-DRT_LDS_STACK_DEPTH=32"],
+    "stack32_w5": ["-DRT_LDS_STACK_DEPTH=32", "-DRT_TRACE_MIN_WAVES=5"],
+    "stack24_w6": ["-DRT_LDS_STACK_DEPTH=24", "-DRT_TRACE_MIN_WAVES=6"],
+    "contract": ["-ffp-contract=fast"],
+}
+
+
+def build_one(name, flags):
+    import __graft_entry__ as g
+    out = os.path.join(VDIR, name)
+    os.makedirs(out, exist_ok=True)
+    flags = [f for f in flags if not f.startswith("+")]
+    base = [f for f in g.HIPCC_FLAGS if not (f.startswith("-ffp-contract") and any(x.startswith("-ffp-contract") for x in flags))]
+    cmd = [g._hipcc(), *base, *flags, "-Rpass-analysis=kernel-resource-usage", "-c", "rayhip.hip", "-o", os.path.join(out, "rayhip.o")]
+    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    subprocess.run([g._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(out, "rayhip.o"),
+                    os.path.join(CSRC, "_build", "sort.o"), "-o", os.path.join(out, "librayhip.so")], cwd=CSRC, check=True)
+    res = {}
+    cur = None
+    for line in r.stderr.splitlines():
+        if "Function Name:" in line:
+            cur = line.split("Function Name:")[1].split("[")[0].strip()
+            cur = "closest" if "k_trace_closestILb0" in cur else "shadow" if "k_trace_shadowILb0" in cur else \
+                "shade" if "k_shadeILb0" in cur else None
+        elif cur and any(k in line for k in ("VGPRs:", "ScratchSize", "Occupancy", "LDS Size")):
+            body = line.split("remark:")[1].rsplit("[-Rpass", 1)[0]
+            k, v = body.rsplit(":", 1)
+            res.setdefault(cur, {})[k.strip().split(" ")[0]] = v.strip()
+    if r.returncode != 0:
+        print(name, "FAILED\n", r.stderr[-2000:])
+    return name, res
+
+
+def build():
+    with cf.ThreadPoolExecutor(4) as ex:
+        for name, res in ex.map(lambda kv: build_one(*kv), VARIANTS.items()):
+            print(name, json.dumps(res))
+
+
+def run(workload="sponza", K=16):
+    # one process per variant: the HIP runtime resolves kernels by name across loaded code objects, so two
+    # variants of the same kernels must never live in one process
+    import bench
+    bench.get_scene_blob(workload, bench.WORKLOADS[workload], 0, 1, lambda: None)  # build + cache once
+    for name in VARIANTS:
+        if os.path.exists(os.path.join(VDIR, name, "librayhip.so")):
+            subprocess.run([sys.executable, __file__, "run1", name, workload, str(K)])
+
+
+def run1(name, workload="sponza", K=16):
+    # NOTE: must not load libray_hip.so here (ray_amd.api): it pulls the default librayhip.so into the global
+    # symbol scope and the variant's kernel stubs (weak template symbols) would bind to it
+    import numpy as np
+    import bench
+    from ray_amd import hip
+    wl = bench.WORKLOADS[workload]
+    cache_dir = os.environ.get("RAY_AMD_CACHE", "/tmp/ray_amd_cache")
+    with open(os.path.join(cache_dir, f"{workload}_{wl.get('detail', 0)}.rayscene"), "rb") as f:
+        blob = f.read()
+    pmj = np.load(os.path.join(ROOT, "tests", "golden", "pmj02_samples.npy"))
+    ref_path = f"/tmp/variants_ref_{workload}_{K}.npy"
+    ref_img = np.load(ref_path) if os.path.exists(ref_path) else None
+    if True:
+        path = os.path.join(VDIR, name, "librayhip.so")
+        L = hip.Library(path)
+        ctx = hip.Context(0, L)
+        ctx.upload_static(pmj)
+        ctx.resize(wl["w"], wl["h"])
+        ctx.upload_scene_blob(blob)
+        for it in range(1, 3):
+            ctx.render(it, flags=(hip.FLAG_SORT_RAYS if "+sort" in VARIANTS[name] else 0))
+        ctx.sync()
+        ctx.trav_timing()
+        ctx.stage_times()
+        t0 = time.perf_counter()
+        rflags = (hip.FLAG_SORT_RAYS if "+sort" in VARIANTS[name] else 0) | (hip.FLAG_NO_REFILL if "+norefill" in VARIANTS[name] else 0)
+        for it in range(3, 3 + K):
+            ctx.render(it, flags=hip.FLAG_TIME_STAGES | rflags)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        (k2, n2), (k3, n3) = ctx.trav_timing()
+        st = ctx.stage_times()
+        img = ctx.readback(hip.BUF_RAW)
+        if ref_img is None:
+            ref_img = img
+            np.save(ref_path, img)
+        d = np.abs(img - ref_img)
+        ctx.render(3 + K, flags=hip.FLAG_COUNT_TRAVERSAL)
+        c2, c3 = ctx.trav_counters()
+        print(f"{name:14s} {wl['w'] * wl['h'] * K / dt / 1e6:7.1f} Msamples/s  step {dt / K * 1e3:6.2f} ms | K2 {k2 / K:6.2f} ms K3 {k3 / K:5.2f} ms "
+              f"shade {(st['primary_shade'] + st['secondary_shade']) / K / 1e3:5.2f} ms gen {st['primary_ray_gen'] / K / 1e3:4.2f} sort {st['secondary_sort'] / K / 1e3:4.2f} | "
+              f"vs first: max|d| {d.max():.2e} frac>1e-3 {(d.max(axis=-1) > 1e-3).mean():.2e} | max_stack {c2['max_stack']}/{c3['max_stack']}",
+              flush=True)
+        ctx.close()
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    elif sys.argv[1] == "run1":
+        run1(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    else:
+        run(*(sys.argv[2:3] or ["sponza"]), *(int(x) for x in sys.argv[3:4]))
