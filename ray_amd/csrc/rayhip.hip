@@ -520,8 +520,8 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
     uint32_t *spill = c->stack_spill.as<uint32_t>();
     const TraceParams tp_ = make_trace_params(*cam, c->sc.tlas_root, iteration);
 
-    const bool refill = (flags & RAYHIP_FLAG_NO_REFILL) == 0;
-    // K2 launcher: persistent ray-refill kernel by default, plain kernel on request; instrumented variants on request
+    const bool refill = (flags & RAYHIP_FLAG_REFILL) != 0;
+    // K2 launcher: one-ray-per-lane kernel by default, persistent ray-refill kernel on request; instrumented variants on request
     auto launch_closest = [&](const RaySoA &r, const uint32_t *cnt_ptr, int init_hits) {
         if (refill) {
             if (count) {
@@ -830,7 +830,7 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     HIP_TRY(hipMemset(tc, 0, sizeof(before)));
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
-    if (flags & RAYHIP_FLAG_NO_REFILL) {
+    if ((flags & RAYHIP_FLAG_REFILL) == 0) {
         k_trace_closest<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0,
                                                          c->stack_spill.as<uint32_t>(), tc);
     } else {

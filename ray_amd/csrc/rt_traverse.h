@@ -32,29 +32,41 @@ struct ArrayStack {
 
 #define RT_SIGN_OF(f) (((f) >= 0) ? 1 : -1)
 
-// CoreRef.cpp:24-50
-RT_HD void intersect_tri(const f3 ro, const f3 rd, const rayhip_tri_accel &tri, const uint32_t prim_index, Hit &inter) {
-    const float det = rd.x * tri.n_plane[0] + rd.y * tri.n_plane[1] + rd.z * tri.n_plane[2];
-    const float dett = tri.n_plane[3] - (ro.x * tri.n_plane[0] + ro.y * tri.n_plane[1] + ro.z * tri.n_plane[2]);
-    if (det == 0.0f || RT_SIGN_OF(dett) != RT_SIGN_OF(det * inter.t - dett)) {
-        return;
-    }
+// One triangle fetched as three 16-byte loads issued together (a single memory round trip per triangle).
+struct TriData {
+    float4 n, u, v;
+};
+RT_HD TriData load_tri(const rayhip_tri_accel *tris, const uint32_t i) {
+    const float4 *p = reinterpret_cast<const float4 *>(tris + i);
+    TriData t;
+    t.n = p[0], t.u = p[1], t.v = p[2];
+    return t;
+}
+
+// CoreRef.cpp:24-50.  Same operations in the same order as the reference; the three early `return`s are folded
+// into one predicate so that no load or divide sits behind a branch (on the GPU every early-out used to cost a
+// dependent memory round trip: n_plane -> branch -> u_plane -> branch -> v_plane).  The speculated arithmetic is
+// discarded when the predicate fails, so accepted hits are bit-identical.
+RT_HD void intersect_tri(const f3 ro, const f3 rd, const TriData &tri, const uint32_t prim_index, Hit &inter) {
+    const float det = rd.x * tri.n.x + rd.y * tri.n.y + rd.z * tri.n.z;
+    const float dett = tri.n.w - (ro.x * tri.n.x + ro.y * tri.n.y + ro.z * tri.n.z);
+    bool ok = !(det == 0.0f || RT_SIGN_OF(dett) != RT_SIGN_OF(det * inter.t - dett));
+
     const float p0 = det * ro.x + dett * rd.x, p1 = det * ro.y + dett * rd.y, p2 = det * ro.z + dett * rd.z;
 
-    const float detu = (p0 * tri.u_plane[0] + p1 * tri.u_plane[1] + p2 * tri.u_plane[2]) + det * tri.u_plane[3];
-    if (RT_SIGN_OF(detu) != RT_SIGN_OF(det - detu)) {
-        return;
-    }
-    const float detv = (p0 * tri.v_plane[0] + p1 * tri.v_plane[1] + p2 * tri.v_plane[2]) + det * tri.v_plane[3];
-    if (RT_SIGN_OF(detv) != RT_SIGN_OF(det - detu - detv)) {
-        return;
-    }
-    const float rdet = (1.0f / det);
+    const float detu = (p0 * tri.u.x + p1 * tri.u.y + p2 * tri.u.z) + det * tri.u.w;
+    ok = ok && !(RT_SIGN_OF(detu) != RT_SIGN_OF(det - detu));
 
-    inter.prim_index = (det < 0.0f) ? int(prim_index) : -int(prim_index) - 1;
-    inter.t = dett * rdet;
-    inter.u = detu * rdet;
-    inter.v = detv * rdet;
+    const float detv = (p0 * tri.v.x + p1 * tri.v.y + p2 * tri.v.z) + det * tri.v.w;
+    ok = ok && !(RT_SIGN_OF(detv) != RT_SIGN_OF(det - detu - detv));
+
+    const float rdet = (1.0f / det);
+    if (ok) {
+        inter.prim_index = (det < 0.0f) ? int(prim_index) : -int(prim_index) - 1;
+        inter.t = dett * rdet;
+        inter.u = detu * rdet;
+        inter.v = detv * rdet;
+    }
 }
 #undef RT_SIGN_OF
 
@@ -95,6 +107,45 @@ RT_HD bool bbox_test(const f3 o, const f3 inv_d, const float t, const float mn[3
     return tmin <= tmax && tmin <= t && tmax > 0;
 }
 
+// One visit of an inner node (body of the inner loop, CoreRef.cpp:1961-1993): fetch the 64-byte node as four
+// 16-byte loads issued together -- child links included, so the node costs ONE memory round trip -- slab-test both
+// children against the current t, descend into the nearer one and push the farther one.
+template <class Stack>
+RT_HD void bvh2_node_step(const rayhip_bvh2_node *nodes, const f3 ro, const f3 inv_d, const float t, uint32_t &cur,
+                          Stack &st, TravCount *cnt) {
+    const float4 *np = reinterpret_cast<const float4 *>(nodes + cur);
+    const float4 d0 = np[0], d1 = np[1], d2 = np[2], links = np[3];
+    const uint32_t left_child = float_as_uint(links.x), right_child = float_as_uint(links.y);
+    if (cnt) {
+        ++cnt->nodes;
+        cnt->max_stack = st.size > cnt->max_stack ? st.size : cnt->max_stack;
+    }
+    const float ch0_min[3] = {d0.x, d0.z, d2.x};
+    const float ch0_max[3] = {d0.y, d0.w, d2.y};
+    const float ch1_min[3] = {d1.x, d1.z, d2.z};
+    const float ch1_max[3] = {d1.y, d1.w, d2.w};
+
+    float ch0_dist, ch1_dist;
+    const bool ch0_res = bbox_test(ro, inv_d, t, ch0_min, ch0_max, ch0_dist);
+    const bool ch1_res = bbox_test(ro, inv_d, t, ch1_min, ch1_max, ch1_dist);
+
+    // `cur = ch0_res ? children[0] : children[1]; if both: nearer first, push the farther` as selects
+    uint32_t next = ch0_res ? left_child : right_child;
+    uint32_t far_child = right_child;
+    if (ch0_res && ch1_res && ch1_dist < ch0_dist) {
+        far_child = next;
+        next = right_child;
+    }
+    if (!ch0_res && !ch1_res) {
+        cur = st.pop();
+    } else {
+        cur = next;
+        if (ch0_res && ch1_res) {
+            st.push(far_child);
+        }
+    }
+}
+
 // Ordered DFS over the bvh2 pool.  `leaf(word)` handles one leaf word and returns true to stop the whole
 // walk (any-hit early out).  `t_ref` is read at every node so that hits found in earlier leaves prune.
 // Loop structure == CoreRef.cpp:1958-2014 / 2439-2490.
@@ -108,35 +159,7 @@ RT_HD bool walk_bvh2(const rayhip_bvh2_node *nodes, const uint32_t root_index, c
     while (st.size > base) {
         uint32_t leaf_node = 0;
         while (st.size > base && (cur & BVH2_PRIM_COUNT_BITS) == 0) {
-            const rayhip_bvh2_node &n = nodes[cur];
-            if (cnt) {
-                ++cnt->nodes;
-                cnt->max_stack = st.size > cnt->max_stack ? st.size : cnt->max_stack;
-            }
-            uint32_t children[2] = {n.left_child, n.right_child};
-
-            const float ch0_min[3] = {n.ch_data0[0], n.ch_data0[2], n.ch_data2[0]};
-            const float ch0_max[3] = {n.ch_data0[1], n.ch_data0[3], n.ch_data2[1]};
-            const float ch1_min[3] = {n.ch_data1[0], n.ch_data1[2], n.ch_data2[2]};
-            const float ch1_max[3] = {n.ch_data1[1], n.ch_data1[3], n.ch_data2[3]};
-
-            float ch0_dist, ch1_dist;
-            const bool ch0_res = bbox_test(ro, inv_d, t_ref, ch0_min, ch0_max, ch0_dist);
-            const bool ch1_res = bbox_test(ro, inv_d, t_ref, ch1_min, ch1_max, ch1_dist);
-
-            if (!ch0_res && !ch1_res) {
-                cur = st.pop();
-            } else {
-                cur = ch0_res ? children[0] : children[1];
-                if (ch0_res && ch1_res) {
-                    if (ch1_dist < ch0_dist) {
-                        const uint32_t temp = cur;
-                        cur = children[1];
-                        children[1] = temp;
-                    }
-                    st.push(children[1]);
-                }
-            }
+            bvh2_node_step(nodes, ro, inv_d, t_ref, cur, st, cnt);
             if ((cur & BVH2_PRIM_COUNT_BITS) != 0 && (leaf_node & BVH2_PRIM_COUNT_BITS) == 0) {
                 leaf_node = cur;
                 cur = st.pop();
@@ -170,8 +193,12 @@ RT_HD bool intersect_tris_closest(const f3 ro, const f3 rd, const rayhip_tri_acc
     inter.t = out_inter.t;
     inter.u = 0.0f;
     inter.v = -1.0f;
+    // the next triangle's 48 bytes are requested before the current one is tested (one round trip in flight ahead)
+    TriData cur_tri = load_tri(tris, uint32_t(tri_start));
     for (int i = tri_start; i < tri_end; ++i) {
-        intersect_tri(ro, rd, tris[i], uint32_t(i), inter);
+        const TriData next_tri = (i + 1 < tri_end) ? load_tri(tris, uint32_t(i + 1)) : cur_tri;
+        intersect_tri(ro, rd, cur_tri, uint32_t(i), inter);
+        cur_tri = next_tri;
     }
     const bool hit = inter.v >= 0.0f;
     out_inter.obj_index = hit ? inter.obj_index : out_inter.obj_index;
@@ -192,8 +219,11 @@ RT_HD bool intersect_tris_any(const f3 ro, const f3 rd, const rayhip_tri_accel *
     inter.t = out_inter.t;
     inter.u = 0.0f;
     inter.v = -1.0f;
+    TriData cur_tri = load_tri(tris, uint32_t(tri_start));
     for (int i = tri_start; i < tri_end; ++i) {
-        intersect_tri(ro, rd, tris[i], uint32_t(i), inter);
+        const TriData next_tri = (i + 1 < tri_end) ? load_tri(tris, uint32_t(i + 1)) : cur_tri;
+        intersect_tri(ro, rd, cur_tri, uint32_t(i), inter);
+        cur_tri = next_tri;
         if (inter.v >= 0.0f && ((inter.prim_index > 0 && (materials[indices[i]].front_mi & MATERIAL_SOLID_BIT)) ||
                                 (inter.prim_index < 0 && (materials[indices[i]].back_mi & MATERIAL_SOLID_BIT)))) {
             break;

@@ -113,35 +113,7 @@ template <class Stack> RT_HD void tm_resume(ClosestMachine &m, Stack &st, bool a
 
 // one iteration of the inner node loop, CoreRef.cpp:1961-2010
 template <class Stack> RT_HD void tm_node_step(ClosestMachine &m, const SceneView &sc, Stack &st, TravCount *cnt) {
-    const rayhip_bvh2_node &n = sc.nodes[m.cur];
-    if (cnt) {
-        ++cnt->nodes;
-        cnt->max_stack = st.size > cnt->max_stack ? st.size : cnt->max_stack;
-    }
-    uint32_t children[2] = {n.left_child, n.right_child};
-
-    const float ch0_min[3] = {n.ch_data0[0], n.ch_data0[2], n.ch_data2[0]};
-    const float ch0_max[3] = {n.ch_data0[1], n.ch_data0[3], n.ch_data2[1]};
-    const float ch1_min[3] = {n.ch_data1[0], n.ch_data1[2], n.ch_data2[2]};
-    const float ch1_max[3] = {n.ch_data1[1], n.ch_data1[3], n.ch_data2[3]};
-
-    float ch0_dist, ch1_dist;
-    const bool ch0_res = bbox_test(m.o, m.inv_d, m.h.t, ch0_min, ch0_max, ch0_dist);
-    const bool ch1_res = bbox_test(m.o, m.inv_d, m.h.t, ch1_min, ch1_max, ch1_dist);
-
-    if (!ch0_res && !ch1_res) {
-        m.cur = st.pop();
-    } else {
-        m.cur = ch0_res ? children[0] : children[1];
-        if (ch0_res && ch1_res) {
-            if (ch1_dist < ch0_dist) {
-                const uint32_t temp = m.cur;
-                m.cur = children[1];
-                children[1] = temp;
-            }
-            st.push(children[1]);
-        }
-    }
+    bvh2_node_step(sc.nodes, m.o, m.inv_d, m.h.t, m.cur, st, cnt);
     if (tm_is_leaf(m.cur) && !tm_is_leaf(m.leaf_node)) {
         m.leaf_node = m.cur;
         m.cur = st.pop();

@@ -344,7 +344,7 @@ HS_API int hostsim_k_generate_primary_rays(hostsim_ctx *c, const rayhip_camera *
 
 HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam, rayhip_ray *rays, rayhip_hit *hits,
                                        int count, int iteration, uint32_t flags, rayhip_trav_counters *out_counters) {
-    const bool machine = use_machine() || (flags & RAYHIP_FLAG_NO_REFILL) == 0;
+    const bool machine = use_machine() || (flags & RAYHIP_FLAG_REFILL) != 0;
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     ArrayStack st;
     rayhip_trav_counters acc = {};

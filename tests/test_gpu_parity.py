@@ -66,7 +66,7 @@ def test_primary_rays(gpu_lib, name):
     np.testing.assert_allclose(hits["t"], ref_h["t"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("kernel_flags", [0, hip.FLAG_NO_REFILL], ids=["refill", "plain"])
+@pytest.mark.parametrize("kernel_flags", [0, hip.FLAG_REFILL], ids=["plain", "refill"])
 @pytest.mark.parametrize("name", SCENES)
 def test_closest_hit_on_reference_rays(gpu_lib, name, kernel_flags):
     """K2 (both kernel forms) on the reference's own rays: exact (obj_index, prim_index); |dt|,|du|,|dv| <= 1e-5 rel"""
@@ -98,7 +98,7 @@ def test_traversal_work_counters_match_host(gpu_lib, hostsim_lib, name):
     g = util.golden_ref(name)
     gpu = util.make_context(gpu_lib, name)
     host = util.make_context(hostsim_lib, name)
-    for fl in (0, hip.FLAG_NO_REFILL):  # persistent ray-refill kernel and plain kernel: same per-ray visiting order
+    for fl in (0, hip.FLAG_REFILL):  # plain kernel and persistent ray-refill kernel: same per-ray visiting order
         _, hg, tc_g = gpu.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=fl)
         _, hh, tc_h = host.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=fl)
         assert tc_g == tc_h
@@ -158,7 +158,7 @@ def test_refill_kernel_matches_plain_kernel(gpu_lib):
     """the persistent ray-refill traversal must give the same image as one-ray-per-lane traversal, bit for bit"""
     name = "cornell_principled"
     a = util.render_frames(util.make_context(gpu_lib, name, 192, 128), 3)
-    b = util.render_frames(util.make_context(gpu_lib, name, 192, 128), 3, flags=hip.FLAG_NO_REFILL)
+    b = util.render_frames(util.make_context(gpu_lib, name, 192, 128), 3, flags=hip.FLAG_REFILL)
     assert np.array_equal(a, b)
 
 
