@@ -18,7 +18,8 @@
 //     inside a 32-lane half).  48 entries x 64 lanes x 4 B = 12 KiB per wave, the same budget the reference's
 //     shader takes (shaders/intersect_scene.comp.glsl:87).
 //   * ray compaction between stages uses one atomic per wavefront: ballot + mbcnt prefix (wave_alloc) instead of
-//     the reference's per-thread atomicAdd (shaders/shade.comp.glsl:2432,2452).
+//     the reference's per-thread atomicAdd (shaders/shade.comp.glsl:2432,2452), and the wavefronts are spread over
+//     64 counters (RayQueue below) because same-address atomics serialise at ~11 ns each on MI355X.
 //   * all per-ray state is SoA float4 planes (rt_types.h): 16 B per lane per access, 1 KiB per wave instruction.
 #pragma once
 
@@ -92,6 +93,40 @@ __device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter, const bool pre
     return base + prefix;
 }
 
+// Striped ray queue.  The slots of a wavefront-state buffer are split into `stripes` equal segments, each with its
+// own fill counter on its own 256-byte line.  A 64-ray chunk read from stripe s writes its survivors to stripe s of
+// the output queue, so (a) a stripe can never overflow -- it receives at most what it held, and the ray generator
+// deals pixel chunks round-robin -- and (b) the one-atomic-per-wavefront slot allocation is spread over `stripes`
+// addresses.  Measured on MI355X (tools/atomic_bench.hip): 11.5 ns per atomic on one counter, 0.37 ns on 64; with
+// one counter the 250 k allocations of a 1080p frame were half of the shade kernels' time.  Rays stay densely packed
+// inside each stripe, so wavefronts stay full; stripes == 1 is the plain dense queue (kernel-level test hooks, ray
+// sort, refill kernel).
+constexpr uint32_t QUEUE_COUNTER_STRIDE = 64; // uint32 words between stripe counters
+constexpr uint32_t QUEUE_MAX_STRIPES = 64;
+struct RayQueue {
+    uint32_t *counts; // counts[s * QUEUE_COUNTER_STRIDE] = rays in stripe s
+    uint32_t stripes;
+    uint32_t chunks_per_stripe; // stripe capacity / 64
+
+    __device__ __forceinline__ uint32_t total_chunks() const { return stripes * chunks_per_stripe; }
+    // chunk c (wave-uniform) -> its stripe, first slot and number of live lanes; false if the chunk is empty.
+    // Chunks are numbered stripe-minor so that consecutive wavefronts work on different stripes.
+    __device__ __forceinline__ bool chunk(const uint32_t c, uint32_t &stripe, uint32_t &slot0, uint32_t &n_live) const {
+        stripe = c % stripes;
+        const uint32_t j = c / stripes;
+        const uint32_t n = counts[stripe * QUEUE_COUNTER_STRIDE];
+        if (j * WAVE >= n) {
+            return false;
+        }
+        slot0 = (stripe * chunks_per_stripe + j) * WAVE;
+        n_live = n - j * WAVE < uint32_t(WAVE) ? n - j * WAVE : uint32_t(WAVE);
+        return true;
+    }
+    __device__ __forceinline__ uint32_t alloc(const uint32_t stripe, const bool pred) const {
+        return stripe * chunks_per_stripe * WAVE + wave_alloc(counts + stripe * QUEUE_COUNTER_STRIDE, pred);
+    }
+};
+
 struct PixelBuffers {
     float4 *temp, *full, *half, *raw, *final_, *base_color, *depth_normals;
     uint16_t *required_samples;
@@ -101,13 +136,17 @@ struct PixelBuffers {
 __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint32_t *__restrict__ pmj,
                                                const float *__restrict__ filter_table,
                                                const uint16_t *__restrict__ required_samples, const RaySoA rays,
-                                               const HitSoA hits, uint32_t *__restrict__ out_count) {
+                                               const HitSoA hits, const RayQueue out) {
     const int n = p.rect[2] * p.rect[3];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((n + WAVE - 1) / WAVE) * WAVE; i += gridDim.x * blockDim.x) {
+    const uint32_t n_chunks = uint32_t((n + WAVE - 1) / WAVE), waves_per_block = blockDim.x / WAVE;
+    const uint32_t lane = threadIdx.x % WAVE;
+    // pixel chunk pc -> stripe pc % stripes: every stripe gets at most ceil(n_chunks / stripes) chunks
+    for (uint32_t pc = blockIdx.x * waves_per_block + threadIdx.x / WAVE; pc < n_chunks; pc += gridDim.x * waves_per_block) {
+        const int i = int(pc * WAVE + lane);
         const bool in_rect = i < n;
         const int x = p.rect[0] + (in_rect ? i % p.rect[2] : 0), y = p.rect[1] + (in_rect ? i / p.rect[2] : 0);
         const bool live = in_rect && pixel_owned(p.shard, p.w, x, y) && !(required_samples[y * p.w + x] < p.iteration);
-        const uint32_t slot = wave_alloc(out_count, live);
+        const uint32_t slot = out.alloc(pc % out.stripes, live);
         if (live) {
             Ray r;
             Hit h;
@@ -122,13 +161,17 @@ __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint
 // One ray per lane; grid-stride over the device-resident ray count.
 template <bool COUNT>
 __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest(const SceneView sc, const TraceParams tp, const RaySoA rays,
-                                                       const HitSoA hits, const uint32_t *__restrict__ ray_count,
+                                                       const HitSoA hits, const RayQueue queue,
                                                        const int init_hits, uint32_t *__restrict__ stack_spill,
                                                        unsigned long long *__restrict__ counters) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
-    const uint32_t n = *ray_count;
     const uint32_t lane = threadIdx.x;
-    for (uint32_t i = blockIdx.x * WAVE + lane; i < n; i += gridDim.x * WAVE) {
+    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
+            continue;
+        }
+        const uint32_t i = slot0 + lane;
         Ray r;
         load_ray_od(rays, i, r);
         {
@@ -257,15 +300,19 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest_refi
 // ---- K3 ---------------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const SceneView sc, const TraceParams tp, const ShadowSoA shadow,
-                                                      const uint32_t *__restrict__ ray_count, const float limit,
+                                                      const RayQueue queue, const float limit,
                                                       const int img_w, float4 *__restrict__ temp_buf,
                                                       float4 *__restrict__ out_rc, /* test hook, may be null */
                                                       uint32_t *__restrict__ stack_spill,
                                                       unsigned long long *__restrict__ counters) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
-    const uint32_t n = *ray_count;
     const uint32_t lane = threadIdx.x;
-    for (uint32_t i = blockIdx.x * WAVE + lane; i < n; i += gridDim.x * WAVE) {
+    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
+            continue;
+        }
+        const uint32_t i = slot0 + lane;
         const ShadowRay r = load_shadow(shadow, i);
         LdsStack st;
         st.lane_base = &lds_stack[lane];
@@ -291,14 +338,17 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const
 // ---- K5 ---------------------------------------------------------------------------------------------------
 template <bool PRIMARY>
 __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
-                                               const HitSoA hits, const uint32_t *__restrict__ ray_count,
-                                               const RaySoA rays_out, uint32_t *__restrict__ out_ray_count,
-                                               const ShadowSoA shadow_out, uint32_t *__restrict__ out_shadow_count,
+                                               const HitSoA hits, const RayQueue in, const RaySoA rays_out,
+                                               const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
                                                const PixelBuffers px, const int img_w, const float mix_factor) {
-    const uint32_t n = *ray_count;
-    const uint32_t n_pad = ((n + WAVE - 1) / WAVE) * WAVE; // whole waves stay in the loop for the ballots
-    for (uint32_t i = blockIdx.x * WAVE + threadIdx.x; i < n_pad; i += gridDim.x * WAVE) {
-        const bool active = i < n;
+    for (uint32_t c = blockIdx.x; c < in.total_chunks(); c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!in.chunk(c, stripe, slot0, n_live)) {
+            continue;
+        }
+        // whole wave stays in the body for the ballots
+        const uint32_t i = slot0 + threadIdx.x;
+        const bool active = threadIdx.x < n_live;
         Ray new_ray;
         ShadowRay sh_r;
         ShadeResult res;
@@ -315,11 +365,12 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
                 add_secondary_pixel(res, xy, img_w, px.temp);
             }
         }
-        const uint32_t ray_slot = wave_alloc(out_ray_count, res.emit_secondary);
+        // survivors go to the same stripe they came from (see RayQueue)
+        const uint32_t ray_slot = out_rays.alloc(stripe, res.emit_secondary);
         if (res.emit_secondary) {
             store_ray(rays_out, ray_slot, new_ray);
         }
-        const uint32_t sh_slot = wave_alloc(out_shadow_count, res.emit_shadow);
+        const uint32_t sh_slot = out_shadow.alloc(stripe, res.emit_shadow);
         if (res.emit_shadow) {
             store_shadow(shadow_out, sh_slot, sh_r);
         }

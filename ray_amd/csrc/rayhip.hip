@@ -95,7 +95,7 @@ struct rayhip_ctx {
     RaySoA rays[2] = {};
     HitSoA hits = {};
     ShadowSoA shadow = {};
-    DevBuf counters;      // uint32: ray_count[MAX_BOUNCE_SLOTS], shadow_count[MAX_BOUNCE_SLOTS]
+    DevBuf counters;      // uint32 [MAX_BOUNCE_SLOTS][2: rays, shadow rays][QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE]
     DevBuf trav_counters; // u64 [2][5]
     DevBuf stack_spill;   // per-wave overflow slabs of the traversal stack
     DevBuf sort_keys[2], sort_idx[2], sort_temp;
@@ -115,8 +115,19 @@ struct rayhip_ctx {
     unsigned long long trav_launches[2] = {0, 0};
     double stage_us[11] = {};
 
-    uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + b; }
-    uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + MAX_BOUNCE_SLOTS + b; }
+    static constexpr size_t QUEUE_WORDS = size_t(QUEUE_MAX_STRIPES) * QUEUE_COUNTER_STRIDE;
+    uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + size_t(2 * b) * QUEUE_WORDS; }
+    uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + size_t(2 * b + 1) * QUEUE_WORDS; }
+    // queue geometry for a frame of `items` pixels split over `stripes` stripes
+    static RayQueue make_queue(uint32_t *counts, size_t items, uint32_t stripes) {
+        const size_t chunks = (items + WAVE - 1) / WAVE;
+        return RayQueue{counts, stripes, uint32_t((chunks + stripes - 1) / stripes)};
+    }
+    RayQueue ray_queue(int b, size_t items, uint32_t stripes) const { return make_queue(ray_count(b), items, stripes); }
+    RayQueue shadow_queue(int b, size_t items, uint32_t stripes) const { return make_queue(shadow_count(b), items, stripes); }
+    int clear_queues(int bounces, hipStream_t s) const {
+        return hipMemsetAsync(counters.p, 0, size_t(2 * bounces) * QUEUE_WORDS * sizeof(uint32_t), s) == hipSuccess ? 0 : 1;
+    }
 };
 
 namespace {
@@ -137,9 +148,9 @@ int use_device(rayhip_ctx *c) {
 }
 
 int alloc_frame(rayhip_ctx *c, int w, int h) {
-    const size_t n = size_t(w) * size_t(h);
-    if (c->px_temp.alloc(n * 16) || c->px_full.alloc(n * 16) || c->px_half.alloc(n * 16) || c->px_raw.alloc(n * 16) ||
-        c->px_final.alloc(n * 16) || c->px_base.alloc(n * 16) || c->px_dn.alloc(n * 16) || c->px_req.alloc(n * 2)) {
+    const size_t npix = size_t(w) * size_t(h);
+    if (c->px_temp.alloc(npix * 16) || c->px_full.alloc(npix * 16) || c->px_half.alloc(npix * 16) || c->px_raw.alloc(npix * 16) ||
+        c->px_final.alloc(npix * 16) || c->px_base.alloc(npix * 16) || c->px_dn.alloc(npix * 16) || c->px_req.alloc(npix * 2)) {
         return 1;
     }
     c->px.temp = c->px_temp.as<float4>(), c->px.full = c->px_full.as<float4>(), c->px.half = c->px_half.as<float4>();
@@ -147,6 +158,8 @@ int alloc_frame(rayhip_ctx *c, int w, int h) {
     c->px.base_color = c->px_base.as<float4>(), c->px.depth_normals = c->px_dn.as<float4>();
     c->px.required_samples = c->px_req.as<uint16_t>();
 
+    // wavefront-state slots: one per pixel + the rounding of the striped queues (each stripe holds whole chunks)
+    const size_t n = npix + size_t(WAVE) * QUEUE_MAX_STRIPES;
     for (int k = 0; k < 2; ++k) {
         for (int pl = 0; pl < 5; ++pl) {
             if (c->ray_planes[k][pl].alloc(n * (pl == 4 ? 8 : 16))) {
@@ -291,7 +304,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         delete c;
         return 1;
     }
-    if (c->counters.alloc(sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS) || c->trav_counters.alloc(sizeof(unsigned long long) * 10)) {
+    if (c->counters.alloc(sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 10)) {
         delete c;
         return 1;
     }
@@ -522,25 +535,29 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
 
     const bool refill = (flags & RAYHIP_FLAG_REFILL) != 0;
     // K2 launcher: one-ray-per-lane kernel by default, persistent ray-refill kernel on request; instrumented variants on request
-    auto launch_closest = [&](const RaySoA &r, const uint32_t *cnt_ptr, int init_hits) {
+    // striped queues unless a stage needs one dense ray array (sort, refill kernel)
+    const uint32_t stripes = (sort_rays || refill) ? 1u : QUEUE_MAX_STRIPES;
+    auto launch_closest = [&](const RaySoA &r, const RayQueue &q, int init_hits) {
         if (refill) {
             if (count) {
-                k_trace_closest_refill<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, cnt_ptr, init_hits, spill, tc);
+                k_trace_closest_refill<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q.counts, init_hits, spill, tc);
             } else {
-                k_trace_closest_refill<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, cnt_ptr, init_hits, spill, tc);
+                k_trace_closest_refill<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q.counts, init_hits, spill, tc);
             }
         } else {
             if (count) {
-                k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, cnt_ptr, init_hits, spill, tc);
+                k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
             } else {
-                k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, cnt_ptr, init_hits, spill, tc);
+                k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
             }
         }
     };
 
     StageTimer tm(c, stats != nullptr || (flags & RAYHIP_FLAG_TIME_STAGES) != 0);
 
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS, s));
+    if (c->clear_queues(max_depth + 2, s)) {
+        return fail("queue counter clear failed");
+    }
 
     const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
@@ -550,12 +567,12 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         return 1;
     }
     k_raygen<<<grid_for(c, npix, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
-                                                    c->rays[0], c->hits, c->ray_count(0));
+                                                    c->rays[0], c->hits, c->ray_queue(0, npix, stripes));
     if (tm.mark(ST_PTRACE, 0)) {
         return 1;
     }
     if (c->sc.tlas_root != 0xffffffffu) {
-        launch_closest(c->rays[0], c->ray_count(0), 0);
+        launch_closest(c->rays[0], c->ray_queue(0, npix, stripes), 0);
     }
     int cur = 0;
     for (int bounce = 0; bounce <= max_depth; ++bounce) {
@@ -577,30 +594,30 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
             if (tm.mark(ST_STRACE, 0)) {
                 return 1;
             }
-            launch_closest(c->rays[cur], c->ray_count(bounce), 1);
+            launch_closest(c->rays[cur], c->ray_queue(bounce, npix, stripes), 1);
         }
         if (tm.mark(bounce == 0 ? ST_PSHADE : ST_SSHADE, -1)) {
             return 1;
         }
         const ShadeParams sp = make_shade_params(*cam, iteration, bounce);
         if (bounce == 0) {
-            k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_count(bounce), c->rays[cur ^ 1],
-                                                  c->ray_count(bounce + 1), c->shadow, c->shadow_count(bounce), c->px, c->w,
-                                                  mix_factor);
+            k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, npix, stripes),
+                                                  c->rays[cur ^ 1], c->ray_queue(bounce + 1, npix, stripes), c->shadow,
+                                                  c->shadow_queue(bounce, npix, stripes), c->px, c->w, mix_factor);
         } else {
-            k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_count(bounce), c->rays[cur ^ 1],
-                                                   c->ray_count(bounce + 1), c->shadow, c->shadow_count(bounce), c->px, c->w,
-                                                   mix_factor);
+            k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, npix, stripes),
+                                                   c->rays[cur ^ 1], c->ray_queue(bounce + 1, npix, stripes), c->shadow,
+                                                   c->shadow_queue(bounce, npix, stripes), c->px, c->w, mix_factor);
         }
         if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
             return 1;
         }
         const float limit = shadow_clamp_limit(*cam, bounce);
         if (count) {
-            k_trace_shadow<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_count(bounce), limit, c->w, c->px.temp,
-                                                         nullptr, spill, tc + 5);
+            k_trace_shadow<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit, c->w,
+                                                         c->px.temp, nullptr, spill, tc + 5);
         } else {
-            k_trace_shadow<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_count(bounce), limit, c->w,
+            k_trace_shadow<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit, c->w,
                                                           c->px.temp, nullptr, spill, tc + 5);
         }
         cur ^= 1;
@@ -759,10 +776,13 @@ int rayhip_k_generate_primary_rays(rayhip_ctx *c, const rayhip_camera *cam, cons
     }
     hipStream_t s = c->stream;
     const size_t npix = size_t(rect[2]) * size_t(rect[3]);
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS, s));
+    if (c->clear_queues(1, s)) {
+        return fail("queue counter clear failed");
+    }
     const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
+    // kernel-level hooks use one dense stripe so that the host sees a plain array
     k_raygen<<<grid_for(c, npix, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
-                                                    c->rays[0], c->hits, c->ray_count(0));
+                                                    c->rays[0], c->hits, c->ray_queue(0, npix, 1));
     HIP_TRY(hipGetLastError());
     uint32_t n = 0;
     HIP_TRY(hipMemcpyAsync(&n, c->ray_count(0), 4, hipMemcpyDeviceToHost, s));
@@ -831,7 +851,7 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     if ((flags & RAYHIP_FLAG_REFILL) == 0) {
-        k_trace_closest<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0,
+        k_trace_closest<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_queue(0, size_t(count), 1), 0,
                                                          c->stack_spill.as<uint32_t>(), tc);
     } else {
         k_trace_closest_refill<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0,
@@ -894,7 +914,7 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     // results land in the (otherwise idle) hit plane
-    k_trace_shadow<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_count(0), FLT_MAX, c->w, c->px.temp,
+    k_trace_shadow<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
                                                     c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
