@@ -273,9 +273,6 @@ enum {
 enum {
     RAYHIP_FLAG_SORT_RAYS = 1u << 0,     /* ray sort between bounces (RendererVK.cpp:641-652) */
     RAYHIP_FLAG_COUNT_TRAVERSAL = 1u << 1, /* run the instrumented traversal kernels (slower) */
-    RAYHIP_FLAG_REFILL = 1u << 3,          /* closest-hit traversal with the persistent ray-refill kernel instead of the
-                                              one-ray-per-lane kernel (same results; measured slower on MI355X, kept
-                                              for A/B measurements) */
     RAYHIP_FLAG_TIME_STAGES = 1u << 2      /* record HIP events around every stage WITHOUT synchronising; read the
                                               result later with rayhip_get_stage_times / rayhip_get_trav_timing */
 };
@@ -360,7 +357,7 @@ RAYHIP_API int rayhip_k_generate_primary_rays(rayhip_ctx *ctx, const rayhip_came
                                               int *out_count);
 /* Ref::IntersectScene closest hit (CoreRef.cpp:3041-3158): rays/hits are in-out host arrays */
 RAYHIP_API int rayhip_k_intersect_closest(rayhip_ctx *ctx, const rayhip_camera *cam, rayhip_ray *rays,
-                                          rayhip_hit *hits, int count, int iteration, uint32_t flags /* REFILL */,
+                                          rayhip_hit *hits, int count, int iteration, uint32_t flags /* reserved, 0 */,
                                           rayhip_trav_counters *out_counters /* may be NULL */);
 /* Ref::IntersectScene(shadow_ray_t) (CoreRef.cpp:3160-3262): out_rc[count][4] visibility * colour */
 RAYHIP_API int rayhip_k_intersect_shadow(rayhip_ctx *ctx, const rayhip_camera *cam,

@@ -4,6 +4,7 @@
 //   K1  primary_ray_gen.comp.glsl            -> k_raygen
 //   K2  intersect_scene.comp.glsl            -> k_trace_closest      (the roofline kernel)
 //   K3  intersect_scene_shadow.comp.glsl     -> k_trace_shadow
+//   K4  intersect_area_lights.comp.glsl      -> k_intersect_area_lights (+ k_shadow_blockers for the shadow-ray form)
 //   K5  shade.comp.glsl (PRIMARY/SECONDARY)  -> k_shade<PRIMARY>
 //   K9  prepare_indir_args.comp.glsl         -> (gone) ray counts stay in HBM; every stage is launched with a
 //                                               fixed grid and grid-strides over the count it reads there, so the
@@ -25,10 +26,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include "rt_arealights.h"
 #include "rt_params.h"
 #include "rt_pixel.h"
 #include "rt_sort.h"
-#include "rt_travmachine.h"
 
 namespace rt {
 
@@ -100,7 +101,7 @@ __device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter, const bool pre
 // addresses.  Measured on MI355X (tools/atomic_bench.hip): 11.5 ns per atomic on one counter, 0.37 ns on 64; with
 // one counter the 250 k allocations of a 1080p frame were half of the shade kernels' time.  Rays stay densely packed
 // inside each stripe, so wavefronts stay full; stripes == 1 is the plain dense queue (kernel-level test hooks, ray
-// sort, refill kernel).
+// sort).
 constexpr uint32_t QUEUE_COUNTER_STRIDE = 64; // uint32 words between stripe counters
 constexpr uint32_t QUEUE_MAX_STRIPES = 64;
 struct RayQueue {
@@ -210,93 +211,6 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest(cons
     }
 }
 
-// K2, persistent form with ray refill.  Every wavefront owns the 64-ray chunks w, w + gridDim, w + 2*gridDim, ... (no
-// atomics: the hand-out counter is wave-uniform) and runs the resumable state machine of rt_travmachine.h: a lane
-// whose ray is finished takes the next ray of the wave's chunks at the top of the loop while the other lanes keep
-// walking.  Per ray the visiting order -- and therefore hits and work counters -- are those of k_trace_closest.
-template <bool COUNT>
-__global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest_refill(
-    const SceneView sc, const TraceParams tp, const RaySoA rays, const HitSoA hits, const uint32_t *__restrict__ ray_count,
-    const int init_hits, uint32_t *__restrict__ stack_spill, unsigned long long *__restrict__ counters) {
-    __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
-    const uint32_t n = *ray_count;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t num_waves = gridDim.x, w = blockIdx.x;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
-
-    LdsStack st;
-    st.lane_base = &lds_stack[lane];
-    st.spill_base = stack_spill + size_t(blockIdx.x) * size_t(STACK_SPILL_DEPTH * WAVE) + lane;
-    st.size = 0;
-
-    ClosestMachine m;
-    m.state = TM_IDLE;
-    uint32_t my_ray = 0;
-    uint32_t consumed = 0; // wave-uniform: how many rays of this wave's chunks have been handed out
-    TravCount tc = {0, 0, 0, 0};
-    uint32_t rays_done = 0;
-
-    for (;;) {
-        // ---- refill: idle lanes take the next rays of this wave's chunks
-        const bool idle = (m.state == TM_IDLE);
-        const unsigned long long idle_mask = __ballot(idle);
-        if (idle_mask != 0ull) {
-            const uint32_t j = consumed + uint32_t(__popcll(idle_mask & lanes_below));
-            const uint32_t g = (w + (j >> 6) * num_waves) * WAVE + (j & 63u);
-            if (idle && g < n) {
-                Ray r;
-                load_ray_od(rays, g, r);
-                const uint2 xd = rays.xy_depth[g];
-                r.xy = xd.x, r.depth = xd.y;
-                const Hit h = init_hits ? make_hit() : load_hit(hits, g);
-                my_ray = g;
-                tm_start(m, tp, r, h, st);
-            }
-            consumed += uint32_t(__popcll(idle_mask));
-        }
-        if (!__any(m.state != TM_IDLE)) {
-            break;
-        }
-        // ---- node phase: walk inner nodes until this lane has a pending leaf (or its level/ray ends)
-        while (m.state == TM_NODE) {
-            tm_node_step(m, sc, st, COUNT ? &tc : nullptr);
-        }
-        // ---- leaf phase: one leaf per lane (instance entry or up to 8 triangle tests)
-        if (m.state == TM_LEAF) {
-            tm_leaf_step(m, sc, st, COUNT ? &tc : nullptr);
-        }
-        // ---- completion: index indirection, transparency round, write-back
-        if (m.state == TM_FINISH) {
-            Ray r;
-            const float4 o = rays.o_pdf[my_ray], c = rays.c_cs[my_ray];
-            const uint2 xd = rays.xy_depth[my_ray];
-            r.o = {o.x, o.y, o.z};
-            r.d = m.rd;
-            r.c = {c.x, c.y, c.z};
-            r.cone_spread = c.w;
-            r.xy = xd.x, r.depth = xd.y;
-            const bool done = tm_finish(m, sc, tp, r, st);
-            if (r.depth != xd.y || r.c.x != c.x || r.c.y != c.y || r.c.z != c.z) {
-                rays.c_cs[my_ray] = mkfloat4(r.c.x, r.c.y, r.c.z, r.cone_spread);
-                uint2 nxd;
-                nxd.x = r.xy, nxd.y = r.depth;
-                rays.xy_depth[my_ray] = nxd;
-            }
-            if (done) {
-                store_hit(hits, my_ray, m.h);
-                ++rays_done;
-            }
-        }
-    }
-    if (COUNT) {
-        atomicAdd(&counters[0], (unsigned long long)rays_done);
-        atomicAdd(&counters[1], (unsigned long long)tc.nodes);
-        atomicAdd(&counters[2], (unsigned long long)tc.tris);
-        atomicAdd(&counters[3], (unsigned long long)tc.instances);
-        atomicMax(&counters[4], (unsigned long long)tc.max_stack);
-    }
-}
-
 // ---- K3 ---------------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const SceneView sc, const TraceParams tp, const ShadowSoA shadow,
@@ -331,6 +245,50 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const
             atomicAdd(&counters[2], (unsigned long long)tc.tris);
             atomicAdd(&counters[3], (unsigned long long)tc.instances);
             atomicMax(&counters[4], (unsigned long long)tc.max_stack);
+        }
+    }
+}
+
+// ---- K4 ---------------------------------------------------------------------------------------------------
+// Implicit hits of visible analytic lights for secondary rays; runs right after K2 on the same queue
+// (CoreRef.cpp:4847-4849).  Only launched when the scene has visible lights.
+__global__ void __launch_bounds__(WAVE) k_intersect_area_lights(const SceneView sc, const RaySoA rays, const HitSoA hits,
+                                                               const RayQueue queue) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
+            continue;
+        }
+        const uint32_t i = slot0 + lane;
+        Ray r;
+        load_ray_od(rays, i, r);
+        const uint32_t depth = rays.xy_depth[i].y;
+        Hit h = load_hit(hits, i);
+        const Hit before = h;
+        intersect_area_lights(sc, r.o, r.d, depth, h);
+        if (h.obj_index != before.obj_index || h.t != before.t || h.u != before.u || h.v != before.v) {
+            store_hit(hits, i, h);
+        }
+    }
+}
+
+// Shadow-ray form (CoreRef.cpp:4868-4870: rc *= IntersectAreaLights(sh_r)).  The factor is exactly 0 or 1, so it is
+// applied to the ray's throughput BEFORE K3 instead of to K3's result: a blocked ray carries c = 0 through the
+// any-hit walk and adds 0 to its pixel, bit for bit what the reference adds.
+__global__ void __launch_bounds__(WAVE) k_shadow_blockers(const SceneView sc, const ShadowSoA shadow, const RayQueue queue) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
+            continue;
+        }
+        const uint32_t i = slot0 + lane;
+        const ShadowRay r = load_shadow(shadow, i);
+        if (intersect_area_lights_shadow(sc, r) == 0.0f) {
+            float4 cx = shadow.c_xy[i];
+            cx.x = cx.y = cx.z = 0.0f;
+            shadow.c_xy[i] = cx;
         }
     }
 }

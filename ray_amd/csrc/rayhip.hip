@@ -516,9 +516,6 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
     if (rect[0] < 0 || rect[1] < 0 || rect[2] <= 0 || rect[3] <= 0 || rect[0] + rect[2] > c->w || rect[1] + rect[3] > c->h) {
         return fail("rect outside the frame");
     }
-    if (c->sc.visible_lights_count != 0 || c->sc.blocker_lights_count != 0) {
-        return fail("visible / blocker analytic lights (IntersectAreaLights) are not supported yet");
-    }
     const int max_depth = cam->pass_settings.max_total_depth;
     if (max_depth + 2 > MAX_BOUNCE_SLOTS) {
         return fail("max_total_depth too large");
@@ -533,23 +530,14 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
     uint32_t *spill = c->stack_spill.as<uint32_t>();
     const TraceParams tp_ = make_trace_params(*cam, c->sc.tlas_root, iteration);
 
-    const bool refill = (flags & RAYHIP_FLAG_REFILL) != 0;
-    // K2 launcher: one-ray-per-lane kernel by default, persistent ray-refill kernel on request; instrumented variants on request
-    // striped queues unless a stage needs one dense ray array (sort, refill kernel)
-    const uint32_t stripes = (sort_rays || refill) ? 1u : QUEUE_MAX_STRIPES;
+    // striped queues unless a stage needs one dense ray array (the sort)
+    const uint32_t stripes = sort_rays ? 1u : QUEUE_MAX_STRIPES;
+    // K2 launcher (instrumented variant on request)
     auto launch_closest = [&](const RaySoA &r, const RayQueue &q, int init_hits) {
-        if (refill) {
-            if (count) {
-                k_trace_closest_refill<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q.counts, init_hits, spill, tc);
-            } else {
-                k_trace_closest_refill<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q.counts, init_hits, spill, tc);
-            }
+        if (count) {
+            k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
         } else {
-            if (count) {
-                k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
-            } else {
-                k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
-            }
+            k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
         }
     };
 
@@ -595,6 +583,9 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
                 return 1;
             }
             launch_closest(c->rays[cur], c->ray_queue(bounce, npix, stripes), 1);
+            if (c->sc.visible_lights_count != 0) {
+                k_intersect_area_lights<<<gtrace, WAVE, 0, s>>>(c->sc, c->rays[cur], c->hits, c->ray_queue(bounce, npix, stripes));
+            }
         }
         if (tm.mark(bounce == 0 ? ST_PSHADE : ST_SSHADE, -1)) {
             return 1;
@@ -613,6 +604,9 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
             return 1;
         }
         const float limit = shadow_clamp_limit(*cam, bounce);
+        if (c->sc.blocker_lights_count != 0) {
+            k_shadow_blockers<<<gtrace, WAVE, 0, s>>>(c->sc, c->shadow, c->shadow_queue(bounce, npix, stripes));
+        }
         if (count) {
             k_trace_shadow<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit, c->w,
                                                          c->px.temp, nullptr, spill, tc + 5);
@@ -792,11 +786,12 @@ int rayhip_k_generate_primary_rays(rayhip_ctx *c, const rayhip_camera *cam, cons
     std::vector<float> hv(n);
     for (int k = 0; k < 4; ++k) {
         pl[k].resize(n);
-        HIP_TRY(hipMemcpy(pl[k].data(), c->ray_planes[0][k].p, size_t(n) * 16, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(pl[k].data(), c->ray_planes[0][k].p, size_t(n) * 16, hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(hipMemcpy(xd.data(), c->ray_planes[0][4].p, size_t(n) * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hp.data(), c->hit_planes[0].p, size_t(n) * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hv.data(), c->hit_planes[1].p, size_t(n) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(xd.data(), c->ray_planes[0][4].p, size_t(n) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hp.data(), c->hit_planes[0].p, size_t(n) * 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hv.data(), c->hit_planes[1].p, size_t(n) * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     for (uint32_t i = 0; i < n; ++i) {
         rayhip_ray &r = out_rays[i];
         r.o[0] = pl[0][i].x, r.o[1] = pl[0][i].y, r.o[2] = pl[0][i].z, r.pdf = pl[0][i].w;
@@ -837,39 +832,37 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
         hv[i] = hits[i].v;
     }
     for (int k = 0; k < 4; ++k) {
-        HIP_TRY(hipMemcpy(c->ray_planes[0][k].p, pl[k].data(), size_t(count) * 16, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(c->ray_planes[0][k].p, pl[k].data(), size_t(count) * 16, hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(hipMemcpy(c->ray_planes[0][4].p, xd.data(), size_t(count) * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->hit_planes[0].p, hp.data(), size_t(count) * 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->hit_planes[1].p, hv.data(), size_t(count) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->ray_planes[0][4].p, xd.data(), size_t(count) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->hit_planes[0].p, hp.data(), size_t(count) * 16, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->hit_planes[1].p, hv.data(), size_t(count) * 4, hipMemcpyHostToDevice, s));
     const uint32_t n = uint32_t(count);
-    HIP_TRY(hipMemcpy(c->ray_count(0), &n, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->ray_count(0), &n, 4, hipMemcpyHostToDevice, s));
     unsigned long long *tc = c->trav_counters.as<unsigned long long>();
     unsigned long long before[5], after[5];
-    HIP_TRY(hipMemcpy(before, tc, sizeof(before), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(tc, 0, sizeof(before)));
+    HIP_TRY(hipMemcpyAsync(before, tc, sizeof(before), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(tc, 0, sizeof(before), s));
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
-    if ((flags & RAYHIP_FLAG_REFILL) == 0) {
-        k_trace_closest<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_queue(0, size_t(count), 1), 0,
-                                                         c->stack_spill.as<uint32_t>(), tc);
-    } else {
-        k_trace_closest_refill<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_count(0), 0,
-                                                                c->stack_spill.as<uint32_t>(), tc);
-    }
+    (void)flags;
+    k_trace_closest<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_queue(0, size_t(count), 1), 0,
+                                                     c->stack_spill.as<uint32_t>(), tc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipMemcpy(after, tc, sizeof(after), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tc, before, sizeof(before), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(after, tc, sizeof(after), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(tc, before, sizeof(before), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
     if (out_counters) {
         out_counters->rays = after[0], out_counters->nodes = after[1];
         out_counters->tris = after[2], out_counters->instances = after[3];
         out_counters->max_stack = after[4];
     }
-    HIP_TRY(hipMemcpy(pl[2].data(), c->ray_planes[0][2].p, size_t(count) * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(xd.data(), c->ray_planes[0][4].p, size_t(count) * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hp.data(), c->hit_planes[0].p, size_t(count) * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hv.data(), c->hit_planes[1].p, size_t(count) * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(pl[2].data(), c->ray_planes[0][2].p, size_t(count) * 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(xd.data(), c->ray_planes[0][4].p, size_t(count) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hp.data(), c->hit_planes[0].p, size_t(count) * 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(hv.data(), c->hit_planes[1].p, size_t(count) * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     for (int i = 0; i < count; ++i) {
         rays[i].c[0] = pl[2][i].x, rays[i].c[1] = pl[2][i].y, rays[i].c[2] = pl[2][i].z;
         rays[i].depth = xd[i].y;
@@ -903,14 +896,14 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
         pl[2][i] = make_float4(rays[i].c[0], rays[i].c[1], rays[i].c[2], xy_f);
     }
     for (int k = 0; k < 3; ++k) {
-        HIP_TRY(hipMemcpy(c->shadow_planes[k].p, pl[k].data(), size_t(count) * 16, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(c->shadow_planes[k].p, pl[k].data(), size_t(count) * 16, hipMemcpyHostToDevice, s));
     }
     const uint32_t n = uint32_t(count);
-    HIP_TRY(hipMemcpy(c->shadow_count(0), &n, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(c->shadow_count(0), &n, 4, hipMemcpyHostToDevice, s));
     unsigned long long *tc = c->trav_counters.as<unsigned long long>() + 5;
     unsigned long long before[5], after[5];
-    HIP_TRY(hipMemcpy(before, tc, sizeof(before), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(tc, 0, sizeof(before)));
+    HIP_TRY(hipMemcpyAsync(before, tc, sizeof(before), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(tc, 0, sizeof(before), s));
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     // results land in the (otherwise idle) hit plane
@@ -918,14 +911,16 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
                                                     c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipMemcpy(after, tc, sizeof(after), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(tc, before, sizeof(before), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(after, tc, sizeof(after), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(tc, before, sizeof(before), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
     if (out_counters) {
         out_counters->rays = after[0], out_counters->nodes = after[1];
         out_counters->tris = after[2], out_counters->instances = after[3];
         out_counters->max_stack = after[4];
     }
-    HIP_TRY(hipMemcpy(out_rc, c->hit_planes[0].p, size_t(count) * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(out_rc, c->hit_planes[0].p, size_t(count) * 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 
@@ -937,18 +932,20 @@ int rayhip_k_scrambled_rand(rayhip_ctx *c, const uint32_t *dims, const uint32_t 
     if (!c->pmj.p) {
         return fail("k_scrambled_rand needs the PMJ table");
     }
+    hipStream_t s = c->stream;
     DevBuf d, sd, sm, o;
     if (d.alloc(size_t(count) * 4) || sd.alloc(size_t(count) * 4) || sm.alloc(size_t(count) * 4) || o.alloc(size_t(count) * 8)) {
         return 1;
     }
-    HIP_TRY(hipMemcpy(d.p, dims, size_t(count) * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(sd.p, seeds, size_t(count) * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(sm.p, samples, size_t(count) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(d.p, dims, size_t(count) * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sd.p, seeds, size_t(count) * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(sm.p, samples, size_t(count) * 4, hipMemcpyHostToDevice, s));
     k_scrambled_rand<<<(count + 255) / 256, 256, 0, c->stream>>>(d.as<uint32_t>(), sd.as<uint32_t>(), sm.as<int32_t>(), count,
                                                                  c->sc.pmj, o.as<float2>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out_xy, o.p, size_t(count) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(out_xy, o.p, size_t(count) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     d.release(), sd.release(), sm.release(), o.release();
     return 0;
 }

@@ -17,7 +17,6 @@ BUF_FINAL, BUF_RAW, BUF_BASE_COLOR, BUF_DEPTH_NORMALS = 0, 1, 2, 3
 FLAG_SORT_RAYS = 1 << 0
 FLAG_COUNT_TRAVERSAL = 1 << 1
 FLAG_TIME_STAGES = 1 << 2
-FLAG_REFILL = 1 << 3
 
 
 class PassSettings(C.Structure):

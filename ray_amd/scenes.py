@@ -144,6 +144,68 @@ def cornell_principled(scene, **cam_overrides):
     scene.Finalize()
 
 
+def bump_normal_map(res: int = 64) -> np.ndarray:
+    """tangent-space normal map of a sine bump field, RGBA8 (x, y, z in 0..255; z reconstructed from x, y)"""
+    i, j = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
+    dx = 0.35 * np.cos(2 * math.pi * j / 16.0)
+    dy = 0.35 * np.cos(2 * math.pi * i / 16.0)
+    n = np.stack([-dx, -dy, np.ones_like(dx)], axis=-1)
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    img = np.empty((res, res, 4), dtype=np.uint8)
+    img[..., :3] = np.clip(np.rint((n * 0.5 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+    img[..., 3] = 255
+    return img
+
+
+def _translate(x, y, z, rot_x_deg=0.0, rot_z_deg=0.0):
+    """column-major 4x4 (the layout Ray's AddLight(xform) takes): R_z * R_x then translation"""
+    ax, az = math.radians(rot_x_deg), math.radians(rot_z_deg)
+    rx = np.array([[1, 0, 0], [0, math.cos(ax), -math.sin(ax)], [0, math.sin(ax), math.cos(ax)]])
+    rz = np.array([[math.cos(az), -math.sin(az), 0], [math.sin(az), math.cos(az), 0], [0, 0, 1]])
+    m = np.eye(4)
+    m[:3, :3] = rz @ rx
+    m[:3, 3] = (x, y, z)
+    return m.T.astype(np.float32).ravel()  # column-major
+
+
+def cornell_lights(scene, **cam_overrides):
+    """Cornell box lit by every analytic light type (all visible to secondary rays -> IntersectAreaLights, MIS) with a
+    zoo of shading nodes: Principled floor with textures, Oren-Nayar walls, normal-mapped glossy back wall, refractive
+    short block, Mix(diffuse, transparent) tall block.  Not a reference sample; built to cover SURVEY 8 a11-a14."""
+    scene.SetEnvironment(env_col=(0.02, 0.03, 0.05))
+    tex = scene.AddTexture(checkerboard(128, 16))
+    nmap = scene.AddTexture(bump_normal_map(64), is_srgb=False, is_normalmap=True)
+    floor_m = scene.AddMaterial(PrincipledMat(base_texture=tex, roughness=0.4, specular=0.5, clearcoat=0.5,
+                                              clearcoat_roughness=0.1, sheen=0.3))
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5), roughness=0.6))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.05, 0.05), roughness=0.3))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.05, 0.5, 0.05)))
+    back = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=(0.7, 0.7, 0.75), roughness=0.3,
+                                         normal_map=nmap, normal_map_intensity=0.8))
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=15.0, importance_sample=True))
+    glass = scene.AddMaterial(ShadingNode(type=eShadingNode.Refractive, base_color=(0.9, 0.95, 1.0), roughness=0.05, ior=1.45))
+    blue = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.1, 0.15, 0.6)))
+    clear = scene.AddMaterial(ShadingNode(type=eShadingNode.Transparent, base_color=(0.9, 0.9, 0.9)))
+    veil = scene.AddMaterial(ShadingNode(type=eShadingNode.Mix, mix_materials=(blue, clear), strength=0.5))
+    attrs, idx = cornell_mesh_arrays()
+    # floor | back wall | ceiling | left | right | light quad | short block (5 quads) | tall block (5 quads)
+    groups = [(floor_m, None, 0, 6), (back, None, 6, 6), (grey, None, 12, 6), (red, None, 19, 6), (green, None, 25, 6),
+              (emit, 0xFFFFFFFF, 31, 6), (glass, glass, 37, 30), (veil, veil, 67, 30)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+
+    scene.AddLight("sphere", color=(6.0, 5.0, 4.0), position=(-0.12, 0.42, -0.12), radius=0.025)
+    scene.AddLight("spot", color=(20.0, 20.0, 26.0), position=(-0.47, 0.50, -0.10), direction=(0.45, -0.85, -0.3),
+                   radius=0.015, spot_size=55.0, spot_blend=0.2)
+    scene.AddLight("rect", color=(8.0, 8.0, 7.0), width=0.16, height=0.10, xform=_translate(-0.30, 0.52, -0.44))
+    scene.AddLight("disk", color=(2.0, 7.0, 2.5), width=0.09, height=0.12, doublesided=True,
+                   xform=_translate(-0.545, 0.30, -0.30, rot_z_deg=-90.0))
+    scene.AddLight("line", color=(7.0, 2.0, 2.0), radius=0.006, height=0.25, xform=_translate(-0.02, 0.35, -0.30, rot_x_deg=90.0))
+    scene.AddLight("directional", color=(1.2, 1.1, 1.0), direction=(0.25, -0.45, -1.0), angle=4.0)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
 # ---- procedural atrium ("Sponza / Bistro class") ---------------------------------------------------------------
 def _grid(nu: int, nv: int, fn, flip=False):
     """Tessellated parametric patch.  fn(u, v) -> (P[...,3], N[...,3]); returns attrs [n,8], tri indices."""
@@ -307,4 +369,5 @@ def _unit(v):
 SCENES = {
     "cornell_basic": cornell_basic,
     "cornell_principled": cornell_principled,
+    "cornell_lights": cornell_lights,
 }

@@ -18,9 +18,9 @@
 #include <string>
 #include <vector>
 
+#include "../../ray_amd/csrc/rt_arealights.h"
 #include "../../ray_amd/csrc/rt_params.h"
 #include "../../ray_amd/csrc/rt_pixel.h"
-#include "../../ray_amd/csrc/rt_travmachine.h"
 #include "../../ray_amd/csrc/scene_blob.h"
 
 using namespace rt;
@@ -149,19 +149,9 @@ HS_API int hostsim_scene_upload_blob(hostsim_ctx *c, const void *blob, size_t si
     return 0;
 }
 
-// HOSTSIM_MACHINE=1 routes closest-hit tracing through the resumable state machine (rt_travmachine.h) instead of the
-// straight-line loops, so the two can be compared ray by ray on the CPU
-static bool use_machine() {
-    const char *e = getenv("HOSTSIM_MACHINE");
-    return e && e[0] == '1';
-}
 template <class Stack>
 static void trace_closest(const SceneView &sc, const TraceParams &tp, Ray &r, Hit &h, Stack &st, TravCount *cnt) {
-    if (use_machine()) {
-        intersect_scene_closest_machine(sc, tp, r, h, st, cnt);
-    } else {
-        intersect_scene_closest(sc, tp, r, h, st, cnt);
-    }
+    intersect_scene_closest(sc, tp, r, h, st, cnt);
 }
 
 static void add_counters(rayhip_trav_counters &dst, const TravCount &tc) {
@@ -216,6 +206,10 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
                 if (count) {
                     add_counters(c->counters[0], tc);
                 }
+                // K4 (TraceRays(..., trace_lights = true), CoreRef.cpp:4847-4849)
+                if (c->sc.visible_lights_count != 0) {
+                    intersect_area_lights(c->sc, rays[i].o, rays[i].d, rays[i].depth, hits[i]);
+                }
             }
         }
         // K5: shade
@@ -242,9 +236,12 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
         const float limit = shadow_clamp_limit(*cam, bounce);
         for (size_t i = 0; i < shadow.size(); ++i) {
             TravCount tc = {};
-            const f3 rc = intersect_scene_shadow(c->sc, tp, shadow[i], st, count ? &tc : nullptr);
+            f3 rc = intersect_scene_shadow(c->sc, tp, shadow[i], st, count ? &tc : nullptr);
             if (count) {
                 add_counters(c->counters[1], tc);
+            }
+            if (c->sc.blocker_lights_count != 0) { // CoreRef.cpp:4868-4870
+                rc *= intersect_area_lights_shadow(c->sc, shadow[i]);
             }
             add_shadow_pixel(rc, limit, shadow[i].xy, w, c->temp.data());
         }
@@ -344,7 +341,7 @@ HS_API int hostsim_k_generate_primary_rays(hostsim_ctx *c, const rayhip_camera *
 
 HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam, rayhip_ray *rays, rayhip_hit *hits,
                                        int count, int iteration, uint32_t flags, rayhip_trav_counters *out_counters) {
-    const bool machine = use_machine() || (flags & RAYHIP_FLAG_REFILL) != 0;
+    (void)flags;
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     ArrayStack st;
     rayhip_trav_counters acc = {};
@@ -352,11 +349,7 @@ HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam,
         Ray r = from_abi(rays[i]);
         Hit h = {hits[i].obj_index, hits[i].prim_index, hits[i].t, hits[i].u, hits[i].v};
         TravCount tc = {};
-        if (machine) {
-            intersect_scene_closest_machine(c->sc, tp, r, h, st, &tc); // what the refill kernel runs per ray
-        } else {
-            intersect_scene_closest(c->sc, tp, r, h, st, &tc);
-        }
+        intersect_scene_closest(c->sc, tp, r, h, st, &tc);
         add_counters(acc, tc);
         rays[i] = to_abi(r);
         hits[i] = rayhip_hit{h.obj_index, h.prim_index, h.t, h.u, h.v};

@@ -95,7 +95,7 @@ def run1(name, workload="sponza", K=16):
         ctx.trav_timing()
         ctx.stage_times()
         t0 = time.perf_counter()
-        rflags = (hip.FLAG_SORT_RAYS if "+sort" in VARIANTS[name] else 0) | (hip.FLAG_REFILL if "+refill" in VARIANTS[name] else 0)
+        rflags = (hip.FLAG_SORT_RAYS if "+sort" in VARIANTS[name] else 0)
         for it in range(3, 3 + K):
             ctx.render(it, flags=hip.FLAG_TIME_STAGES | rflags)
         ctx.sync()
