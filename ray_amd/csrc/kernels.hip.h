@@ -26,6 +26,25 @@
 
 #include <hip/hip_runtime.h>
 
+#ifdef RT_PROFILE_SHADE
+// Tuning build: wave-level time attribution inside k_shade.  Every marker charges the cycles since the previous
+// marker (hit by ANY lanes of this wave) to the section that ends there; because divergent paths of a wavefront
+// execute one after the other, the sections partition the wave's time exactly.
+namespace rt {
+__device__ unsigned long long g_prof_acc[32];
+__shared__ unsigned long long s_prof_last;
+__shared__ unsigned long long s_prof_acc[32];
+__device__ __forceinline__ void prof_mark(const int k) {
+    const unsigned long long mask = __ballot(1);
+    if (int(__lane_id()) == __ffsll((long long)mask) - 1) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        s_prof_acc[k] += t - s_prof_last;
+        s_prof_last = t;
+    }
+}
+} // namespace rt
+#define RT_PROF(k) ::rt::prof_mark(k);
+#endif
 #include "rt_arealights.h"
 #include "rt_params.h"
 #include "rt_pixel.h"
@@ -299,11 +318,20 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
                                                const HitSoA hits, const RayQueue in, const RaySoA rays_out,
                                                const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
                                                const PixelBuffers px, const int img_w, const float mix_factor) {
+#ifdef RT_PROFILE_SHADE
+    if (threadIdx.x < 32) {
+        s_prof_acc[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) {
+        s_prof_last = __builtin_readcyclecounter();
+    }
+#endif
     for (uint32_t c = blockIdx.x; c < in.total_chunks(); c += gridDim.x) {
         uint32_t stripe, slot0, n_live;
         if (!in.chunk(c, stripe, slot0, n_live)) {
             continue;
         }
+        RT_PROF(30)
         // whole wave stays in the body for the ballots
         const uint32_t i = slot0 + threadIdx.x;
         const bool active = threadIdx.x < n_live;
@@ -316,12 +344,14 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
             const Ray ray = load_ray(rays_in, i);
             const Hit inter = load_hit(hits, i);
             xy = ray.xy;
+            RT_PROF(0)
             res = shade_surface(sc, sp, inter, ray, new_ray, sh_r);
             if (PRIMARY) {
                 write_primary_pixel(res, xy, img_w, mix_factor, px.temp, px.base_color, px.depth_normals);
             } else {
                 add_secondary_pixel(res, xy, img_w, px.temp);
             }
+            RT_PROF(28)
         }
         // survivors go to the same stripe they came from (see RayQueue)
         const uint32_t ray_slot = out_rays.alloc(stripe, res.emit_secondary);
@@ -332,7 +362,14 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
         if (res.emit_shadow) {
             store_shadow(shadow_out, sh_slot, sh_r);
         }
+        RT_PROF(29)
     }
+#ifdef RT_PROFILE_SHADE
+    RT_PROF(31)
+    if (threadIdx.x < 32 && s_prof_acc[threadIdx.x] != 0) {
+        atomicAdd(&g_prof_acc[threadIdx.x], s_prof_acc[threadIdx.x]);
+    }
+#endif
 }
 
 // ---- K6 / K8: ray sort ----------------------------------------------------------------------------------------

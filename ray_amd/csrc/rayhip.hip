@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/rayhip.h"
+#include "bvh_layout.h"
 #include "kernels.hip.h"
 #include "scene_blob.h"
 #include "sort.h"
@@ -79,7 +80,7 @@ struct rayhip_ctx {
     DevBuf pmj, filter_table;
     // scene
     DevBuf nodes, tris, tri_indices, tri_materials, materials, vertices, vtx_indices, mesh_instances, lights, li_indices,
-        light_cwnodes, textures, texels;
+        light_cwnodes, light_children, textures, texels;
     SceneView sc = {};
     float bbox_min[3] = {}, bbox_max[3] = {};
     bool have_scene = false;
@@ -300,6 +301,12 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         per_cu = 8;
     }
     c->grid_waves = c->props.multiProcessorCount * per_cu;
+    if (const char *e = getenv("RAYHIP_GRID_MULT")) { // tuning: oversubscribe the persistent grid (dynamic balancing)
+        const int m = atoi(e);
+        if (m >= 1 && m <= 64) {
+            c->grid_waves *= m;
+        }
+    }
     if (c->stack_spill.alloc(size_t(c->grid_waves) * STACK_SPILL_DEPTH * WAVE * sizeof(uint32_t))) {
         delete c;
         return 1;
@@ -323,7 +330,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         (void)hipEventDestroy(e);
     }
     DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
-                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes,
+                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
                      &c->px_dn, &c->px_req, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
                      &c->shadow_planes[2], &c->counters, &c->trav_counters, &c->stack_spill,
@@ -416,17 +423,51 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
     if (upload(c, c->field, d->field, size_t(d->field##_count) * sizeof(*d->field))) {                                 \
         return 1;                                                                                                      \
     }
-    UP(nodes)
-    UP(tris)
-    UP(tri_indices)
+    // HBM layout pass (bvh_layout.h): depth-first node order with sibling pairs in one 128-byte line, triangles in
+    // leaf-visit order.  RAYHIP_NO_LAYOUT=1 keeps the reference builder's order (A/B measurements).
+    rayhip_layout::Result lay;
+    {
+        const char *e = getenv("RAYHIP_NO_LAYOUT");
+        if (!(e && e[0] == '1')) {
+            lay = rayhip_layout::optimize(*d);
+        }
+    }
+    uint32_t tlas_root = d->tlas_root;
+    if (lay.applied) {
+        tlas_root = lay.tlas_root;
+        if (upload(c, c->nodes, lay.nodes.data(), lay.nodes.size() * sizeof(rayhip_bvh2_node)) ||
+            upload(c, c->tris, lay.tris.data(), lay.tris.size() * sizeof(rayhip_tri_accel)) ||
+            upload(c, c->tri_indices, lay.tri_indices.data(), lay.tri_indices.size() * sizeof(uint32_t)) ||
+            upload(c, c->mesh_instances, lay.mesh_instances.data(), lay.mesh_instances.size() * sizeof(rayhip_mesh_instance))) {
+            return 1;
+        }
+    } else {
+        UP(nodes)
+        UP(tris)
+        UP(tri_indices)
+        UP(mesh_instances)
+    }
     UP(tri_materials)
     UP(materials)
     UP(vertices)
     UP(vtx_indices)
-    UP(mesh_instances)
     UP(lights)
     UP(li_indices)
     UP(light_cwnodes)
+    { // node-only half of the light-tree importance, evaluated once per scene (rt_lights.h: decode_lnode_child)
+        std::vector<float4> lc(size_t(d->light_cwnodes_count) * 24);
+        for (uint32_t n = 0; n < d->light_cwnodes_count; ++n) {
+            for (int i = 0; i < 8; ++i) {
+                const LNodeChild ch = decode_lnode_child(d->light_cwnodes[n], i);
+                float4 *o = &lc[(size_t(n) * 8 + size_t(i)) * 3];
+                o[0] = ch.axis_extent, o[1] = ch.pc_valid, o[2] = ch.cosines;
+            }
+        }
+        if (upload(c, c->light_children, lc.data(), lc.size() * sizeof(float4))) {
+            return 1;
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream)); // `lc` goes out of scope
+    }
     UP(textures)
     UP(texels)
 #undef UP
@@ -437,6 +478,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
     v.materials = c->materials.as<rayhip_material>(), v.vertices = c->vertices.as<rayhip_vertex>();
     v.vtx_indices = c->vtx_indices.as<uint32_t>(), v.mesh_instances = c->mesh_instances.as<rayhip_mesh_instance>();
     v.lights = c->lights.as<rayhip_light>(), v.li_indices = c->li_indices.as<uint32_t>();
+    v.light_children = c->light_children.as<float4>();
     v.light_cwnodes = c->light_cwnodes.as<rayhip_light_cwbvh_node>(), v.textures = c->textures.as<rayhip_texture>();
     v.texels = c->texels.as<uint32_t>();
     memcpy(v.tex_table, d->tex_table, sizeof(v.tex_table));
@@ -444,7 +486,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
     v.light_cwnodes_count = d->light_cwnodes_count;
     v.visible_lights_count = d->visible_lights_count;
     v.blocker_lights_count = d->blocker_lights_count;
-    v.tlas_root = d->tlas_root;
+    v.tlas_root = tlas_root;
     v.env = d->env;
     memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
     { // ray-sort grid: true bounds of the TLAS root (Scene::GetBounds takes fminf for the max corner, SceneCPU.cpp:1553)
@@ -949,5 +991,21 @@ int rayhip_k_scrambled_rand(rayhip_ctx *c, const uint32_t *dims, const uint32_t 
     d.release(), sd.release(), sm.release(), o.release();
     return 0;
 }
+
+#ifdef RT_PROFILE_SHADE
+// tuning build only (tools/variants.py): cycles per shade-kernel section, see RT_PROF in kernels.hip.h
+__attribute__((visibility("default"))) int rayhip_tuning_read_profile(rayhip_ctx *c, unsigned long long out[32], int reset) {
+    if (use_device(c)) {
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_prof_acc), 32 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[32] = {};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_prof_acc), z, sizeof(z)));
+    }
+    return 0;
+}
+#endif
 
 } // extern "C"

@@ -223,7 +223,7 @@ RT_HD void intersect_area_lights(const SceneView &sc, const f3 ro, const f3 rd, 
                 break;
             }
             float factors[8];
-            calc_lnode_importance(n, ro, factors);
+            calc_lnode_importance(sc, cur.index, ro, factors);
             const float total_importance = total_importance8(factors);
             if (total_importance == 0.0f) {
                 reached_leaf = false;

@@ -16,6 +16,11 @@
 // Build with -ffp-contract=off for bit-parity with the reference; see DESIGN.md "Numerics".
 #pragma once
 
+// RT_PROF(k): section marker of the shade-kernel profile build (tools/variants.py, -DRT_PROFILE_SHADE); nothing otherwise
+#ifndef RT_PROF
+#define RT_PROF(k)
+#endif
+
 #include <stdint.h>
 
 #if defined(__HIPCC__)

@@ -250,12 +250,28 @@ RT_HD float sin_sub_clamped(float sin_a, float cos_a, float sin_b, float cos_b) 
     return (cos_a > cos_b) ? 0.0f : (sin_a * cos_b - cos_a * sin_b);
 }
 
-// importance of child i of node n as seen from P.  CoreRef.cpp:1004-1066, one SSE lane.
-RT_HD float lnode_child_importance(const rayhip_light_cwbvh_node &n, const int i, const f3 P) {
+// calc_lnode_importance (CoreRef.cpp:1004-1066) is split in two:
+//   * decode_lnode_child: everything that depends on the node only (box un-quantisation, decode_oct_dir :935-947,
+//     decode_cosines :949-956, box centre / half-diagonal) -- about half of the arithmetic, 8 divisions and 3 square
+//     roots per child.  It is evaluated ONCE per scene into the `light_children` table (three float4 per child) when
+//     the scene is uploaded, by this very function compiled for the host (same IEEE operations, so the same bits the
+//     device would produce), instead of 8 x depth times per shade point;
+//   * lnode_child_importance: the part that depends on the shade point P.
+// Measured before the split: light-tree work was 56 % of the shade kernel's time (41 % NEE + 15 % emissive-hit MIS).
+struct LNodeChild {
+    float4 axis_extent; // decoded cone axis, half-diagonal of the child box
+    float4 pc_valid;    // box centre, 1 if the slot has a finite box (else importance = flux)
+    float4 cosines;     // cos_omega_n, sin_omega_n, cos_omega_e, flux
+};
+
+RT_HD LNodeChild decode_lnode_child(const rayhip_light_cwbvh_node &n, const int i) {
     float bmin[3], bmax[3];
     cw_child_bounds(n, i, bmin, bmax);
 
-    float imp = n.flux[i];
+    LNodeChild o;
+    o.axis_extent = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+    o.pc_valid = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+    o.cosines = mkfloat4(0.0f, 0.0f, 0.0f, n.flux[i]);
     if (bmin[0] > -MAX_DIST) {
         // decode_oct_dir, CoreRef.cpp:935-947
         const uint32_t oct = n.axis[i];
@@ -271,12 +287,28 @@ RT_HD float lnode_child_importance(const rayhip_light_cwbvh_node &n, const int i
             const float l = sqrtf(ax * ax + ay * ay + az * az);
             ax = ax / l, ay = ay / l, az = az / l;
         }
-
         const float ext[3] = {bmax[0] - bmin[0], bmax[1] - bmin[1], bmax[2] - bmin[2]};
         const float extent = 0.5f * sqrtf(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
 
-        const float pc[3] = {0.5f * (bmin[0] + bmax[0]), 0.5f * (bmin[1] + bmax[1]), 0.5f * (bmin[2] + bmax[2])};
-        float wi[3] = {P.x - pc[0], P.y - pc[1], P.z - pc[2]};
+        // decode_cosines, CoreRef.cpp:949-956
+        const uint32_t cv = n.cos_omega_ne[i];
+        const float cos_omega_n = 2.0f * (float((cv >> 16) & 0x0000ffff) / 65534.0f) - 1.0f;
+        const float cos_omega_e = 2.0f * (float(cv & 0x0000ffff) / 65534.0f) - 1.0f;
+        const float sin_omega_n = sqrtf(1.0f - cos_omega_n * cos_omega_n);
+
+        o.axis_extent = mkfloat4(ax, ay, az, extent);
+        o.pc_valid = mkfloat4(0.5f * (bmin[0] + bmax[0]), 0.5f * (bmin[1] + bmax[1]), 0.5f * (bmin[2] + bmax[2]), 1.0f);
+        o.cosines = mkfloat4(cos_omega_n, sin_omega_n, cos_omega_e, n.flux[i]);
+    }
+    return o;
+}
+
+// importance of one child as seen from P
+RT_HD float lnode_child_importance(const LNodeChild &ch, const f3 P) {
+    float imp = ch.cosines.w;
+    if (ch.pc_valid.w != 0.0f) {
+        const float ax = ch.axis_extent.x, ay = ch.axis_extent.y, az = ch.axis_extent.z, extent = ch.axis_extent.w;
+        float wi[3] = {P.x - ch.pc_valid.x, P.y - ch.pc_valid.y, P.z - ch.pc_valid.z};
         const float dist2 = wi[0] * wi[0] + wi[1] * wi[1] + wi[2] * wi[2];
         const float dist = sqrtf(dist2);
         wi[0] /= dist, wi[1] /= dist, wi[2] /= dist;
@@ -292,11 +324,7 @@ RT_HD float lnode_child_importance(const rayhip_light_cwbvh_node &n, const int i
         }
         const float sin_omega_b = sqrtf(1.0f - cos_omega_b * cos_omega_b);
 
-        // decode_cosines, CoreRef.cpp:949-956
-        const uint32_t cv = n.cos_omega_ne[i];
-        const float cos_omega_n = 2.0f * (float((cv >> 16) & 0x0000ffff) / 65534.0f) - 1.0f;
-        const float cos_omega_e = 2.0f * (float(cv & 0x0000ffff) / 65534.0f) - 1.0f;
-        const float sin_omega_n = sqrtf(1.0f - cos_omega_n * cos_omega_n);
+        const float cos_omega_n = ch.cosines.x, sin_omega_n = ch.cosines.y, cos_omega_e = ch.cosines.z;
 
         const float cos_omega_x = cos_sub_clamped(sin_omega_w, cos_omega_w, sin_omega_n, cos_omega_n);
         const float sin_omega_x = sin_sub_clamped(sin_omega_w, cos_omega_w, sin_omega_n, cos_omega_n);
@@ -311,9 +339,13 @@ RT_HD float lnode_child_importance(const rayhip_light_cwbvh_node &n, const int i
     return imp;
 }
 
-RT_HD void calc_lnode_importance(const rayhip_light_cwbvh_node &n, const f3 P, float importance[8]) {
+// importance of the eight children of light-tree node `node_index` (through the table decode_lnode_child filled)
+RT_HD void calc_lnode_importance(const SceneView &sc, const uint32_t node_index, const f3 P, float importance[8]) {
+    const float4 *t = sc.light_children + size_t(node_index) * 24;
     for (int i = 0; i < 8; ++i) {
-        importance[i] = lnode_child_importance(n, i, P);
+        LNodeChild ch;
+        ch.axis_extent = t[3 * i + 0], ch.pc_valid = t[3 * i + 1], ch.cosines = t[3 * i + 2];
+        importance[i] = lnode_child_importance(ch, P);
     }
 }
 // hsum(fvec4{imp[0..3]} + fvec4{imp[4..7]}), SSE2 hsum order
@@ -365,7 +397,7 @@ RT_HD void sample_light_source(const SceneView &sc, const f3 P, const f3 T, cons
         while ((i & LEAF_NODE_BIT) == 0) {
             const rayhip_light_cwbvh_node &node = sc.light_cwnodes[i];
             float importance[8];
-            calc_lnode_importance(node, P, importance);
+            calc_lnode_importance(sc, i, P, importance);
 
             const float total_importance = total_importance8(importance);
             if (total_importance == 0.0f) {
@@ -400,6 +432,7 @@ RT_HD void sample_light_source(const SceneView &sc, const f3 P, const f3 T, cons
         light_index = (i & PRIM_INDEX_BITS);
         factor = 1.0f / factor;
     }
+    RT_PROF(15)
     const rayhip_light &l = sc.lights[light_index];
     const uint32_t ltype = light_type(l);
 
@@ -703,7 +736,7 @@ RT_HD float eval_tri_light_factor(const SceneView &sc, const f3 P, const f3 ro, 
             uint32_t mask = cw_point_mask(node, P);
             if (mask) {
                 float importance[8];
-                calc_lnode_importance(node, ro, importance);
+                calc_lnode_importance(sc, cur, ro, importance);
 
                 const float total_importance = total_importance8(importance);
                 if (total_importance == 0.0f) {

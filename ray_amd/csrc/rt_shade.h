@@ -183,6 +183,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
             env_col *= (sp.limits[0] / sum);
         }
         res.col = env_col;
+        RT_PROF(1)
         return res;
     }
 
@@ -197,6 +198,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
             lcol *= (sp.limits[0] / sum);
         }
         res.col = mk4(lcol, 1.0f);
+        RT_PROF(2)
         return res;
     }
 
@@ -253,6 +255,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
     lambda += fast_log2(cone_width);
 
     const float ext_ior = peek_ior_stack(ray.ior, is_backfacing);
+    RT_PROF(3)
 
     f3 col = {0.0f, 0.0f, 0.0f};
 
@@ -324,6 +327,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
 
     surf.B = safe_normalize(cross(tangent, surf.N));
     surf.T = cross(surf.N, surf.B);
+    RT_PROF(4)
 
     LightSample ls = make_light_sample();
     if (sc.light_cwnodes_count != 0 && mat->type != NODE_EMISSIVE) {
@@ -332,6 +336,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
 
         sample_light_source(sc, surf.P, surf.T, surf.B, surf.N, rand_pick_light, rand_light_uv, tex_rand, ls);
     }
+    RT_PROF(5)
     const float N_dot_L = dot(surf.N, ls.L);
 
     // sample base texture
@@ -384,6 +389,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
     sh_r.dist = 0.0f;
 
     const float regularize_alpha = (get_diff_depth(ray.depth) > 0) ? ps.regularize_alpha : 0.0f;
+    RT_PROF(6)
 
     // Sample materials
     if (mat->type == NODE_DIFFUSE) {
@@ -393,6 +399,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
         if (diff_depth < ps.max_diff_depth && total_depth < ps.max_total_depth) {
             Sample_DiffuseNode(ray, surf, base_color, roughness, rand_bsdf, mix_weight, new_ray);
         }
+        RT_PROF(7)
     } else if (mat->type == NODE_GLOSSY) {
         const float specular = 0.5f;
         const float spec_ior = (2.0f / (1.0f - sqrtf(0.08f * specular))) - 1.0f;
@@ -405,6 +412,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
             Sample_GlossyNode(ray, surf, base_color, roughness, regularize_alpha, spec_ior, spec_F0, rand_bsdf, mix_weight,
                               new_ray);
         }
+        RT_PROF(8)
     } else if (mat->type == NODE_REFRACTIVE) {
         if (ls.pdf > 0.0f && (ls.ray_flags & RAY_TYPE_REFR_BIT) != 0 && N_dot_L < 0.0f) {
             const float eta = is_backfacing ? (mat->ior / ext_ior) : (ext_ior / mat->ior);
@@ -415,6 +423,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
             Sample_RefractiveNode(ray, surf, base_color, roughness, regularize_alpha, is_backfacing, mat->ior, ext_ior,
                                   rand_bsdf, mix_weight, new_ray);
         }
+        RT_PROF(9)
     } else if (mat->type == NODE_EMISSIVE) {
         float mis_weight = 1.0f;
         if ((ray.depth & 0x00ffffff) != 0 && (mat->flags & MAT_FLAG_IMP_SAMPLE)) {
@@ -439,6 +448,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
             }
         }
         col += mix_weight * mis_weight * mat->tangent_rotation_or_strength * base_color;
+        RT_PROF(10)
     } else if (mat->type == NODE_PRINCIPLED) {
         float metallic = float(mat->metallic_unorm) / 65535.0f;
         if (mat->textures[METALLIC_TEXTURE] != 0xffffffff) {
@@ -498,13 +508,16 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
 
         const LobeWeights lobe_weights =
             get_lobe_weights(mixf(base_color_lum, 1.0f, sheen), spec_color_lum, specular, metallic, transmission, clearcoat);
+        RT_PROF(11)
 
         if (ls.pdf > 0.0f) {
             col += Evaluate_PrincipledNode(ls, ray, surf, lobe_weights, diff, spec, coat, trans, metallic, transmission,
                                            N_dot_L, mix_weight, (total_depth < ps.max_total_depth), regularize_alpha, sh_r);
         }
+        RT_PROF(12)
         Sample_PrincipledNode(ps, ray, surf, lobe_weights, diff, spec, coat, trans, metallic, transmission, rand_bsdf,
                               mix_rand, mix_weight, regularize_alpha, new_ray);
+        RT_PROF(13)
     }
 
     const bool can_terminate_path = total_depth > ps.min_total_depth;
@@ -542,6 +555,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
         col *= (sp.limits[1] / sum);
     }
     res.col = mk4(col, 1.0f);
+    RT_PROF(14)
     return res;
 }
 

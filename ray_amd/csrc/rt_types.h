@@ -29,6 +29,7 @@ struct SceneView {
     const rayhip_light *lights;
     const uint32_t *li_indices;
     const rayhip_light_cwbvh_node *light_cwnodes;
+    const float4 *light_children; // 24 float4 per light-tree node: decode_lnode_child of its 8 children (rt_lights.h)
     const rayhip_texture *textures;
     const uint32_t *texels;
     const uint32_t *pmj; // 32 dims x 4096 samples x 2 (u32), reference Core.h:363-368

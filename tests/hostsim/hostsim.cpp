@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "../../ray_amd/csrc/bvh_layout.h"
 #include "../../ray_amd/csrc/rt_arealights.h"
 #include "../../ray_amd/csrc/rt_params.h"
 #include "../../ray_amd/csrc/rt_pixel.h"
@@ -40,6 +41,7 @@ struct HostScene {
     std::vector<rayhip_light> lights;
     std::vector<uint32_t> li_indices;
     std::vector<rayhip_light_cwbvh_node> light_cwnodes;
+    std::vector<float4> light_children;
     std::vector<rayhip_texture> textures;
     std::vector<uint32_t> texels;
 };
@@ -56,7 +58,11 @@ struct hostsim_ctx {
     std::vector<uint16_t> required_samples;
     rayhip_trav_counters counters[2] = {};
     Shard shard = {64, 1, 0};
+    bool layout_applied = false;
 };
+
+// test hook: did the last scene upload go through the HBM layout pass?
+extern "C" __attribute__((visibility("default"))) int hostsim_layout_applied(hostsim_ctx *c);
 
 #define HS_API extern "C" __attribute__((visibility("default")))
 
@@ -68,6 +74,7 @@ HS_API int hostsim_ctx_create(int, hostsim_ctx **out) {
     return 0;
 }
 HS_API void hostsim_ctx_destroy(hostsim_ctx *c) { delete c; }
+int hostsim_layout_applied(hostsim_ctx *c) { return c->layout_applied ? 1 : 0; }
 HS_API int hostsim_ctx_device_name(hostsim_ctx *, char *buf, int cap) {
     snprintf(buf, size_t(cap), "hostsim (CPU, test only)");
     return 0;
@@ -109,13 +116,39 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d) {
     CP(lights);
     CP(li_indices);
     CP(light_cwnodes);
+    s.light_children.resize(size_t(d->light_cwnodes_count) * 24);
+    for (uint32_t n = 0; n < d->light_cwnodes_count; ++n) {
+        for (int i = 0; i < 8; ++i) {
+            const LNodeChild ch = decode_lnode_child(d->light_cwnodes[n], i);
+            float4 *o = &s.light_children[(size_t(n) * 8 + size_t(i)) * 3];
+            o[0] = ch.axis_extent, o[1] = ch.pc_valid, o[2] = ch.cosines;
+        }
+    }
     CP(textures);
     CP(texels);
 #undef CP
+    // the same HBM layout pass librayhip applies at upload (results must not depend on it); HOSTSIM_NO_LAYOUT=1 skips
+    uint32_t tlas_root = d->tlas_root;
+    {
+        const char *e = getenv("HOSTSIM_NO_LAYOUT");
+        if (!(e && e[0] == '1')) {
+            rayhip_layout::Result lay = rayhip_layout::optimize(*d);
+            if (lay.applied) {
+                s.nodes.swap(lay.nodes), s.tris.swap(lay.tris), s.tri_indices.swap(lay.tri_indices);
+                s.mesh_instances.swap(lay.mesh_instances);
+                tlas_root = lay.tlas_root;
+            }
+            c->layout_applied = lay.applied;
+            if (!lay.applied && getenv("HOSTSIM_VERBOSE")) {
+                fprintf(stderr, "hostsim: layout pass skipped: %s\n", lay.why_not);
+            }
+        }
+    }
     SceneView &v = c->sc;
     v.nodes = s.nodes.data(), v.tris = s.tris.data(), v.tri_indices = s.tri_indices.data();
     v.tri_materials = s.tri_materials.data(), v.materials = s.materials.data(), v.vertices = s.vertices.data();
     v.vtx_indices = s.vtx_indices.data(), v.mesh_instances = s.mesh_instances.data(), v.lights = s.lights.data();
+    v.light_children = s.light_children.data();
     v.li_indices = s.li_indices.data(), v.light_cwnodes = s.light_cwnodes.data(), v.textures = s.textures.data();
     v.texels = s.texels.data();
     memcpy(v.tex_table, d->tex_table, sizeof(v.tex_table));
@@ -123,7 +156,7 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d) {
     v.light_cwnodes_count = d->light_cwnodes_count;
     v.visible_lights_count = d->visible_lights_count;
     v.blocker_lights_count = d->blocker_lights_count;
-    v.tlas_root = d->tlas_root;
+    v.tlas_root = tlas_root;
     v.env = d->env;
     memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
     return 0;

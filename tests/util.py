@@ -60,3 +60,18 @@ def render_frames(ctx: hip.Context, spp: int, flags: int = 0) -> np.ndarray:
 
 def sort_by_xy(arr: np.ndarray) -> np.ndarray:
     return arr[np.argsort(arr["xy"], kind="stable")]
+
+
+def assert_hits_identical(got: np.ndarray, ref: np.ndarray):
+    """Bit-for-bit equality of hit records in every field that carries information.
+
+    For a ray that ends as a miss (v < 0) the reference leaves `prim_index = tri_indices[<stale index>]` behind
+    (the index indirection runs on misses too, CoreRef.cpp:2017-2022) -- a value that depends on the ORDER of the
+    triangle array, which librayhip permutes for locality (bvh_layout.h).  Nothing reads it (ShadeSurface tests v first),
+    so it is compared only for real hits; t, u, v and obj_index are compared for every ray.
+    """
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), f
+    assert np.array_equal(got["obj_index"], ref["obj_index"])
+    hit = ref["v"] >= 0
+    assert np.array_equal(got["prim_index"][hit], ref["prim_index"][hit])

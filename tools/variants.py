@@ -113,6 +113,25 @@ def run1(name, workload="sponza", K=16):
               f"shade {(st['primary_shade'] + st['secondary_shade']) / K / 1e3:5.2f} ms gen {st['primary_ray_gen'] / K / 1e3:4.2f} sort {st['secondary_sort'] / K / 1e3:4.2f} | "
               f"vs first: max|d| {d.max():.2e} frac>1e-3 {(d.max(axis=-1) > 1e-3).mean():.2e} | max_stack {c2['max_stack']}/{c3['max_stack']}",
               flush=True)
+        if hasattr(L.lib, "rayhip_tuning_read_profile"):
+            import ctypes
+            f = L.lib.rayhip_tuning_read_profile
+            f.argtypes, f.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong * 32), ctypes.c_int], ctypes.c_int
+            buf = (ctypes.c_ulonglong * 32)()
+            f(ctx._ctx, ctypes.byref(buf), 1)
+            for it in range(100, 100 + K):
+                ctx.render(it)
+            f(ctx._ctx, ctypes.byref(buf), 1)
+            names = {0: "load ray+hit", 1: "miss/env", 2: "light hit", 3: "surface setup (verts, TBN, lod)", 4: "mix + normal map + tangent",
+                     5: "NEE: per-type light sample", 15: "NEE: light-tree descent", 6: "textures + ray init", 7: "diffuse eval+sample", 8: "glossy eval+sample",
+                     9: "refractive eval+sample", 10: "emissive", 11: "principled setup", 12: "principled eval",
+                     13: "principled sample", 14: "tail (RR, shadow ray)", 28: "pixel write", 29: "compaction + stores",
+                     30: "chunk fetch / loop", 31: "exit"}
+            tot = float(sum(buf)) or 1.0
+            print("  shade-kernel wave time by section:")
+            for k in range(32):
+                if buf[k]:
+                    print(f"    {k:2d} {names.get(k, '?'):34s} {100.0 * buf[k] / tot:5.1f} %")
         ctx.close()
 
 
