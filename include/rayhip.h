@@ -357,7 +357,7 @@ RAYHIP_API int rayhip_k_generate_primary_rays(rayhip_ctx *ctx, const rayhip_came
                                               int *out_count);
 /* Ref::IntersectScene closest hit (CoreRef.cpp:3041-3158): rays/hits are in-out host arrays */
 RAYHIP_API int rayhip_k_intersect_closest(rayhip_ctx *ctx, const rayhip_camera *cam, rayhip_ray *rays,
-                                          rayhip_hit *hits, int count, int iteration, uint32_t flags /* reserved, 0 */,
+                                          rayhip_hit *hits, int count, int iteration, uint32_t flags /* COUNT_TRAVERSAL: instrumented BVH2 kernel + counters; 0: the kernel rayhip_render uses */,
                                           rayhip_trav_counters *out_counters /* may be NULL */);
 /* Ref::IntersectScene(shadow_ray_t) (CoreRef.cpp:3160-3262): out_rc[count][4] visibility * colour */
 RAYHIP_API int rayhip_k_intersect_shadow(rayhip_ctx *ctx, const rayhip_camera *cam,

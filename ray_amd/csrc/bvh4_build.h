@@ -1,0 +1,223 @@
+// bvh4_build.h -- host-side collapse of the reference's BVH2 BLAS trees into the 4-wide quantised form of rt_bvh4.h.
+// Runs once per scene upload (rayhip.hip) and in the host build of the kernels (tests/hostsim).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "rt_bvh4.h"
+
+namespace rayhip_bvh4 {
+
+struct Box {
+    float lo[3], hi[3];
+};
+struct Slot {
+    Box box;
+    uint32_t ref; // BVH2 child word: inner node index or leaf word
+};
+
+inline bool is_leaf(uint32_t w) { return (w & rt::BVH2_PRIM_COUNT_BITS) != 0; }
+
+// the two child boxes stored in a bvh2 node (reference layout, Core.h:72-80: ch_data0 = child 0 {xmin,xmax,ymin,ymax},
+// ch_data1 = child 1, ch_data2 = {z0min,z0max,z1min,z1max})
+inline void children_of(const rayhip_bvh2_node &n, Slot out[2]) {
+    out[0].box = Box{{n.ch_data0[0], n.ch_data0[2], n.ch_data2[0]}, {n.ch_data0[1], n.ch_data0[3], n.ch_data2[1]}};
+    out[1].box = Box{{n.ch_data1[0], n.ch_data1[2], n.ch_data2[2]}, {n.ch_data1[1], n.ch_data1[3], n.ch_data2[3]}};
+    out[0].ref = n.left_child, out[1].ref = n.right_child;
+}
+
+inline float half_area(const Box &b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Quantise `n_slots` child boxes onto the node grid.  Returns false if a box cannot be represented conservatively
+// (non-finite coordinates): the caller then keeps the BVH2 for the whole scene.
+inline bool quantise(const Slot *slots, const int n_slots, rt::Bvh4Node &out) {
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = slots[0].box.lo[a], hi[a] = slots[0].box.hi[a];
+        for (int c = 1; c < n_slots; ++c) {
+            lo[a] = std::fmin(lo[a], slots[c].box.lo[a]);
+            hi[a] = std::fmax(hi[a], slots[c].box.hi[a]);
+        }
+        if (!std::isfinite(lo[a]) || !std::isfinite(hi[a]) || hi[a] < lo[a]) {
+            return false;
+        }
+    }
+    memset(&out, 0, sizeof(out));
+    uint32_t exps = 0;
+    float scale[3];
+    for (int a = 0; a < 3; ++a) {
+        out.org[a] = lo[a];
+        // smallest power of two s with org + 255 * s >= hi, evaluated with the device's de-quantisation
+        int e = 1;
+        const float need = (hi[a] - lo[a]) / 255.0f;
+        if (need > 0.0f) {
+            int ex;
+            std::frexp(need, &ex); // need = m * 2^ex, m in [0.5, 1)
+            e = ex + 127;          // 2^ex >= need
+            if (e < 1) {
+                e = 1;
+            }
+        }
+        while (e < 254 && rt::bvh4_dequant(255u, rt::uint_as_float(uint32_t(e) << 23), lo[a]) < hi[a]) {
+            ++e;
+        }
+        if (e >= 254) {
+            return false;
+        }
+        scale[a] = rt::uint_as_float(uint32_t(e) << 23);
+        exps |= uint32_t(e) << (8 * a);
+    }
+    out.exps = exps;
+    for (int c = 0; c < 4; ++c) {
+        out.child[c] = rt::BVH4_EMPTY;
+    }
+    for (int c = 0; c < n_slots; ++c) {
+        for (int a = 0; a < 3; ++a) {
+            const float flo = std::floor((slots[c].box.lo[a] - lo[a]) / scale[a]);
+            const float fhi = std::ceil((slots[c].box.hi[a] - lo[a]) / scale[a]);
+            int qlo = int(std::fmin(std::fmax(flo, 0.0f), 255.0f)), qhi = int(std::fmin(std::fmax(fhi, 0.0f), 255.0f));
+            // make it hold for the value the device computes
+            while (qlo > 0 && rt::bvh4_dequant(uint32_t(qlo), scale[a], lo[a]) > slots[c].box.lo[a]) {
+                --qlo;
+            }
+            while (qhi < 255 && rt::bvh4_dequant(uint32_t(qhi), scale[a], lo[a]) < slots[c].box.hi[a]) {
+                ++qhi;
+            }
+            if (rt::bvh4_dequant(uint32_t(qlo), scale[a], lo[a]) > slots[c].box.lo[a] ||
+                rt::bvh4_dequant(uint32_t(qhi), scale[a], lo[a]) < slots[c].box.hi[a]) {
+                return false;
+            }
+            out.qlo[a] |= uint32_t(qlo) << (8 * c);
+            out.qhi[a] |= uint32_t(qhi) << (8 * c);
+        }
+    }
+    return true;
+}
+
+struct Result {
+    std::vector<rt::Bvh4Node> nodes;
+    std::vector<uint32_t> blas_root4; // per mesh instance: root of its 4-wide BLAS (0xffffffff: not referenced)
+    bool ok = false;
+};
+
+// nodes / mesh instances as they will be uploaded (i.e. after bvh_layout).  Only instances referenced by TLAS leaves
+// are followed (the instance array is a sparse pool).
+inline Result build(const rayhip_bvh2_node *nodes, const uint32_t n_nodes, const rayhip_mesh_instance *mis, const uint32_t n_mis,
+                    const uint32_t tlas_root) {
+    Result out;
+    out.blas_root4.assign(n_mis, 0xffffffffu);
+    if (tlas_root == 0xffffffffu || tlas_root >= n_nodes) {
+        return out;
+    }
+    // instances referenced by the TLAS
+    std::vector<uint32_t> inst;
+    {
+        std::vector<uint32_t> stack = {tlas_root};
+        size_t visited = 0;
+        while (!stack.empty()) {
+            const uint32_t n = stack.back();
+            stack.pop_back();
+            if (n >= n_nodes || ++visited > n_nodes) {
+                return out;
+            }
+            const uint32_t ch[2] = {nodes[n].left_child, nodes[n].right_child};
+            for (int k = 0; k < 2; ++k) {
+                if (is_leaf(ch[k])) {
+                    const uint32_t mi = ch[k] & rt::BVH2_PRIM_INDEX_BITS;
+                    if (mi >= n_mis) {
+                        return out;
+                    }
+                    inst.push_back(mi);
+                } else {
+                    stack.push_back(ch[k]);
+                }
+            }
+        }
+    }
+    std::vector<uint32_t> root4_of_bvh2(n_nodes, 0xffffffffu); // shared BLAS: build once
+    struct Work {
+        uint32_t bvh2_node, out_index;
+    };
+    for (const uint32_t mi : inst) {
+        const uint32_t root2 = mis[mi].node_index;
+        if (root2 >= n_nodes) {
+            return out;
+        }
+        if (root4_of_bvh2[root2] != 0xffffffffu) {
+            out.blas_root4[mi] = root4_of_bvh2[root2];
+            continue;
+        }
+        const uint32_t root4 = uint32_t(out.nodes.size());
+        out.nodes.emplace_back();
+        std::vector<Work> stack = {Work{root2, root4}};
+        size_t made = 0;
+        while (!stack.empty()) {
+            const Work w = stack.back();
+            stack.pop_back();
+            if (++made > size_t(n_nodes) + 1) {
+                return out; // not a tree
+            }
+            Slot slots[4];
+            children_of(nodes[w.bvh2_node], slots);
+            int n_slots = 2;
+            while (n_slots < 4) {
+                int best = -1;
+                float best_area = -1.0f;
+                for (int c = 0; c < n_slots; ++c) {
+                    if (!is_leaf(slots[c].ref) && half_area(slots[c].box) > best_area) {
+                        best_area = half_area(slots[c].box), best = c;
+                    }
+                }
+                if (best < 0) {
+                    break;
+                }
+                if (slots[best].ref >= n_nodes) {
+                    return out;
+                }
+                Slot two[2];
+                children_of(nodes[slots[best].ref], two);
+                slots[best] = two[0];
+                slots[n_slots++] = two[1];
+            }
+            rt::Bvh4Node node;
+            if (!quantise(slots, n_slots, node)) {
+                return out;
+            }
+            // inner children get consecutive indices (one or two 128-byte lines), laid out before their subtrees
+            const uint32_t first_child = uint32_t(out.nodes.size());
+            uint32_t n_inner = 0;
+            for (int c = 0; c < n_slots; ++c) {
+                if (is_leaf(slots[c].ref)) {
+                    node.child[c] = slots[c].ref;
+                } else {
+                    if (slots[c].ref >= n_nodes) {
+                        return out;
+                    }
+                    node.child[c] = first_child + n_inner++;
+                }
+            }
+            if (uint64_t(first_child) + n_inner >= rt::BVH4_SENTINEL) {
+                return out;
+            }
+            out.nodes.resize(size_t(first_child) + n_inner);
+            out.nodes[w.out_index] = node;
+            for (int c = n_slots - 1; c >= 0; --c) { // first inner child is processed next (depth-first layout)
+                if (!is_leaf(slots[c].ref)) {
+                    stack.push_back(Work{slots[c].ref, node.child[c]});
+                }
+            }
+        }
+        root4_of_bvh2[root2] = root4;
+        out.blas_root4[mi] = root4;
+    }
+    out.ok = true;
+    return out;
+}
+
+} // namespace rayhip_bvh4

@@ -45,6 +45,27 @@ __device__ __forceinline__ void prof_mark(const int k) {
 } // namespace rt
 #define RT_PROF(k) ::rt::prof_mark(k);
 #endif
+#ifdef RT_PROFILE_TRACE
+// Tuning build: the same wave-time attribution inside k_trace_closest (sections 16..27 of g_prof_acc)
+namespace rt {
+__device__ unsigned long long g_prof_acc[32];
+__shared__ unsigned long long s_prof_last;
+__shared__ unsigned long long s_prof_acc[32];
+__device__ __forceinline__ void prof_mark(const int k) {
+    const unsigned long long mask = __ballot(1);
+    if (int(__lane_id()) == __ffsll((long long)mask) - 1) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        s_prof_acc[k] += t - s_prof_last;
+        s_prof_last = t;
+    }
+}
+__device__ __forceinline__ void prof_wait(float4 &a, float4 &b, float4 &c, float4 &d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(d.x));
+}
+} // namespace rt
+#define RT_PROF_T(k) ::rt::prof_mark(k);
+#define RT_PROF_WAIT(a, b, c, d) ::rt::prof_wait(const_cast<float4 &>(a), const_cast<float4 &>(b), const_cast<float4 &>(c), const_cast<float4 &>(d));
+#endif
 #include "rt_arealights.h"
 #include "rt_params.h"
 #include "rt_pixel.h"
@@ -64,7 +85,7 @@ namespace rt {
 #define RT_LDS_STACK_DEPTH 24
 #endif
 #ifndef RT_TRACE_MIN_WAVES
-#define RT_TRACE_MIN_WAVES 6
+#define RT_TRACE_MIN_WAVES 5 // 96 VGPRs: the 4-wide node visit spills badly at 80 (6 waves: K2 7.9 ms vs 5.7 ms at 5 or 4)
 #endif
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 1
@@ -93,6 +114,25 @@ struct LdsStack {
             return lane_base[size * WAVE];
         }
         return size < uint32_t(STACK_TOTAL_DEPTH) ? spill_base[(size - LDS_STACK_DEPTH) * WAVE] : 0x1fffffffu;
+    }
+    // slot access for the 4-wide walk (rt_bvh4.h): three consecutive slots are one address + immediate offsets
+    __device__ __forceinline__ bool fast_range(const uint32_t idx_end) const { return idx_end <= uint32_t(LDS_STACK_DEPTH); }
+    __device__ __forceinline__ void write3_fast(const uint32_t idx, const uint32_t a, const uint32_t b, const uint32_t c) {
+        uint32_t *p = lane_base + idx * WAVE;
+        p[0] = a, p[WAVE] = b, p[2 * WAVE] = c;
+    }
+    __device__ __forceinline__ void write_at(const uint32_t idx, const uint32_t v) {
+        if (idx < uint32_t(LDS_STACK_DEPTH)) {
+            lane_base[idx * WAVE] = v;
+        } else if (idx < uint32_t(STACK_TOTAL_DEPTH)) {
+            spill_base[(idx - LDS_STACK_DEPTH) * WAVE] = v;
+        }
+    }
+    __device__ __forceinline__ uint32_t read_at(const uint32_t idx) const {
+        if (idx < uint32_t(LDS_STACK_DEPTH)) {
+            return lane_base[idx * WAVE];
+        }
+        return idx < uint32_t(STACK_TOTAL_DEPTH) ? spill_base[(idx - LDS_STACK_DEPTH) * WAVE] : 0x1fffffffu;
     }
 };
 
@@ -179,18 +219,30 @@ __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint
 
 // ---- K2 ---------------------------------------------------------------------------------------------------
 // One ray per lane; grid-stride over the device-resident ray count.
-template <bool COUNT>
+// COUNT: instrumented walk of the reference's BVH2 (visit counters = algorithmic bytes); WIDE: 4-wide BLAS (rt_bvh4.h)
+template <bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest(const SceneView sc, const TraceParams tp, const RaySoA rays,
                                                        const HitSoA hits, const RayQueue queue,
                                                        const int init_hits, uint32_t *__restrict__ stack_spill,
                                                        unsigned long long *__restrict__ counters) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t lane = threadIdx.x;
+#ifdef RT_PROFILE_TRACE
+    if (WIDE) {
+        if (threadIdx.x < 32) {
+            s_prof_acc[threadIdx.x] = 0;
+        }
+        if (threadIdx.x == 0) {
+            s_prof_last = __builtin_readcyclecounter();
+        }
+    }
+#endif
     for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
         }
+        RT_PROF_T(24)
         const uint32_t i = slot0 + lane;
         Ray r;
         load_ray_od(rays, i, r);
@@ -210,7 +262,9 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest(cons
         st.spill_base = stack_spill + size_t(blockIdx.x) * size_t(STACK_SPILL_DEPTH * WAVE) + lane;
         st.size = 0;
         TravCount tc = {0, 0, 0, 0};
-        intersect_scene_closest(sc, tp, r, h, st, COUNT ? &tc : nullptr);
+        RT_PROF_T(25)
+        intersect_scene_closest<WIDE>(sc, tp, r, h, st, COUNT ? &tc : nullptr);
+        RT_PROF_T(26)
 
         store_hit(hits, i, h);
         // only rays that crossed (or died on) a transparent surface changed throughput / depth
@@ -228,10 +282,18 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest(cons
             atomicMax(&counters[4], (unsigned long long)tc.max_stack);
         }
     }
+#ifdef RT_PROFILE_TRACE
+    if (WIDE) {
+        RT_PROF_T(27)
+        if (threadIdx.x < 32 && s_prof_acc[threadIdx.x] != 0) {
+            atomicAdd(&g_prof_acc[threadIdx.x], s_prof_acc[threadIdx.x]);
+        }
+    }
+#endif
 }
 
 // ---- K3 ---------------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const SceneView sc, const TraceParams tp, const ShadowSoA shadow,
                                                       const RayQueue queue, const float limit,
                                                       const int img_w, float4 *__restrict__ temp_buf,
@@ -252,7 +314,7 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const
         st.spill_base = stack_spill + size_t(blockIdx.x) * size_t(STACK_SPILL_DEPTH * WAVE) + lane;
         st.size = 0;
         TravCount tc = {0, 0, 0, 0};
-        const f3 rc = intersect_scene_shadow(sc, tp, r, st, COUNT ? &tc : nullptr);
+        const f3 rc = intersect_scene_shadow<WIDE>(sc, tp, r, st, COUNT ? &tc : nullptr);
         if (out_rc) {
             out_rc[i] = mkfloat4(rc.x, rc.y, rc.z, 0.0f);
         } else {

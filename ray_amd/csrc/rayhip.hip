@@ -15,8 +15,9 @@
 #include <vector>
 
 #include "../../include/rayhip.h"
+#include "kernels.hip.h" // first: it configures the profiling macros the rt_*.h headers expand
+#include "bvh4_build.h"
 #include "bvh_layout.h"
-#include "kernels.hip.h"
 #include "scene_blob.h"
 #include "sort.h"
 
@@ -80,7 +81,7 @@ struct rayhip_ctx {
     DevBuf pmj, filter_table;
     // scene
     DevBuf nodes, tris, tri_indices, tri_materials, materials, vertices, vtx_indices, mesh_instances, lights, li_indices,
-        light_cwnodes, light_children, textures, texels;
+        light_cwnodes, light_children, textures, texels, nodes4, blas_root4;
     SceneView sc = {};
     float bbox_min[3] = {}, bbox_max[3] = {};
     bool have_scene = false;
@@ -297,7 +298,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     }
     // persistent grid of the wave-per-block kernels: as many blocks as are resident (LDS stack + VGPR budget)
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false>, WAVE, 0) != hipSuccess || per_cu <= 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false, true>, WAVE, 0) != hipSuccess || per_cu <= 0) {
         per_cu = 8;
     }
     // 4x more blocks than are resident: each block then owns ~1/4 of the chunks a resident wave would, and the
@@ -334,7 +335,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         (void)hipEventDestroy(e);
     }
     DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
-                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children,
+                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->nodes4, &c->blas_root4,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
                      &c->px_dn, &c->px_req, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
                      &c->shadow_planes[2], &c->counters, &c->trav_counters, &c->stack_spill,
@@ -451,6 +452,26 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
         UP(tri_indices)
         UP(mesh_instances)
     }
+    // 4-wide quantised BLAS trees (rt_bvh4.h) over the node order that was just uploaded; RAYHIP_NO_BVH4=1 keeps the
+    // kernels on the reference's BVH2 (A/B measurements)
+    bool have_wide = false;
+    {
+        const char *e = getenv("RAYHIP_NO_BVH4");
+        if (!(e && e[0] == '1')) {
+            const rayhip_bvh2_node *n2 = lay.applied ? lay.nodes.data() : d->nodes;
+            const uint32_t n2_count = lay.applied ? uint32_t(lay.nodes.size()) : d->nodes_count;
+            const rayhip_mesh_instance *mis = lay.applied ? lay.mesh_instances.data() : d->mesh_instances;
+            rayhip_bvh4::Result b4 = rayhip_bvh4::build(n2, n2_count, mis, d->mesh_instances_count, tlas_root);
+            if (b4.ok && !b4.nodes.empty()) {
+                if (upload(c, c->nodes4, b4.nodes.data(), b4.nodes.size() * sizeof(Bvh4Node)) ||
+                    upload(c, c->blas_root4, b4.blas_root4.data(), b4.blas_root4.size() * sizeof(uint32_t))) {
+                    return 1;
+                }
+                HIP_TRY(hipStreamSynchronize(c->stream)); // b4 goes out of scope
+                have_wide = true;
+            }
+        }
+    }
     UP(tri_materials)
     UP(materials)
     UP(vertices)
@@ -483,6 +504,8 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
     v.vtx_indices = c->vtx_indices.as<uint32_t>(), v.mesh_instances = c->mesh_instances.as<rayhip_mesh_instance>();
     v.lights = c->lights.as<rayhip_light>(), v.li_indices = c->li_indices.as<uint32_t>();
     v.light_children = c->light_children.as<float4>();
+    v.nodes4 = have_wide ? c->nodes4.as<Bvh4Node>() : nullptr;
+    v.blas_root4 = have_wide ? c->blas_root4.as<uint32_t>() : nullptr;
     v.light_cwnodes = c->light_cwnodes.as<rayhip_light_cwbvh_node>(), v.textures = c->textures.as<rayhip_texture>();
     v.texels = c->texels.as<uint32_t>();
     memcpy(v.tex_table, d->tex_table, sizeof(v.tex_table));
@@ -581,9 +604,11 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
     // K2 launcher (instrumented variant on request)
     auto launch_closest = [&](const RaySoA &r, const RayQueue &q, int init_hits) {
         if (count) {
-            k_trace_closest<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
+            k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
+        } else if (c->sc.nodes4) {
+            k_trace_closest<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
         } else {
-            k_trace_closest<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
+            k_trace_closest<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
         }
     };
 
@@ -654,11 +679,14 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
             k_shadow_blockers<<<gtrace, WAVE, 0, s>>>(c->sc, c->shadow, c->shadow_queue(bounce, npix, stripes));
         }
         if (count) {
-            k_trace_shadow<true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit, c->w,
-                                                         c->px.temp, nullptr, spill, tc + 5);
+            k_trace_shadow<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit,
+                                                                c->w, c->px.temp, nullptr, spill, tc + 5);
+        } else if (c->sc.nodes4) {
+            k_trace_shadow<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit,
+                                                                c->w, c->px.temp, nullptr, spill, tc + 5);
         } else {
-            k_trace_shadow<false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit, c->w,
-                                                          c->px.temp, nullptr, spill, tc + 5);
+            k_trace_shadow<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit,
+                                                                 c->w, c->px.temp, nullptr, spill, tc + 5);
         }
         cur ^= 1;
     }
@@ -891,9 +919,14 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     HIP_TRY(hipMemsetAsync(tc, 0, sizeof(before), s));
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
-    (void)flags;
-    k_trace_closest<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, c->ray_queue(0, size_t(count), 1), 0,
-                                                     c->stack_spill.as<uint32_t>(), tc);
+    const RayQueue q = c->ray_queue(0, size_t(count), 1);
+    if (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) { // instrumented walk of the reference's BVH2
+        k_trace_closest<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc);
+    } else if (c->sc.nodes4) { // what rayhip_render launches
+        k_trace_closest<false, true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc);
+    } else {
+        k_trace_closest<false, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpyAsync(after, tc, sizeof(after), hipMemcpyDeviceToHost, s));
@@ -953,7 +986,7 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     // results land in the (otherwise idle) hit plane
-    k_trace_shadow<true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
+    k_trace_shadow<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
                                                     c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -996,7 +1029,7 @@ int rayhip_k_scrambled_rand(rayhip_ctx *c, const uint32_t *dims, const uint32_t 
     return 0;
 }
 
-#ifdef RT_PROFILE_SHADE
+#if defined(RT_PROFILE_SHADE) || defined(RT_PROFILE_TRACE)
 // tuning build only (tools/variants.py): cycles per shade-kernel section, see RT_PROF in kernels.hip.h
 __attribute__((visibility("default"))) int rayhip_tuning_read_profile(rayhip_ctx *c, unsigned long long out[32], int reset) {
     if (use_device(c)) {

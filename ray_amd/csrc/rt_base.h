@@ -20,6 +20,12 @@
 #ifndef RT_PROF
 #define RT_PROF(k)
 #endif
+// same for the traversal-kernel profile build (-DRT_PROFILE_TRACE); RT_PROF_WAIT forces the loads just issued to land
+// before the next marker so that "waiting for memory" becomes its own section
+#ifndef RT_PROF_T
+#define RT_PROF_T(k)
+#define RT_PROF_WAIT(...)
+#endif
 
 #include <stdint.h>
 

@@ -1,0 +1,158 @@
+// rt_bvh4.h -- 4-wide BLAS with 8-bit quantised child boxes: the acceleration structure the non-instrumented
+// traversal kernels walk on MI355X.
+//
+// Why not the reference's BVH2 as it is: a bvh2_node_t visit is four 16-byte gathers for two boxes, and the texture
+// addresser of a CU retires about one lane-address per cycle for 128-bit loads (tools/gather_bench.hip, TA_BUSY 60 %
+// in profiles/r01), so the closest-hit kernel is bound by the NUMBER of node fetches and by the length of the
+// dependent fetch chain, not by bytes or flops.  Collapsing two BVH2 levels into one node halves both: the same 64
+// bytes / four gathers now carry four boxes.
+//
+// What makes it safe (results must be the reference's): the BVH only culls.  A child box here is the reference's
+// fp32 box rounded OUTWARDS onto a 256-step grid spanning the node (lo: floor, hi: ceil; checked after rounding with
+// the very expression the device evaluates, and widened until it contains the fp32 box), and the slab test is the
+// reference's own bbox_test on the de-quantised box.  Floating-point subtraction and multiplication are monotonic, so
+// whenever the reference's test accepts a child with its exact box, this test accepts it with the wider box: every
+// triangle the reference tests with a chance to hit is tested here, IntersectTri is unchanged, and the closest hit
+// (t, u, v, triangle) is the same -- only exact-t ties between different triangles could resolve differently, as they
+// already do between the reference's own BVH2 and wide-BVH back-ends.  The instrumented kernels
+// (RAYHIP_FLAG_COUNT_TRAVERSAL) keep walking the BVH2, so the algorithmic-bytes counters stay those of the reference
+// algorithm.  The TLAS stays BVH2 (a handful of nodes).
+//
+// Node, 64 bytes, 16-byte aligned, fetched as 4 x global_load_dwordx4:
+//   [0]  org.xyz                float  grid origin = node box min
+//        scale exponents        3 x u8 biased exponent E of the per-axis grid step 2^(E-127), 1 pad byte
+//   [1]  child[4]               inner: bvh4 node index | leaf: (count-1)<<29 | first entry in tris[] (reference leaf word)
+//   [2]  qlo[x][4] qlo[y][4] qlo[z][4] qhi[x][4]     u8, [axis][child]
+//   [3]  qhi[y][4] qhi[z][4] pad pad                 (empty slot: child = BVH4_EMPTY)
+#pragma once
+
+#include "rt_isect.h"
+
+namespace rt {
+
+struct alignas(16) Bvh4Node {
+    float org[3];
+    uint32_t exps; // byte 0,1,2 = biased exponent of the x,y,z grid step
+    uint32_t child[4];
+    uint32_t qlo[3]; // byte c of qlo[a] = child c, axis a
+    uint32_t qhi[3];
+    uint32_t _pad[2];
+};
+static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node must be one 64-byte fetch unit");
+
+constexpr uint32_t BVH4_SENTINEL = 0x1fffffffu; // same stack sentinel as the BVH2 walk (never a node index)
+constexpr uint32_t BVH4_EMPTY = 0xffffffffu;    // unused child slot
+
+// grid step of one axis from its biased exponent byte
+RT_HD float bvh4_scale(const uint32_t exps, const int axis) { return uint_as_float(((exps >> (8 * axis)) & 0xffu) << 23); }
+// one de-quantised box coordinate: a single fused multiply-add, the same operation on host (builder check) and device
+RT_HD float bvh4_dequant(const uint32_t q, const float scale, const float org) { return __builtin_fmaf(float(q), scale, org); }
+
+// One visit of a 4-wide node: test the four children against [0, t] and return them sorted by entry distance
+// (ref[0] nearest); n_hit = number of children hit.
+RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 ro, const f3 inv_d, const float t, uint32_t ref[4],
+                          uint32_t &n_hit) {
+    RT_PROF_T(16)
+    const float4 *np = reinterpret_cast<const float4 *>(nodes4 + cur);
+    const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+    RT_PROF_WAIT(w0, w1, w2, w3)
+    RT_PROF_T(17)
+    const uint32_t exps = float_as_uint(w0.w);
+    const float sx = bvh4_scale(exps, 0), sy = bvh4_scale(exps, 1), sz = bvh4_scale(exps, 2);
+    const uint32_t child[4] = {float_as_uint(w1.x), float_as_uint(w1.y), float_as_uint(w1.z), float_as_uint(w1.w)};
+    const uint32_t qlx = float_as_uint(w2.x), qly = float_as_uint(w2.y), qlz = float_as_uint(w2.z);
+    const uint32_t qhx = float_as_uint(w2.w), qhy = float_as_uint(w3.x), qhz = float_as_uint(w3.y);
+
+    const float none = 3.402823466e+38f;
+    float dist[4];
+    n_hit = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int sh = 8 * c;
+        const float lo[3] = {bvh4_dequant((qlx >> sh) & 0xffu, sx, w0.x), bvh4_dequant((qly >> sh) & 0xffu, sy, w0.y),
+                             bvh4_dequant((qlz >> sh) & 0xffu, sz, w0.z)};
+        const float hi[3] = {bvh4_dequant((qhx >> sh) & 0xffu, sx, w0.x), bvh4_dequant((qhy >> sh) & 0xffu, sy, w0.y),
+                             bvh4_dequant((qhz >> sh) & 0xffu, sz, w0.z)};
+        float d;
+        const bool hit = bbox_test(ro, inv_d, t, lo, hi, d) && child[c] != BVH4_EMPTY;
+        dist[c] = hit ? d : none;
+        ref[c] = child[c];
+        n_hit += hit ? 1u : 0u;
+    }
+    // sorting network on (dist, ref), ascending: (0,1) (2,3) (0,2) (1,3) (1,2); children that were not hit sort last
+#define RT_CSWAP(a, b)                                                                                                  \
+    {                                                                                                                   \
+        const bool sw = dist[b] < dist[a];                                                                              \
+        const float da = sw ? dist[b] : dist[a], db = sw ? dist[a] : dist[b];                                           \
+        const uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];                                            \
+        dist[a] = da, dist[b] = db, ref[a] = ra, ref[b] = rb;                                                           \
+    }
+    RT_CSWAP(0, 1)
+    RT_CSWAP(2, 3)
+    RT_CSWAP(0, 2)
+    RT_CSWAP(1, 3)
+    RT_CSWAP(1, 2)
+#undef RT_CSWAP
+    RT_PROF_T(18)
+}
+
+// Ordered walk over a 4-wide BLAS.  `leaf(word)` gets a reference leaf word and returns true to stop (any-hit early
+// out).  `t_ref` is re-read at every node so that hits found in earlier leaves prune.
+//
+// Stack discipline (measured: with a plain LDS push/pop per child the stack code was 35 % of the kernel's wave time):
+//   * the top of the stack lives in a register (`tos`).  A pop hands out the register and starts the LDS read of
+//     the next entry, whose latency then hides behind the next node fetch instead of sitting in front of it;
+//   * a node visit pushes up to three children with three UNCONDITIONAL stores to consecutive slots (one address,
+//     immediate offsets) and then advances `size` by the number that were real -- stale values above `size` are
+//     never read -- instead of three compare/branch/store sequences;
+//   * only when the three slots would leave the LDS part of the stack does it fall back to the generic path that
+//     can spill to HBM.
+template <class Stack, class LeafFn>
+RT_HD bool walk_bvh4(const Bvh4Node *nodes4, const uint32_t root, const f3 ro, const f3 inv_d, const float &t_ref, Stack &st,
+                     LeafFn &&leaf) {
+    const uint32_t base = st.size;
+    uint32_t size = base;
+    st.write_at(size++, BVH4_SENTINEL); // second sentinel, so that the read-ahead of a pop never leaves this level
+    uint32_t tos = BVH4_SENTINEL;
+    uint32_t cur = root;
+    for (;;) {
+        while ((cur & BVH2_PRIM_COUNT_BITS) == 0 && cur != BVH4_SENTINEL) {
+            uint32_t ref[4], n_hit;
+            bvh4_test_node(nodes4, cur, ro, inv_d, t_ref, ref, n_hit);
+            if (n_hit == 0) {
+                cur = tos;
+                tos = st.read_at(--size);
+            } else {
+                cur = ref[0];
+                // bottom -> top: old tos, farthest ... third nearest; the second nearest becomes the new tos
+                const uint32_t s1 = (n_hit == 4) ? ref[3] : ref[2];
+                if (st.fast_range(size + 3)) {
+                    st.write3_fast(size, tos, s1, ref[2]);
+                } else if (n_hit > 1) {
+                    st.write_at(size, tos);
+                    if (n_hit > 2) {
+                        st.write_at(size + 1, s1);
+                    }
+                    if (n_hit > 3) {
+                        st.write_at(size + 2, ref[2]);
+                    }
+                }
+                size += n_hit - 1;
+                tos = (n_hit > 1) ? ref[1] : tos;
+            }
+            RT_PROF_T(19)
+        }
+        if (cur == BVH4_SENTINEL) {
+            break;
+        }
+        if (leaf(cur)) {
+            st.size = base;
+            return true;
+        }
+        cur = tos;
+        tos = st.read_at(--size);
+    }
+    st.size = base;
+    return false;
+}
+
+} // namespace rt

@@ -16,96 +16,10 @@
 // `stack_size == 0`.
 #pragma once
 
-#include "rt_rng.h"
-#include "rt_texture.h"
-#include "rt_types.h"
+#include "rt_bvh4.h"
+#include "rt_isect.h"
 
 namespace rt {
-
-// plain array stack (host simulation, and the spill fallback)
-struct ArrayStack {
-    uint32_t data[2 * MAX_STACK_SIZE];
-    uint32_t size = 0;
-    RT_HD void push(uint32_t v) { data[size++] = v; }
-    RT_HD uint32_t pop() { return data[--size]; }
-};
-
-#define RT_SIGN_OF(f) (((f) >= 0) ? 1 : -1)
-
-// One triangle fetched as three 16-byte loads issued together (a single memory round trip per triangle).
-struct TriData {
-    float4 n, u, v;
-};
-RT_HD TriData load_tri(const rayhip_tri_accel *tris, const uint32_t i) {
-    const float4 *p = reinterpret_cast<const float4 *>(tris + i);
-    TriData t;
-    t.n = p[0], t.u = p[1], t.v = p[2];
-    return t;
-}
-
-// CoreRef.cpp:24-50.  Same operations in the same order as the reference; the three early `return`s are folded
-// into one predicate so that no load or divide sits behind a branch (on the GPU every early-out used to cost a
-// dependent memory round trip: n_plane -> branch -> u_plane -> branch -> v_plane).  The speculated arithmetic is
-// discarded when the predicate fails, so accepted hits are bit-identical.
-RT_HD void intersect_tri(const f3 ro, const f3 rd, const TriData &tri, const uint32_t prim_index, Hit &inter) {
-    const float det = rd.x * tri.n.x + rd.y * tri.n.y + rd.z * tri.n.z;
-    const float dett = tri.n.w - (ro.x * tri.n.x + ro.y * tri.n.y + ro.z * tri.n.z);
-    bool ok = !(det == 0.0f || RT_SIGN_OF(dett) != RT_SIGN_OF(det * inter.t - dett));
-
-    const float p0 = det * ro.x + dett * rd.x, p1 = det * ro.y + dett * rd.y, p2 = det * ro.z + dett * rd.z;
-
-    const float detu = (p0 * tri.u.x + p1 * tri.u.y + p2 * tri.u.z) + det * tri.u.w;
-    ok = ok && !(RT_SIGN_OF(detu) != RT_SIGN_OF(det - detu));
-
-    const float detv = (p0 * tri.v.x + p1 * tri.v.y + p2 * tri.v.z) + det * tri.v.w;
-    ok = ok && !(RT_SIGN_OF(detv) != RT_SIGN_OF(det - detu - detv));
-
-    const float rdet = (1.0f / det);
-    if (ok) {
-        inter.prim_index = (det < 0.0f) ? int(prim_index) : -int(prim_index) - 1;
-        inter.t = dett * rdet;
-        inter.u = detu * rdet;
-        inter.v = detv * rdet;
-    }
-}
-#undef RT_SIGN_OF
-
-// CoreRef.cpp:171-210
-RT_HD bool bbox_test(const f3 o, const f3 inv_d, const float t, const float mn[3], const float mx[3], float &out_dist) {
-    float lo_x = inv_d.x * (mn[0] - o.x);
-    float hi_x = inv_d.x * (mx[0] - o.x);
-    if (lo_x > hi_x) {
-        const float tmp = lo_x;
-        lo_x = hi_x;
-        hi_x = tmp;
-    }
-    float lo_y = inv_d.y * (mn[1] - o.y);
-    float hi_y = inv_d.y * (mx[1] - o.y);
-    if (lo_y > hi_y) {
-        const float tmp = lo_y;
-        lo_y = hi_y;
-        hi_y = tmp;
-    }
-    float lo_z = inv_d.z * (mn[2] - o.z);
-    float hi_z = inv_d.z * (mx[2] - o.z);
-    if (lo_z > hi_z) {
-        const float tmp = lo_z;
-        lo_z = hi_z;
-        hi_z = tmp;
-    }
-    float tmin = lo_x > lo_y ? lo_x : lo_y;
-    if (lo_z > tmin) {
-        tmin = lo_z;
-    }
-    float tmax = hi_x < hi_y ? hi_x : hi_y;
-    if (hi_z < tmax) {
-        tmax = hi_z;
-    }
-    tmax *= 1.00000024f;
-
-    out_dist = tmin;
-    return tmin <= tmax && tmin <= t && tmax > 0;
-}
 
 // One visit of an inner node (body of the inner loop, CoreRef.cpp:1961-1993): fetch the 64-byte node as four
 // 16-byte loads issued together -- child links included, so the node costs ONE memory round trip -- slab-test both
@@ -194,12 +108,16 @@ RT_HD bool intersect_tris_closest(const f3 ro, const f3 rd, const rayhip_tri_acc
     inter.u = 0.0f;
     inter.v = -1.0f;
     // the next triangle's 48 bytes are requested before the current one is tested (one round trip in flight ahead)
+    RT_PROF_T(20)
     TriData cur_tri = load_tri(tris, uint32_t(tri_start));
+    RT_PROF_WAIT(cur_tri.n, cur_tri.u, cur_tri.v, cur_tri.v)
+    RT_PROF_T(21)
     for (int i = tri_start; i < tri_end; ++i) {
         const TriData next_tri = (i + 1 < tri_end) ? load_tri(tris, uint32_t(i + 1)) : cur_tri;
         intersect_tri(ro, rd, cur_tri, uint32_t(i), inter);
         cur_tri = next_tri;
     }
+    RT_PROF_T(22)
     const bool hit = inter.v >= 0.0f;
     out_inter.obj_index = hit ? inter.obj_index : out_inter.obj_index;
     out_inter.prim_index = hit ? inter.prim_index : out_inter.prim_index;
@@ -239,7 +157,9 @@ RT_HD bool intersect_tris_any(const f3 ro, const f3 rd, const rayhip_tri_accel *
 }
 
 // Traverse_TLAS_WithStack_ClosestHit(bvh2), CoreRef.cpp:1943-2025 (+ BLAS :2428-2493)
-template <class Stack>
+// WIDE: the BLAS level walks the 4-wide quantised tree (rt_bvh4.h) instead of the reference's BVH2 -- same leaves,
+// same triangle tests, conservative culling; no visit counters (those describe the reference algorithm).
+template <bool WIDE = false, class Stack>
 RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const uint32_t ray_flags,
                             const uint32_t root_index, Hit &inter, Stack &st, TravCount *cnt) {
     bool res = false;
@@ -255,7 +175,8 @@ RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const
             const f3 _ro = transform_point(ro, mi.inv_xform);
             const f3 _rd = transform_direction(rd, mi.inv_xform);
             const f3 _inv_d = safe_invert(_rd);
-            walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, [&](const uint32_t blas_leaf) {
+            RT_PROF_T(23)
+            auto blas_leaf_fn = [&](const uint32_t blas_leaf) {
                 const int tri_start = int(blas_leaf & BVH2_PRIM_INDEX_BITS),
                           tri_end = int(tri_start + ((blas_leaf & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
                 if (cnt) {
@@ -263,7 +184,12 @@ RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const
                 }
                 res |= intersect_tris_closest(_ro, _rd, sc.tris, tri_start, tri_end, int(mi_index), inter);
                 return false;
-            });
+            };
+            if (WIDE) {
+                walk_bvh4(sc.nodes4, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn);
+            } else {
+                walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, blas_leaf_fn);
+            }
         }
         return false;
     });
@@ -278,7 +204,7 @@ RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const
 }
 
 // Traverse_TLAS_WithStack_AnyHit(bvh2), CoreRef.cpp:2193-2280 (+ BLAS :2619-2693); returns "solid hit found"
-template <class Stack>
+template <bool WIDE = false, class Stack>
 RT_HD bool traverse_any(const SceneView &sc, const f3 ro, const f3 rd, const int ray_type, const uint32_t root_index,
                         Hit &inter, Stack &st, TravCount *cnt) {
     const uint32_t ray_vismask = (1u << ray_type);
@@ -294,7 +220,7 @@ RT_HD bool traverse_any(const SceneView &sc, const f3 ro, const f3 rd, const int
             const f3 _ro = transform_point(ro, mi.inv_xform);
             const f3 _rd = transform_direction(rd, mi.inv_xform);
             const f3 _inv_d = safe_invert(_rd);
-            return walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, [&](const uint32_t blas_leaf) {
+            auto blas_leaf_fn = [&](const uint32_t blas_leaf) {
                 const int tri_start = int(blas_leaf & BVH2_PRIM_INDEX_BITS),
                           tri_end = int(tri_start + ((blas_leaf & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
                 if (cnt) {
@@ -312,7 +238,11 @@ RT_HD bool traverse_any(const SceneView &sc, const f3 ro, const f3 rd, const int
                     }
                 }
                 return false;
-            });
+            };
+            if (WIDE) {
+                return walk_bvh4(sc.nodes4, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn);
+            }
+            return walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, blas_leaf_fn);
         }
         return false;
     });
@@ -414,7 +344,7 @@ RT_HD bool closest_resolve_transparency(const SceneView &sc, const TraceParams &
 // Ref::IntersectScene, closest hit + transparency/mix resolve loop.  CoreRef.cpp:3041-3158.
 // In: r (o,d,c,depth,xy), inter (t preset by the caller: clip range for primary rays, MAX_DIST otherwise).
 // Out: inter; r.c and r.depth are updated when transparent surfaces are crossed.
-template <class Stack>
+template <bool WIDE = false, class Stack>
 RT_HD void intersect_scene_closest(const SceneView &sc, const TraceParams &tp, Ray &r, Hit &inter, Stack &st,
                                    TravCount *cnt) {
     const f3 rd = r.d;
@@ -429,7 +359,7 @@ RT_HD void intersect_scene_closest(const SceneView &sc, const TraceParams &tp, R
     while (true) {
         const float t_val = inter.t;
 
-        const bool hit_found = traverse_closest(sc, ro, rd, ray_flags, tp.root_index, inter, st, cnt);
+        const bool hit_found = traverse_closest<WIDE>(sc, ro, rd, ray_flags, tp.root_index, inter, st, cnt);
         if (!hit_found) {
             break;
         }
@@ -442,7 +372,7 @@ RT_HD void intersect_scene_closest(const SceneView &sc, const TraceParams &tp, R
 }
 
 // Ref::IntersectScene(shadow_ray_t): visibility * throughput towards the light.  CoreRef.cpp:3160-3262.
-template <class Stack>
+template <bool WIDE = false, class Stack>
 RT_HD f3 intersect_scene_shadow(const SceneView &sc, const TraceParams &tp, const ShadowRay &r, Stack &st,
                                 TravCount *cnt) {
     const f3 rd = r.d;
@@ -460,7 +390,7 @@ RT_HD f3 intersect_scene_shadow(const SceneView &sc, const TraceParams &tp, cons
         Hit inter = make_hit();
         inter.t = dist;
 
-        const bool solid_hit = traverse_any(sc, ro, rd, RAY_TYPE_SHADOW, tp.root_index, inter, st, cnt);
+        const bool solid_hit = traverse_any<WIDE>(sc, ro, rd, RAY_TYPE_SHADOW, tp.root_index, inter, st, cnt);
 
         if (solid_hit || depth > tp.max_transp_depth) {
             rc = {0.0f, 0.0f, 0.0f};

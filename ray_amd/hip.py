@@ -231,7 +231,9 @@ class Context:
                                                           rays.ctypes.data, hits.ctypes.data, C.byref(cnt)))
         return rays[:cnt.value], hits[:cnt.value]
 
-    def k_intersect_closest(self, rays: np.ndarray, hits: np.ndarray, iteration: int, cam: Camera = None, flags: int = 0):
+    def k_intersect_closest(self, rays: np.ndarray, hits: np.ndarray, iteration: int, cam: Camera = None,
+                            flags: int = FLAG_COUNT_TRAVERSAL):
+        """flags=FLAG_COUNT_TRAVERSAL: instrumented walk of the reference BVH2 (+ visit counters); 0: the product kernel"""
         rays = np.ascontiguousarray(rays.copy())
         hits = np.ascontiguousarray(hits.copy())
         tc = TravCounters()

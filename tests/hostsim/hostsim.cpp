@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "../../ray_amd/csrc/bvh4_build.h"
 #include "../../ray_amd/csrc/bvh_layout.h"
 #include "../../ray_amd/csrc/rt_arealights.h"
 #include "../../ray_amd/csrc/rt_params.h"
@@ -42,6 +43,8 @@ struct HostScene {
     std::vector<uint32_t> li_indices;
     std::vector<rayhip_light_cwbvh_node> light_cwnodes;
     std::vector<float4> light_children;
+    std::vector<Bvh4Node> nodes4;
+    std::vector<uint32_t> blas_root4;
     std::vector<rayhip_texture> textures;
     std::vector<uint32_t> texels;
 };
@@ -59,6 +62,7 @@ struct hostsim_ctx {
     rayhip_trav_counters counters[2] = {};
     Shard shard = {64, 1, 0};
     bool layout_applied = false;
+    bool wide = false; // walk the 4-wide BLAS (HOSTSIM_BVH4=1)
 };
 
 // test hook: did the last scene upload go through the HBM layout pass?
@@ -144,8 +148,25 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d) {
             }
         }
     }
+    // 4-wide quantised BLAS (rt_bvh4.h), used when HOSTSIM_BVH4=1
+    c->wide = false;
+    {
+        rayhip_bvh4::Result b4 = rayhip_bvh4::build(s.nodes.data(), uint32_t(s.nodes.size()), s.mesh_instances.data(),
+                                                    uint32_t(s.mesh_instances.size()), tlas_root);
+        if (b4.ok) {
+            s.nodes4.swap(b4.nodes), s.blas_root4.swap(b4.blas_root4);
+            const char *e = getenv("HOSTSIM_BVH4");
+            c->wide = e && e[0] == '1';
+        } else {
+            s.nodes4.clear(), s.blas_root4.clear();
+            if (getenv("HOSTSIM_VERBOSE")) {
+                fprintf(stderr, "hostsim: BVH4 build failed\n");
+            }
+        }
+    }
     SceneView &v = c->sc;
     v.nodes = s.nodes.data(), v.tris = s.tris.data(), v.tri_indices = s.tri_indices.data();
+    v.nodes4 = s.nodes4.empty() ? nullptr : s.nodes4.data(), v.blas_root4 = s.blas_root4.empty() ? nullptr : s.blas_root4.data();
     v.tri_materials = s.tri_materials.data(), v.materials = s.materials.data(), v.vertices = s.vertices.data();
     v.vtx_indices = s.vtx_indices.data(), v.mesh_instances = s.mesh_instances.data(), v.lights = s.lights.data();
     v.light_children = s.light_children.data();
@@ -183,8 +204,16 @@ HS_API int hostsim_scene_upload_blob(hostsim_ctx *c, const void *blob, size_t si
 }
 
 template <class Stack>
-static void trace_closest(const SceneView &sc, const TraceParams &tp, Ray &r, Hit &h, Stack &st, TravCount *cnt) {
-    intersect_scene_closest(sc, tp, r, h, st, cnt);
+static void trace_closest(const hostsim_ctx *c, const TraceParams &tp, Ray &r, Hit &h, Stack &st, TravCount *cnt) {
+    if (c->wide) {
+        intersect_scene_closest<true>(c->sc, tp, r, h, st, nullptr);
+    } else {
+        intersect_scene_closest<false>(c->sc, tp, r, h, st, cnt);
+    }
+}
+template <class Stack>
+static f3 trace_shadow(const hostsim_ctx *c, const TraceParams &tp, const ShadowRay &r, Stack &st, TravCount *cnt) {
+    return c->wide ? intersect_scene_shadow<true>(c->sc, tp, r, st, nullptr) : intersect_scene_shadow<false>(c->sc, tp, r, st, cnt);
 }
 
 static void add_counters(rayhip_trav_counters &dst, const TravCount &tc) {
@@ -220,7 +249,7 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
     if (c->sc.tlas_root != 0xffffffff) {
         for (size_t i = 0; i < rays.size(); ++i) {
             TravCount tc = {};
-            trace_closest(c->sc, tp, rays[i], hits[i], st, count ? &tc : nullptr);
+            trace_closest(c, tp, rays[i], hits[i], st, count ? &tc : nullptr);
             if (count) {
                 add_counters(c->counters[0], tc);
             }
@@ -235,7 +264,7 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
             hits.assign(rays.size(), make_hit());
             for (size_t i = 0; i < rays.size(); ++i) {
                 TravCount tc = {};
-                trace_closest(c->sc, tp, rays[i], hits[i], st, count ? &tc : nullptr);
+                trace_closest(c, tp, rays[i], hits[i], st, count ? &tc : nullptr);
                 if (count) {
                     add_counters(c->counters[0], tc);
                 }
@@ -269,7 +298,7 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
         const float limit = shadow_clamp_limit(*cam, bounce);
         for (size_t i = 0; i < shadow.size(); ++i) {
             TravCount tc = {};
-            f3 rc = intersect_scene_shadow(c->sc, tp, shadow[i], st, count ? &tc : nullptr);
+            f3 rc = trace_shadow(c, tp, shadow[i], st, count ? &tc : nullptr);
             if (count) {
                 add_counters(c->counters[1], tc);
             }
@@ -374,7 +403,7 @@ HS_API int hostsim_k_generate_primary_rays(hostsim_ctx *c, const rayhip_camera *
 
 HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam, rayhip_ray *rays, rayhip_hit *hits,
                                        int count, int iteration, uint32_t flags, rayhip_trav_counters *out_counters) {
-    (void)flags;
+    const bool wide = c->wide && (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) == 0;
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     ArrayStack st;
     rayhip_trav_counters acc = {};
@@ -382,7 +411,11 @@ HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam,
         Ray r = from_abi(rays[i]);
         Hit h = {hits[i].obj_index, hits[i].prim_index, hits[i].t, hits[i].u, hits[i].v};
         TravCount tc = {};
-        intersect_scene_closest(c->sc, tp, r, h, st, &tc);
+        if (wide) {
+            intersect_scene_closest<true>(c->sc, tp, r, h, st, nullptr);
+        } else {
+            intersect_scene_closest<false>(c->sc, tp, r, h, st, &tc);
+        }
         add_counters(acc, tc);
         rays[i] = to_abi(r);
         hits[i] = rayhip_hit{h.obj_index, h.prim_index, h.t, h.u, h.v};
@@ -403,7 +436,7 @@ HS_API int hostsim_k_intersect_shadow(hostsim_ctx *c, const rayhip_camera *cam, 
         r.o = mk3(rays[i].o), r.depth = rays[i].depth, r.d = mk3(rays[i].d), r.dist = rays[i].dist;
         r.c = mk3(rays[i].c), r.xy = rays[i].xy;
         TravCount tc = {};
-        const f3 rc = intersect_scene_shadow(c->sc, tp, r, st, &tc);
+        const f3 rc = trace_shadow(c, tp, r, st, &tc);
         add_counters(acc, tc);
         out_rc[4 * i + 0] = rc.x, out_rc[4 * i + 1] = rc.y, out_rc[4 * i + 2] = rc.z, out_rc[4 * i + 3] = 0.0f;
     }

@@ -73,6 +73,9 @@ def test_closest_hit_on_reference_rays(gpu_lib, name):
     g = util.golden_ref(name)
     ctx = util.make_context(gpu_lib, name)
     rays, hits, tc = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1)
+    # the kernel rayhip_render launches (4-wide quantised BLAS, rt_bvh4.h) must find the very same hits
+    rays_w, hits_w, _ = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
+    assert hits_w.tobytes() == hits.tobytes() and rays_w.tobytes() == rays.tobytes()
     ref = g["primary_hits"]
     hit = ref["v"] >= 0
     assert np.array_equal(hits["obj_index"], ref["obj_index"])

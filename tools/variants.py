@@ -80,13 +80,15 @@ def run1(name, workload="sponza", K=16):
     with open(os.path.join(cache_dir, f"{workload}_{wl.get('detail', 0)}.rayscene"), "rb") as f:
         blob = f.read()
     pmj = np.load(os.path.join(ROOT, "tests", "golden", "pmj02_samples.npy"))
-    ref_path = f"/tmp/variants_ref_{workload}_{K}.npy"
+    ref_path = f"/tmp/variants_ref_{workload}_{K}_{os.environ.get('RT_RES_SCALE', '1')}.npy"
     ref_img = np.load(ref_path) if os.path.exists(ref_path) else None
     if True:
         path = os.path.join(VDIR, name, "librayhip.so")
         L = hip.Library(path)
         ctx = hip.Context(0, L)
         ctx.upload_static(pmj)
+        scale = float(os.environ.get("RT_RES_SCALE", "1"))  # tuning: does kernel time scale with the ray count?
+        wl = dict(wl, w=int(wl["w"] * scale), h=int(wl["h"] * scale))
         ctx.resize(wl["w"], wl["h"])
         ctx.upload_scene_blob(blob)
         for it in range(1, 3):
@@ -109,7 +111,7 @@ def run1(name, workload="sponza", K=16):
         d = np.abs(img - ref_img)
         ctx.render(3 + K, flags=hip.FLAG_COUNT_TRAVERSAL)
         c2, c3 = ctx.trav_counters()
-        print(f"{name:14s} {wl['w'] * wl['h'] * K / dt / 1e6:7.1f} Msamples/s  step {dt / K * 1e3:6.2f} ms | K2 {k2 / K:6.2f} ms K3 {k3 / K:5.2f} ms "
+        print(f"{name:14s} {wl['w']}x{wl['h']} {wl['w'] * wl['h'] * K / dt / 1e6:7.1f} Msamples/s  step {dt / K * 1e3:6.2f} ms | K2 {k2 / K:6.2f} ms K3 {k3 / K:5.2f} ms "
               f"shade {(st['primary_shade'] + st['secondary_shade']) / K / 1e3:5.2f} ms gen {st['primary_ray_gen'] / K / 1e3:4.2f} sort {st['secondary_sort'] / K / 1e3:4.2f} | "
               f"vs first: max|d| {d.max():.2e} frac>1e-3 {(d.max(axis=-1) > 1e-3).mean():.2e} | max_stack {c2['max_stack']}/{c3['max_stack']}",
               flush=True)
@@ -126,9 +128,13 @@ def run1(name, workload="sponza", K=16):
                      5: "NEE: per-type light sample", 15: "NEE: light-tree descent", 6: "textures + ray init", 7: "diffuse eval+sample", 8: "glossy eval+sample",
                      9: "refractive eval+sample", 10: "emissive", 11: "principled setup", 12: "principled eval",
                      13: "principled sample", 14: "tail (RR, shadow ray)", 28: "pixel write", 29: "compaction + stores",
-                     30: "chunk fetch / loop", 31: "exit"}
+                     30: "chunk fetch / loop", 31: "exit",
+                     16: "K2 node: loop/stack -> fetch issue", 17: "K2 node: wait for node data", 18: "K2 node: 4 box tests + sort",
+                     19: "K2 node: push/pop (LDS)", 20: "K2 leaf: before tri fetch", 21: "K2 leaf: wait for first tri",
+                     22: "K2 leaf: tri tests (+prefetch waits)", 23: "K2 TLAS: instance transform", 24: "K2 chunk fetch",
+                     25: "K2 ray load", 26: "K2 scene walk residue", 27: "K2 store + exit"}
             tot = float(sum(buf)) or 1.0
-            print("  shade-kernel wave time by section:")
+            print("  wave time by section:")
             for k in range(32):
                 if buf[k]:
                     print(f"    {k:2d} {names.get(k, '?'):34s} {100.0 * buf[k] / tot:5.1f} %")
