@@ -64,6 +64,14 @@ __device__ __forceinline__ void prof_wait(float4 &a, float4 &b, float4 &c, float
 }
 } // namespace rt
 #define RT_PROF_T(k) ::rt::prof_mark(k);
+#define RT_PROF_LANES(k)                                                                                                \
+    {                                                                                                                   \
+        const unsigned long long m_ = __ballot(1);                                                                      \
+        if (int(__lane_id()) == __ffsll((long long)m_) - 1) {                                                           \
+            ::rt::s_prof_acc[k] += (unsigned long long)__popcll(m_);                                                    \
+            ::rt::s_prof_acc[(k) + 1] += 1ull;                                                                          \
+        }                                                                                                               \
+    }
 #define RT_PROF_WAIT(a, b, c, d) ::rt::prof_wait(const_cast<float4 &>(a), const_cast<float4 &>(b), const_cast<float4 &>(c), const_cast<float4 &>(d));
 #endif
 #include "rt_arealights.h"

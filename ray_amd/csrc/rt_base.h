@@ -25,6 +25,7 @@
 #ifndef RT_PROF_T
 #define RT_PROF_T(k)
 #define RT_PROF_WAIT(...)
+#define RT_PROF_LANES(k) // counts active lanes into slot k and wave-level executions into slot k+1
 #endif
 
 #include <stdint.h>

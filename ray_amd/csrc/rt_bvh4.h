@@ -53,6 +53,7 @@ RT_HD float bvh4_dequant(const uint32_t q, const float scale, const float org) {
 RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 ro, const f3 inv_d, const float t, uint32_t ref[4],
                           uint32_t &n_hit) {
     RT_PROF_T(16)
+    RT_PROF_LANES(0)
     const float4 *np = reinterpret_cast<const float4 *>(nodes4 + cur);
     const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
     RT_PROF_WAIT(w0, w1, w2, w3)

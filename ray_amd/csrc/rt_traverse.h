@@ -113,6 +113,7 @@ RT_HD bool intersect_tris_closest(const f3 ro, const f3 rd, const rayhip_tri_acc
     RT_PROF_WAIT(cur_tri.n, cur_tri.u, cur_tri.v, cur_tri.v)
     RT_PROF_T(21)
     for (int i = tri_start; i < tri_end; ++i) {
+        RT_PROF_LANES(2)
         const TriData next_tri = (i + 1 < tri_end) ? load_tri(tris, uint32_t(i + 1)) : cur_tri;
         intersect_tri(ro, rd, cur_tri, uint32_t(i), inter);
         cur_tri = next_tri;
@@ -176,6 +177,7 @@ RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const
             const f3 _rd = transform_direction(rd, mi.inv_xform);
             const f3 _inv_d = safe_invert(_rd);
             RT_PROF_T(23)
+            RT_PROF_LANES(4)
             auto blas_leaf_fn = [&](const uint32_t blas_leaf) {
                 const int tri_start = int(blas_leaf & BVH2_PRIM_INDEX_BITS),
                           tri_end = int(tri_start + ((blas_leaf & BVH2_PRIM_COUNT_BITS) >> 29) + 1);

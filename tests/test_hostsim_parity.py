@@ -98,3 +98,20 @@ def test_layout_pass_is_exercised(lib, name):
     f = lib.lib.hostsim_layout_applied
     f.argtypes, f.restype = [ctypes.c_void_p], ctypes.c_int
     assert f(ctx._ctx) == 1
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_wide_bvh_is_bit_exact(lib, name, monkeypatch):
+    """the 4-wide quantised BLAS the GPU kernels walk (ray_amd/csrc/rt_bvh4.h): conservative boxes + the reference's own
+    slab and triangle tests must reproduce RendererRef bit for bit, hits and frames"""
+    monkeypatch.setenv("HOSTSIM_BVH4", "1")
+    g = util.golden_ref(name)
+    ctx = util.make_context(lib, name)
+    _, hits, tc = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
+    assert tc["nodes"] == 0, "the wide walk has no visit counters: a non-zero count means the BVH2 path ran"
+    util.assert_hits_identical(hits, g["primary_hits"])
+    ctx.render(1)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), g["raw_spp1"])
+    for it in range(2, 9):
+        ctx.render(it)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), g["raw_spp8"])

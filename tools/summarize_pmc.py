@@ -2,7 +2,8 @@
 import csv, glob, os, sys
 from collections import defaultdict
 out, tag, wl = sys.argv[1], sys.argv[2], sys.argv[3]
-for d in sorted(glob.glob(os.path.join(out, f"{tag}_prof_*")) + glob.glob(os.path.join(out, f"{tag}[0-9]*"))):
+dirs = set(glob.glob(os.path.join(out, f"{tag}_prof_*")) + glob.glob(os.path.join(out, f"{tag}[0-9]*")) + glob.glob(os.path.join(out, f"{tag}*")))
+for d in sorted(x for x in dirs if os.path.isdir(x)):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
         with open(f) as fh:

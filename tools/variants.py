@@ -133,6 +133,11 @@ def run1(name, workload="sponza", K=16):
                      19: "K2 node: push/pop (LDS)", 20: "K2 leaf: before tri fetch", 21: "K2 leaf: wait for first tri",
                      22: "K2 leaf: tri tests (+prefetch waits)", 23: "K2 TLAS: instance transform", 24: "K2 chunk fetch",
                      25: "K2 ray load", 26: "K2 scene walk residue", 27: "K2 store + exit"}
+            if buf[1] and "PROFILE_TRACE" in " ".join(VARIANTS[name]):
+                print(f"  lane utilisation: node visits {buf[0] / buf[1] / 64:.3f} ({buf[1]} wave-level visits), "
+                      f"triangle tests {buf[2] / max(buf[3], 1) / 64:.3f} ({buf[3]}), instance entries {buf[4] / max(buf[5], 1) / 64:.3f} ({buf[5]})")
+                for k in range(8):
+                    buf[k] = 0
             tot = float(sum(buf)) or 1.0
             print("  wave time by section:")
             for k in range(32):
