@@ -83,6 +83,17 @@ def get_scene_blob(name, wl, rank, world, barrier):
     return blob, info
 
 
+def measured_traffic(workload):
+    """HBM bytes per K2 launch from the committed rocprofv3 PMC passes (profiles/r01/k2_traffic.json: FETCH_SIZE + WRITE_SIZE,
+    collected in separate runs of this command under the profiler); None for workloads that were not profiled"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "k2_traffic.json")) as f:
+            t = json.load(f).get(workload)
+        return None if t is None else float(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(wl, budget_s=12.0):
     """reference AVX2 backend on the host cores, bounded sample of the same workload"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -229,9 +240,10 @@ def main():
                        "max_depth": int(cam.pass_settings.max_total_depth),
                        "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 RCCL reduce/frame)"},
             "roofline": {
-                "bound": "hbm", "kernel": "k_trace_closest (BVH2 closest-hit traversal, K2)",
+                "bound": "hbm", "kernel": "k_trace_closest<false,true> (closest-hit traversal, K2); algorithmic bytes = "
+                                          "reference BVH2 visit counts on the same rays (SURVEY 8d)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(args.workload),
                 "alg_bytes_per_launch": k2_bytes / max(k2_launches, 1), "avg_launch_ms": k2_ms / max(k2_launches, 1),
                 "launches": k2_launches,
                 "alg_bytes_per_ray": k2_bytes / scale / max(c2["rays"], 1),
