@@ -35,7 +35,7 @@ RT_HD TriData load_tri(const rayhip_tri_accel *tris, const uint32_t i) {
 }
 
 // CoreRef.cpp:24-50.  Same operations in the same order as the reference; the three early `return`s are folded
-// into one predicate so that no load or divide sits behind a branch (on the GPU every early-out used to cost a
+// into one predicate so that no load sits behind a branch (on the GPU every early-out used to cost a
 // dependent memory round trip: n_plane -> branch -> u_plane -> branch -> v_plane).  The speculated arithmetic is
 // discarded when the predicate fails, so accepted hits are bit-identical.
 RT_HD void intersect_tri(const f3 ro, const f3 rd, const TriData &tri, const uint32_t prim_index, Hit &inter) {
@@ -51,8 +51,8 @@ RT_HD void intersect_tri(const f3 ro, const f3 rd, const TriData &tri, const uin
     const float detv = (p0 * tri.v.x + p1 * tri.v.y + p2 * tri.v.z) + det * tri.v.w;
     ok = ok && !(RT_SIGN_OF(detv) != RT_SIGN_OF(det - detu - detv));
 
-    const float rdet = (1.0f / det);
-    if (ok) {
+    if (ok) { // rare: a whole wavefront usually skips the (correctly rounded, ~10 instruction) division
+        const float rdet = (1.0f / det);
         inter.prim_index = (det < 0.0f) ? int(prim_index) : -int(prim_index) - 1;
         inter.t = dett * rdet;
         inter.u = detu * rdet;
@@ -61,37 +61,17 @@ RT_HD void intersect_tri(const f3 ro, const f3 rd, const TriData &tri, const uin
 }
 #undef RT_SIGN_OF
 
-// CoreRef.cpp:171-210
+// CoreRef.cpp:171-210.  The reference orders (lo, hi) per axis with compare-and-swap and folds the three axes with
+// compare-and-select; written here with fminf/fmaxf, which return the same values for the finite inputs of this test
+// (they could only differ in the sign of a zero, and every consumer is a comparison) and compile to single
+// v_min_f32 / v_max_f32 / v_max3_f32 instructions instead of v_cmp + v_cndmask pairs.
 RT_HD bool bbox_test(const f3 o, const f3 inv_d, const float t, const float mn[3], const float mx[3], float &out_dist) {
-    float lo_x = inv_d.x * (mn[0] - o.x);
-    float hi_x = inv_d.x * (mx[0] - o.x);
-    if (lo_x > hi_x) {
-        const float tmp = lo_x;
-        lo_x = hi_x;
-        hi_x = tmp;
-    }
-    float lo_y = inv_d.y * (mn[1] - o.y);
-    float hi_y = inv_d.y * (mx[1] - o.y);
-    if (lo_y > hi_y) {
-        const float tmp = lo_y;
-        lo_y = hi_y;
-        hi_y = tmp;
-    }
-    float lo_z = inv_d.z * (mn[2] - o.z);
-    float hi_z = inv_d.z * (mx[2] - o.z);
-    if (lo_z > hi_z) {
-        const float tmp = lo_z;
-        lo_z = hi_z;
-        hi_z = tmp;
-    }
-    float tmin = lo_x > lo_y ? lo_x : lo_y;
-    if (lo_z > tmin) {
-        tmin = lo_z;
-    }
-    float tmax = hi_x < hi_y ? hi_x : hi_y;
-    if (hi_z < tmax) {
-        tmax = hi_z;
-    }
+    const float lo_x = inv_d.x * (mn[0] - o.x), hi_x = inv_d.x * (mx[0] - o.x);
+    const float lo_y = inv_d.y * (mn[1] - o.y), hi_y = inv_d.y * (mx[1] - o.y);
+    const float lo_z = inv_d.z * (mn[2] - o.z), hi_z = inv_d.z * (mx[2] - o.z);
+
+    const float tmin = fmaxf(fmaxf(fminf(lo_x, hi_x), fminf(lo_y, hi_y)), fminf(lo_z, hi_z));
+    float tmax = fminf(fminf(fmaxf(lo_x, hi_x), fmaxf(lo_y, hi_y)), fmaxf(lo_z, hi_z));
     tmax *= 1.00000024f;
 
     out_dist = tmin;
