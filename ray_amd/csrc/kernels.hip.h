@@ -195,6 +195,12 @@ struct RayQueue {
     }
 };
 
+// hits of importance-sampled emitters whose MIS weight is evaluated by k_shade_emissive
+struct DeferredSoA {
+    float4 *a; // ray slot, tri_index, material index (bits), mix_weight
+    float4 *b; // base_color.rgb
+};
+
 struct PixelBuffers {
     float4 *temp, *full, *half, *raw, *final_, *base_color, *depth_normals;
     uint16_t *required_samples;
@@ -387,6 +393,7 @@ template <bool PRIMARY>
 __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
                                                const HitSoA hits, const RayQueue in, const RaySoA rays_out,
                                                const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
+                                               const DeferredSoA deferred_out, const RayQueue out_deferred,
                                                const PixelBuffers px, const int img_w, const float mix_factor) {
 #ifdef RT_PROFILE_SHADE
     if (threadIdx.x < 32) {
@@ -415,7 +422,7 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
             const Hit inter = load_hit(hits, i);
             xy = ray.xy;
             RT_PROF(0)
-            res = shade_surface(sc, sp, inter, ray, new_ray, sh_r);
+            res = shade_surface<!PRIMARY>(sc, sp, inter, ray, new_ray, sh_r);
             if (PRIMARY) {
                 write_primary_pixel(res, xy, img_w, mix_factor, px.temp, px.base_color, px.depth_normals);
             } else {
@@ -432,6 +439,15 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
         if (res.emit_shadow) {
             store_shadow(shadow_out, sh_slot, sh_r);
         }
+        if (!PRIMARY && __any(active && res.defer_emissive)) { // rare
+            const bool defer = active && res.defer_emissive;
+            const uint32_t d_slot = out_deferred.alloc(stripe, defer);
+            if (defer) {
+                deferred_out.a[d_slot] = mkfloat4(uint_as_float(i), uint_as_float(res.def_tri_index), uint_as_float(res.def_mat_index),
+                                                  res.def_mix_weight);
+                deferred_out.b[d_slot] = mkfloat4(res.def_base_color.x, res.def_base_color.y, res.def_base_color.z, 0.0f);
+            }
+        }
         RT_PROF(29)
     }
 #ifdef RT_PROFILE_SHADE
@@ -440,6 +456,35 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
         atomicAdd(&g_prof_acc[threadIdx.x], s_prof_acc[threadIdx.x]);
     }
 #endif
+}
+
+// Second half of ShadeSecondary for rays that hit an importance-sampled emitter (ShadeRef.cpp:1500-1525): MIS weight
+// against NEE (light-tree walk for the pick probability + spherical-triangle pdf), then the radiance goes into the
+// pixel.  Runs right after k_shade<false> of the same bounce, on the ray / hit buffers that kernel read; such a ray has
+// neither a shadow ray nor a secondary ray, so this is the only contribution of its pixel in this bounce and the
+// per-pixel addition order of the reference is kept.
+__global__ void __launch_bounds__(WAVE) k_shade_emissive(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
+                                                        const DeferredSoA deferred, const RayQueue queue, const PixelBuffers px,
+                                                        const int img_w) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
+            continue;
+        }
+        const float4 a = deferred.a[slot0 + lane], b = deferred.b[slot0 + lane];
+        const uint32_t i = float_as_uint(a.x), tri_index = float_as_uint(a.y), mat_index = float_as_uint(a.z);
+        const float4 o = rays_in.o_pdf[i], d = rays_in.d_cw[i], rc = rays_in.c_cs[i];
+        const uint32_t xy = rays_in.xy_depth[i].x;
+        const Hit inter = load_hit(hits, i);
+        const f3 ro = {o.x, o.y, o.z}, I = {d.x, d.y, d.z};
+        const f3 P = ro + inter.t * I;
+        const float mis_weight = emissive_hit_mis_weight(sc, ro, I, P, inter.t, o.w, tri_index, &sc.mesh_instances[inter.obj_index]);
+        ShadeResult res;
+        res.col = emissive_hit_radiance(sp, a.w, mis_weight, sc.materials[mat_index].tangent_rotation_or_strength, f3{b.x, b.y, b.z},
+                                        f3{rc.x, rc.y, rc.z});
+        add_secondary_pixel(res, xy, img_w, px.temp);
+    }
 }
 
 // ---- K6 / K8: ray sort ----------------------------------------------------------------------------------------

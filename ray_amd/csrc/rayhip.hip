@@ -93,10 +93,11 @@ struct rayhip_ctx {
     PixelBuffers px = {};
 
     // wavefront state, sized w*h
-    DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3];
+    DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3], deferred_planes[2];
     RaySoA rays[2] = {};
     HitSoA hits = {};
     ShadowSoA shadow = {};
+    DeferredSoA deferred = {};
     DevBuf counters;      // uint32 [MAX_BOUNCE_SLOTS][2: rays, shadow rays][QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE]
     DevBuf trav_counters; // u64 [2][5]
     DevBuf stack_spill;   // per-wave overflow slabs of the traversal stack
@@ -118,8 +119,9 @@ struct rayhip_ctx {
     double stage_us[11] = {};
 
     static constexpr size_t QUEUE_WORDS = size_t(QUEUE_MAX_STRIPES) * QUEUE_COUNTER_STRIDE;
-    uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + size_t(2 * b) * QUEUE_WORDS; }
-    uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + size_t(2 * b + 1) * QUEUE_WORDS; }
+    uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + size_t(3 * b) * QUEUE_WORDS; }
+    uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + size_t(3 * b + 1) * QUEUE_WORDS; }
+    uint32_t *deferred_count(int b) const { return counters.as<uint32_t>() + size_t(3 * b + 2) * QUEUE_WORDS; }
     // queue geometry for a frame of `items` pixels split over `stripes` stripes
     static RayQueue make_queue(uint32_t *counts, size_t items, uint32_t stripes) {
         const size_t chunks = (items + WAVE - 1) / WAVE;
@@ -127,8 +129,9 @@ struct rayhip_ctx {
     }
     RayQueue ray_queue(int b, size_t items, uint32_t stripes) const { return make_queue(ray_count(b), items, stripes); }
     RayQueue shadow_queue(int b, size_t items, uint32_t stripes) const { return make_queue(shadow_count(b), items, stripes); }
+    RayQueue deferred_queue(int b, size_t items, uint32_t stripes) const { return make_queue(deferred_count(b), items, stripes); }
     int clear_queues(int bounces, hipStream_t s) const {
-        return hipMemsetAsync(counters.p, 0, size_t(2 * bounces) * QUEUE_WORDS * sizeof(uint32_t), s) == hipSuccess ? 0 : 1;
+        return hipMemsetAsync(counters.p, 0, size_t(3 * bounces) * QUEUE_WORDS * sizeof(uint32_t), s) == hipSuccess ? 0 : 1;
     }
 };
 
@@ -183,6 +186,10 @@ int alloc_frame(rayhip_ctx *c, int w, int h) {
     }
     c->shadow.o_depth = c->shadow_planes[0].as<float4>(), c->shadow.d_dist = c->shadow_planes[1].as<float4>();
     c->shadow.c_xy = c->shadow_planes[2].as<float4>();
+    if (c->deferred_planes[0].alloc(n * 16) || c->deferred_planes[1].alloc(n * 16)) {
+        return 1;
+    }
+    c->deferred.a = c->deferred_planes[0].as<float4>(), c->deferred.b = c->deferred_planes[1].as<float4>();
     size_t temp_bytes = 0;
     if (sort_pairs_temp_bytes(n, SORT_KEY_BITS, &temp_bytes) != hipSuccess) {
         return fail("rocPRIM temp-size query failed");
@@ -316,7 +323,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         delete c;
         return 1;
     }
-    if (c->counters.alloc(sizeof(uint32_t) * 2 * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 10)) {
+    if (c->counters.alloc(sizeof(uint32_t) * 3 * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 10)) {
         delete c;
         return 1;
     }
@@ -338,7 +345,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
                      &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->nodes4, &c->blas_root4,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
                      &c->px_dn, &c->px_req, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
-                     &c->shadow_planes[2], &c->counters, &c->trav_counters, &c->stack_spill,
+                     &c->shadow_planes[2], &c->deferred_planes[0], &c->deferred_planes[1], &c->counters, &c->trav_counters, &c->stack_spill,
                      &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->sort_temp};
     for (DevBuf *b : all) {
         b->release();
@@ -665,11 +672,16 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         if (bounce == 0) {
             k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, npix, stripes),
                                                   c->rays[cur ^ 1], c->ray_queue(bounce + 1, npix, stripes), c->shadow,
-                                                  c->shadow_queue(bounce, npix, stripes), c->px, c->w, mix_factor);
+                                                  c->shadow_queue(bounce, npix, stripes), c->deferred,
+                                                  c->deferred_queue(bounce, npix, stripes), c->px, c->w, mix_factor);
         } else {
             k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, npix, stripes),
                                                    c->rays[cur ^ 1], c->ray_queue(bounce + 1, npix, stripes), c->shadow,
-                                                   c->shadow_queue(bounce, npix, stripes), c->px, c->w, mix_factor);
+                                                   c->shadow_queue(bounce, npix, stripes), c->deferred,
+                                                   c->deferred_queue(bounce, npix, stripes), c->px, c->w, mix_factor);
+            // emitter hits whose MIS weight was deferred (kernels.hip.h); an empty queue costs a few microseconds
+            k_shade_emissive<<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred,
+                                                     c->deferred_queue(bounce, npix, stripes), c->px, c->w);
         }
         if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
             return 1;

@@ -22,7 +22,56 @@ struct ShadeResult {
     f3 base_color;   // aux outputs (only meaningful when has_aux)
     f4 depth_normal; // N.xyz, t
     bool emit_secondary, emit_shadow;
+    // DEFER_EMISSIVE builds only: the hit is an importance-sampled emitter reached by a secondary ray; its MIS weight
+    // (a light-tree walk + a spherical-triangle pdf) is left to k_shade_emissive and `col` does not contain it yet
+    bool defer_emissive;
+    uint32_t def_tri_index, def_mat_index;
+    float def_mix_weight;
+    f3 def_base_color;
 };
+
+// MIS weight of an emissive triangle hit by a BSDF-sampled ray, ShadeRef.cpp:1500-1525 (the NODE_EMISSIVE branch of
+// ShadeSurface).  Factored out so that the device can run it in a kernel of its own (k_shade_emissive): hits of
+// emitters are rare but every wavefront containing one used to pay for this path -- 15 % of the shade kernels' time.
+RT_HD float emissive_hit_mis_weight(const SceneView &sc, const f3 ro, const f3 I, const f3 P, const float inter_t, const float ray_pdf,
+                                    const uint32_t tri_index, const rayhip_mesh_instance *mi) {
+    float mis_weight = 1.0f;
+    const float pdf_factor = eval_tri_light_factor(sc, P, ro, tri_index);
+
+    const rayhip_vertex &v1 = sc.vertices[sc.vtx_indices[tri_index * 3 + 0]];
+    const rayhip_vertex &v2 = sc.vertices[sc.vtx_indices[tri_index * 3 + 1]];
+    const rayhip_vertex &v3 = sc.vertices[sc.vtx_indices[tri_index * 3 + 2]];
+    const f3 p1 = mk3(v1.p), p2 = mk3(v2.p), p3 = mk3(v3.p);
+
+    float light_forward_len;
+    const f3 light_forward = normalize_len(transform_direction(cross(p2 - p1, p3 - p1), mi->xform), light_forward_len);
+    const float tri_area = 0.5f * light_forward_len;
+
+    const float cos_theta = fabsf(dot(I, light_forward)); // abs for doublesided light
+    if (cos_theta > 0.0f) {
+        const f3 P_ls = transform_point(ro, mi->inv_xform);
+        float light_pdf = sample_spherical_triangle(P_ls, p1, p2, p3, f2{0.0f, 0.0f}, nullptr) / pdf_factor;
+        if (light_pdf == 0.0f) {
+            light_pdf = (inter_t * inter_t) / (tri_area * cos_theta * pdf_factor);
+        }
+        const float bsdf_pdf = ray_pdf;
+        mis_weight = power_heuristic(bsdf_pdf, light_pdf);
+    }
+    return mis_weight;
+}
+
+// radiance of an emissive hit and its clamp, exactly the tail ShadeSurface applies to `col` (ShadeRef.cpp:1646-1651)
+RT_HD f4 emissive_hit_radiance(const ShadeParams &sp, const float mix_weight, const float mis_weight, const float strength,
+                               const f3 base_color, const f3 ray_c) {
+    f3 col = {0.0f, 0.0f, 0.0f};
+    col += mix_weight * mis_weight * strength * base_color;
+    col *= ray_c;
+    const float sum = hsum(mk4(col, 0.0f));
+    if (sum > sp.limits[1]) {
+        col *= (sp.limits[1] / sum);
+    }
+    return mk4(col, 1.0f);
+}
 
 // ShadeRef.cpp:1030-1066
 RT_HD f4 Evaluate_EnvColor(const SceneView &sc, const Ray &ray, const float pdf_factor, const f2 rnd) {
@@ -153,6 +202,8 @@ RT_HD f3 Evaluate_LightColor(const SceneView &sc, const Ray &ray, const Hit &int
 }
 
 // Ref::ShadeSurface.  new_ray / sh_r are fully written only when the corresponding emit flag is set.
+// DEFER_EMISSIVE: see ShadeResult::defer_emissive.
+template <bool DEFER_EMISSIVE = false>
 RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, const Hit &inter, const Ray &ray, Ray &new_ray,
                                 ShadowRay &sh_r) {
     const PassLimits &ps = sp.ps;
@@ -161,6 +212,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
     res.base_color = {0.0f, 0.0f, 0.0f};
     res.depth_normal = {0.0f, 0.0f, 0.0f, 0.0f};
     res.emit_secondary = res.emit_shadow = false;
+    res.defer_emissive = false;
 
     const f3 I = ray.d;
     const f3 ro = ray.o;
@@ -427,24 +479,15 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
     } else if (mat->type == NODE_EMISSIVE) {
         float mis_weight = 1.0f;
         if ((ray.depth & 0x00ffffff) != 0 && (mat->flags & MAT_FLAG_IMP_SAMPLE)) {
-            const float pdf_factor = eval_tri_light_factor(sc, surf.P, ro, tri_index);
-
-            const f3 p1 = mk3(v1.p), p2 = mk3(v2.p), p3 = mk3(v3.p);
-
-            float light_forward_len;
-            const f3 light_forward = normalize_len(transform_direction(cross(p2 - p1, p3 - p1), mi->xform), light_forward_len);
-            const float tri_area = 0.5f * light_forward_len;
-
-            const float cos_theta = fabsf(dot(I, light_forward)); // abs for doublesided light
-            if (cos_theta > 0.0f) {
-                const f3 P = transform_point(ro, mi->inv_xform);
-                float light_pdf = sample_spherical_triangle(P, p1, p2, p3, f2{0.0f, 0.0f}, nullptr) / pdf_factor;
-                if (light_pdf == 0.0f) {
-                    light_pdf = (inter.t * inter.t) / (tri_area * cos_theta * pdf_factor);
-                }
-
-                const float bsdf_pdf = ray.pdf;
-                mis_weight = power_heuristic(bsdf_pdf, light_pdf);
+            if (DEFER_EMISSIVE) {
+                res.defer_emissive = true;
+                res.def_tri_index = tri_index;
+                res.def_mat_index = uint32_t(mat - sc.materials);
+                res.def_mix_weight = mix_weight;
+                res.def_base_color = base_color;
+                mis_weight = 0.0f; // nothing is added here; k_shade_emissive adds the weighted radiance
+            } else {
+                mis_weight = emissive_hit_mis_weight(sc, ro, I, surf.P, inter.t, ray.pdf, tri_index, mi);
             }
         }
         col += mix_weight * mis_weight * mat->tangent_rotation_or_strength * base_color;
