@@ -306,7 +306,10 @@ RT_HD LNodeChild decode_lnode_child(const rayhip_light_cwbvh_node &n, const int 
 // importance of one child as seen from P
 RT_HD float lnode_child_importance(const LNodeChild &ch, const f3 P) {
     float imp = ch.cosines.w;
-    if (ch.pc_valid.w != 0.0f) {
+    // (zero flux -- an empty slot or a black light -- stays zero whatever the geometric term: 0 * mul, mul finite
+    // unless P sits exactly on a degenerate box; skipping it lets a wavefront whose lanes are all at sparsely filled
+    // nodes, e.g. the root, jump over the slot)
+    if (ch.pc_valid.w != 0.0f && imp != 0.0f) {
         const float ax = ch.axis_extent.x, ay = ch.axis_extent.y, az = ch.axis_extent.z, extent = ch.axis_extent.w;
         float wi[3] = {P.x - ch.pc_valid.x, P.y - ch.pc_valid.y, P.z - ch.pc_valid.z};
         const float dist2 = wi[0] * wi[0] + wi[1] * wi[1] + wi[2] * wi[2];
@@ -424,10 +427,17 @@ RT_HD void sample_light_source(const SceneView &sc, const f3 P, const f3 T, cons
             for (int j = 1; j < 9; ++j) {
                 next += (factors_cdf[j] <= u1) ? 1 : 0;
             }
+            // factors_cdf[next], factors[next] through selects: with a run-time index the three arrays would have to
+            // live in scratch memory (8 + 9 + 8 stores and the loads back, per tree level)
+            float cdf_next = factors_cdf[0], factor_next = factors[0];
+            for (int j = 1; j < 8; ++j) {
+                cdf_next = (next == j) ? factors_cdf[j] : cdf_next;
+                factor_next = (next == j) ? factors[j] : factor_next;
+            }
 
-            u1 = fractf((u1 - factors_cdf[next]) / factors[next]);
+            u1 = fractf((u1 - cdf_next) / factor_next);
             i = node.child[next];
-            factor *= factors[next];
+            factor *= factor_next;
         }
         light_index = (i & PRIM_INDEX_BITS);
         factor = 1.0f / factor;
