@@ -96,7 +96,7 @@ namespace rt {
 #define RT_TRACE_MIN_WAVES 5 // 96 VGPRs: the 4-wide node visit spills badly at 80 (6 waves: K2 7.9 ms vs 5.7 ms at 5 or 4)
 #endif
 #ifndef RT_SHADE_MIN_WAVES
-#define RT_SHADE_MIN_WAVES 1
+#define RT_SHADE_MIN_WAVES 3 // 168 VGPRs (80 B scratch): 2.98 ms/frame vs 3.17 at 201 VGPRs / 2 waves and at 128 / 4 waves
 #endif
 constexpr int WAVE = 64;
 constexpr int LDS_STACK_DEPTH = RT_LDS_STACK_DEPTH;
