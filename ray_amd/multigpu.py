@@ -38,6 +38,10 @@ def render_sharded(ctx: hip.Context, iterations: Iterable[int], rank: int, world
         import torch
         frame.copy_(torch.from_numpy(ctx.readback(hip.BUF_RAW)))
     dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+    if frame.is_cuda:
+        # the collective is only enqueued (torch stream); librayhip works on its own stream, so wait for it here
+        import torch
+        torch.cuda.current_stream(frame.device).synchronize()
     if rank == 0 and frame.is_cuda:
         ctx.set_raw_device(frame.data_ptr())
     return frame
