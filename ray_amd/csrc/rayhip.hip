@@ -680,7 +680,7 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
                                                    c->shadow_queue(bounce, npix, stripes), c->deferred,
                                                    c->deferred_queue(bounce, npix, stripes), c->px, c->w, mix_factor);
             // emitter hits whose MIS weight was deferred (kernels.hip.h); an empty queue costs a few microseconds
-            k_shade_emissive<<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred,
+            k_shade_emissive<<<std::min(gtrace, 2048), WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred,
                                                      c->deferred_queue(bounce, npix, stripes), c->px, c->w);
         }
         if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
