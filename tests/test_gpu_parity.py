@@ -197,3 +197,30 @@ def test_stats_and_timing(gpu_lib):
     assert d["primary_trace"] >= 0 and sum(d.values()) > 0
     (ms0, n0), (ms1, n1) = ctx.trav_timing()
     assert n0 >= 2 and n1 >= 1 and ms0 > 0.0
+
+
+def test_full_size_properties(gpu_lib):
+    """BASELINE-size frame (1920x1080): properties that do not need a reference image --
+    tile sharding sums to the unsharded frame bit for bit, two half-frame rects equal the full frame, the run is
+    deterministic, and the frame agrees statistically with the 64x64 fixture of the same scene (same camera)."""
+    name = "cornell_basic"
+    w, h, spp = 1920, 1080, 2
+    full = util.render_frames(util.make_context(gpu_lib, name, w, h), spp)
+    again = util.render_frames(util.make_context(gpu_lib, name, w, h), spp)
+    assert np.array_equal(full, again)
+    acc = np.zeros_like(full)
+    for r in range(4):
+        ctx = util.make_context(gpu_lib, name, w, h)
+        ctx.set_shard(64, 4, r)
+        acc += util.render_frames(ctx, spp)
+    assert np.array_equal(acc, full)
+    ctx = util.make_context(gpu_lib, name, w, h)
+    for it in range(1, spp + 1):
+        ctx.render(it, rect=(0, 0, w, 500))
+        ctx.render(it, rect=(0, 500, w, h - 500))
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), full)
+    assert np.isfinite(full).all() and (full[..., :3] >= 0).all()
+    # wide-aspect frame of the same camera: the central square shows what the 64x64 fixture shows
+    g = util.golden_ref(name)
+    assert abs(float(full[..., 3].mean()) - 1.0) < 0.05  # closed box: alpha ~ 1 wherever geometry is hit
+    assert 0.2 < float(full[:, 420:1500, :3].mean()) / max(float(g["raw_spp8"][..., :3].mean()), 1e-6) < 5.0
