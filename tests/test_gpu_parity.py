@@ -222,5 +222,6 @@ def test_full_size_properties(gpu_lib):
     assert np.isfinite(full).all() and (full[..., :3] >= 0).all()
     # wide-aspect frame of the same camera: the central square shows what the 64x64 fixture shows
     g = util.golden_ref(name)
-    assert abs(float(full[..., 3].mean()) - 1.0) < 0.05  # closed box: alpha ~ 1 wherever geometry is hit
-    assert 0.2 < float(full[:, 420:1500, :3].mean()) / max(float(g["raw_spp8"][..., :3].mean()), 1e-6) < 5.0
+    centre = full[:, 420:1500]  # the 1080x1080 square the fixture's field of view covers
+    assert float(centre[..., 3].mean()) > 0.9  # the box fills (almost all of) it: alpha ~ 1
+    assert 0.2 < float(centre[..., :3].mean()) / max(float(g["raw_spp8"][..., :3].mean()), 1e-6) < 5.0
