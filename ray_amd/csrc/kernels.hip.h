@@ -211,14 +211,16 @@ __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint
                                                const float *__restrict__ filter_table,
                                                const uint16_t *__restrict__ required_samples, const RaySoA rays,
                                                const HitSoA hits, const RayQueue out) {
-    const int n = p.rect[2] * p.rect[3];
-    const uint32_t n_chunks = uint32_t((n + WAVE - 1) / WAVE), waves_per_block = blockDim.x / WAVE;
+    // one wavefront = one 8x8 pixel tile: primary rays of a wave start coherent in both directions, so they share
+    // BVH nodes in K2 and materials in the primary shade (a 64x1 strip only is coherent along x)
+    const uint32_t tiles_x = uint32_t(p.rect[2] + 7) / 8u, tiles_y = uint32_t(p.rect[3] + 7) / 8u;
+    const uint32_t n_chunks = tiles_x * tiles_y, waves_per_block = blockDim.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
     // pixel chunk pc -> stripe pc % stripes: every stripe gets at most ceil(n_chunks / stripes) chunks
     for (uint32_t pc = blockIdx.x * waves_per_block + threadIdx.x / WAVE; pc < n_chunks; pc += gridDim.x * waves_per_block) {
-        const int i = int(pc * WAVE + lane);
-        const bool in_rect = i < n;
-        const int x = p.rect[0] + (in_rect ? i % p.rect[2] : 0), y = p.rect[1] + (in_rect ? i / p.rect[2] : 0);
+        const int lx = int((pc % tiles_x) * 8u + (lane & 7u)), ly = int((pc / tiles_x) * 8u + (lane >> 3));
+        const bool in_rect = lx < p.rect[2] && ly < p.rect[3];
+        const int x = p.rect[0] + (in_rect ? lx : 0), y = p.rect[1] + (in_rect ? ly : 0);
         const bool live = in_rect && pixel_owned(p.shard, p.w, x, y) && !(required_samples[y * p.w + x] < p.iteration);
         const uint32_t slot = out.alloc(pc % out.stripes, live);
         if (live) {

@@ -152,6 +152,9 @@ int use_device(rayhip_ctx *c) {
     return 0;
 }
 
+// wavefront-state slots a w x h rect needs: ray generation deals whole 8x8 pixel tiles (k_raygen)
+size_t tile_slots(int w, int h) { return size_t((w + 7) / 8) * size_t((h + 7) / 8) * 64u; }
+
 int alloc_frame(rayhip_ctx *c, int w, int h) {
     const size_t npix = size_t(w) * size_t(h);
     if (c->px_temp.alloc(npix * 16) || c->px_full.alloc(npix * 16) || c->px_half.alloc(npix * 16) || c->px_raw.alloc(npix * 16) ||
@@ -164,7 +167,7 @@ int alloc_frame(rayhip_ctx *c, int w, int h) {
     c->px.required_samples = c->px_req.as<uint16_t>();
 
     // wavefront-state slots: one per pixel + the rounding of the striped queues (each stripe holds whole chunks)
-    const size_t n = npix + size_t(WAVE) * QUEUE_MAX_STRIPES;
+    const size_t n = tile_slots(w, h) + size_t(WAVE) * QUEUE_MAX_STRIPES;
     for (int k = 0; k < 2; ++k) {
         for (int pl = 0; pl < 5; ++pl) {
             if (c->ray_planes[k][pl].alloc(n * (pl == 4 ? 8 : 16))) {
@@ -600,8 +603,9 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
     const bool sort_rays = (flags & RAYHIP_FLAG_SORT_RAYS) != 0;
     hipStream_t s = c->stream;
     const size_t npix = size_t(rect[2]) * size_t(rect[3]);
+    const size_t nslots = tile_slots(rect[2], rect[3]); // ray slots of this rect (whole 8x8 tiles)
     const int gw = c->grid_waves;
-    const int gtrace = int(std::min<size_t>(size_t(gw), (npix + WAVE - 1) / WAVE));
+    const int gtrace = int(std::min<size_t>(size_t(gw), nslots / WAVE));
     unsigned long long *tc = c->trav_counters.as<unsigned long long>();
     uint32_t *spill = c->stack_spill.as<uint32_t>();
     const TraceParams tp_ = make_trace_params(*cam, c->sc.tlas_root, iteration);
@@ -632,13 +636,13 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
     if (tm.mark(ST_GEN, -1)) {
         return 1;
     }
-    k_raygen<<<grid_for(c, npix, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
-                                                    c->rays[0], c->hits, c->ray_queue(0, npix, stripes));
+    k_raygen<<<grid_for(c, nslots, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
+                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, stripes));
     if (tm.mark(ST_PTRACE, 0)) {
         return 1;
     }
     if (c->sc.tlas_root != 0xffffffffu) {
-        launch_closest(c->rays[0], c->ray_queue(0, npix, stripes), 0);
+        launch_closest(c->rays[0], c->ray_queue(0, nslots, stripes), 0);
     }
     int cur = 0;
     for (int bounce = 0; bounce <= max_depth; ++bounce) {
@@ -660,9 +664,9 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
             if (tm.mark(ST_STRACE, 0)) {
                 return 1;
             }
-            launch_closest(c->rays[cur], c->ray_queue(bounce, npix, stripes), 1);
+            launch_closest(c->rays[cur], c->ray_queue(bounce, nslots, stripes), 1);
             if (c->sc.visible_lights_count != 0) {
-                k_intersect_area_lights<<<gtrace, WAVE, 0, s>>>(c->sc, c->rays[cur], c->hits, c->ray_queue(bounce, npix, stripes));
+                k_intersect_area_lights<<<gtrace, WAVE, 0, s>>>(c->sc, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes));
             }
         }
         if (tm.mark(bounce == 0 ? ST_PSHADE : ST_SSHADE, -1)) {
@@ -670,34 +674,34 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         }
         const ShadeParams sp = make_shade_params(*cam, iteration, bounce);
         if (bounce == 0) {
-            k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, npix, stripes),
-                                                  c->rays[cur ^ 1], c->ray_queue(bounce + 1, npix, stripes), c->shadow,
-                                                  c->shadow_queue(bounce, npix, stripes), c->deferred,
-                                                  c->deferred_queue(bounce, npix, stripes), c->px, c->w, mix_factor);
+            k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
+                                                  c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
+                                                  c->shadow_queue(bounce, nslots, stripes), c->deferred,
+                                                  c->deferred_queue(bounce, nslots, stripes), c->px, c->w, mix_factor);
         } else {
-            k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, npix, stripes),
-                                                   c->rays[cur ^ 1], c->ray_queue(bounce + 1, npix, stripes), c->shadow,
-                                                   c->shadow_queue(bounce, npix, stripes), c->deferred,
-                                                   c->deferred_queue(bounce, npix, stripes), c->px, c->w, mix_factor);
+            k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
+                                                   c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
+                                                   c->shadow_queue(bounce, nslots, stripes), c->deferred,
+                                                   c->deferred_queue(bounce, nslots, stripes), c->px, c->w, mix_factor);
             // emitter hits whose MIS weight was deferred (kernels.hip.h); an empty queue costs a few microseconds
             k_shade_emissive<<<std::min(gtrace, 2048), WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred,
-                                                     c->deferred_queue(bounce, npix, stripes), c->px, c->w);
+                                                     c->deferred_queue(bounce, nslots, stripes), c->px, c->w);
         }
         if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
             return 1;
         }
         const float limit = shadow_clamp_limit(*cam, bounce);
         if (c->sc.blocker_lights_count != 0) {
-            k_shadow_blockers<<<gtrace, WAVE, 0, s>>>(c->sc, c->shadow, c->shadow_queue(bounce, npix, stripes));
+            k_shadow_blockers<<<gtrace, WAVE, 0, s>>>(c->sc, c->shadow, c->shadow_queue(bounce, nslots, stripes));
         }
         if (count) {
-            k_trace_shadow<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit,
+            k_trace_shadow<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
                                                                 c->w, c->px.temp, nullptr, spill, tc + 5);
         } else if (c->sc.nodes4) {
-            k_trace_shadow<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit,
+            k_trace_shadow<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
                                                                 c->w, c->px.temp, nullptr, spill, tc + 5);
         } else {
-            k_trace_shadow<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, npix, stripes), limit,
+            k_trace_shadow<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
                                                                  c->w, c->px.temp, nullptr, spill, tc + 5);
         }
         cur ^= 1;
@@ -855,14 +859,14 @@ int rayhip_k_generate_primary_rays(rayhip_ctx *c, const rayhip_camera *cam, cons
         return fail("k_generate_primary_rays needs resize + upload_static + set_filter_table first");
     }
     hipStream_t s = c->stream;
-    const size_t npix = size_t(rect[2]) * size_t(rect[3]);
+    const size_t nslots = tile_slots(rect[2], rect[3]);
     if (c->clear_queues(1, s)) {
         return fail("queue counter clear failed");
     }
     const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
     // kernel-level hooks use one dense stripe so that the host sees a plain array
-    k_raygen<<<grid_for(c, npix, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
-                                                    c->rays[0], c->hits, c->ray_queue(0, npix, 1));
+    k_raygen<<<grid_for(c, nslots, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
+                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, 1));
     HIP_TRY(hipGetLastError());
     uint32_t n = 0;
     HIP_TRY(hipMemcpyAsync(&n, c->ray_count(0), 4, hipMemcpyDeviceToHost, s));
