@@ -169,10 +169,14 @@ def main():
     ctx.set_shard(TILE, world, rank)
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
 
+    batch = int(os.environ.get("RAY_AMD_BATCH", "0")) or multigpu.batch_size(W * H // world)
     it = 0
-    for _ in range(Wm):
-        it += 1
-        ctx.render(it)
+    if Wm > 0:  # untimed warm-up with the same pass shape (allocates the layered buffers)
+        done = 0
+        while done < Wm:
+            n = min(batch, Wm - done)
+            ctx.render_batch(it + 1, n)
+            it, done = it + n, done + n
     if world > 1:  # warm the communicator too
         ctx.readback_device(hip.BUF_RAW, frame.data_ptr())
         dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
@@ -185,7 +189,7 @@ def main():
     t0 = time.perf_counter()
     # K iterations of this rank's tiles + (N>1) the one exchange step of the path: the frame reduce over RCCL/xGMI
     multigpu.render_sharded(ctx, range(it + 1, it + 1 + K), rank, world, dist=dist, frame=frame,
-                            flags=hip.FLAG_TIME_STAGES, tile=TILE)
+                            flags=hip.FLAG_TIME_STAGES, tile=TILE, batch=batch)
     it += K
     ctx.sync()
     torch.cuda.synchronize()
@@ -238,7 +242,8 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['label']}, {W}x{H}, {K} spp", "width": W, "height": H,
                        "spp": K, "unique_tris": info["tris"], "bvh_tris": info["bvh_tris"], "bvh2_nodes": info["nodes"],
                        "max_depth": int(cam.pass_settings.max_total_depth),
-                       "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 RCCL reduce/frame)"},
+                       "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 RCCL reduce/frame)",
+                       "iterations_per_pass": batch},
             "roofline": {
                 "bound": "hbm", "kernel": "k_trace_closest<false,true> (closest-hit traversal, K2); algorithmic bytes = "
                                           "reference BVH2 visit counts on the same rays (SURVEY 8d)",

@@ -319,6 +319,12 @@ RAYHIP_API int rayhip_set_filter_table(rayhip_ctx *ctx, const float *table, int 
  * The call returns when the work is enqueued unless stats != NULL (then it synchronises). */
 RAYHIP_API int rayhip_render(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int iteration,
                              uint32_t flags, rayhip_stats *stats);
+/* The same for `count` consecutive iterations first_iteration .. first_iteration + count - 1 of the rect -- what `count`
+ * RenderScene calls with an unchanged scene and camera produce, bit for bit -- but up to 32 of them share one
+ * wavefront pass (more rays per launch: small frames and tile shards fill the GPU).  Falls back to one pass per
+ * iteration when adaptive sampling is active (variance_threshold != 0) or RAYHIP_FLAG_SORT_RAYS is set. */
+RAYHIP_API int rayhip_render_batch(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int first_iteration,
+                                   int count, uint32_t flags, rayhip_stats *stats);
 
 /* Multi-GPU tile sharding (new): this context renders only the pixels of the tile x tile
  * squares (row-major walk over the frame) whose ordinal % shard_count == shard_index; all other pixels of its

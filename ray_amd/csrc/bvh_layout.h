@@ -23,6 +23,28 @@
 
 namespace rayhip_layout {
 
+// rayhip_bvh2_node / rayhip_tri_accel are declared 16-byte aligned (the kernels fetch them with 128-bit loads), but the
+// C ABI takes the reference's own arrays, and its SparseStorage only guarantees alignof(T) = 4.  Host code that reads
+// the structs by value (the layout pass, the 4-wide collapse) must not see a misaligned pointer: this view re-homes
+// the two arrays when needed.
+struct AlignedDesc {
+    rayhip_scene_desc d;
+    std::vector<rayhip_bvh2_node> nodes;
+    std::vector<rayhip_tri_accel> tris;
+    explicit AlignedDesc(const rayhip_scene_desc &in) : d(in) {
+        if ((reinterpret_cast<uintptr_t>(in.nodes) & 15u) != 0 && in.nodes_count) {
+            nodes.resize(in.nodes_count);
+            memcpy(static_cast<void *>(nodes.data()), static_cast<const void *>(in.nodes), size_t(in.nodes_count) * sizeof(rayhip_bvh2_node));
+            d.nodes = nodes.data();
+        }
+        if ((reinterpret_cast<uintptr_t>(in.tris) & 15u) != 0 && in.tris_count) {
+            tris.resize(in.tris_count);
+            memcpy(static_cast<void *>(tris.data()), static_cast<const void *>(in.tris), size_t(in.tris_count) * sizeof(rayhip_tri_accel));
+            d.tris = tris.data();
+        }
+    }
+};
+
 constexpr uint32_t PRIM_COUNT_BITS = 7u << 29;
 constexpr uint32_t PRIM_INDEX_BITS = ~PRIM_COUNT_BITS;
 constexpr uint32_t NONE = 0xffffffffu;

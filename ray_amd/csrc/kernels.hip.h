@@ -202,31 +202,57 @@ struct DeferredSoA {
 };
 
 struct PixelBuffers {
-    float4 *temp, *full, *half, *raw, *final_, *base_color, *depth_normals;
+    float4 *temp; // [layers][h][w]: radiance of the iteration(s) in flight
+    float4 *full, *half, *raw, *final_, *base_color, *depth_normals;
     uint16_t *required_samples;
+    float4 *aux_base_layers, *aux_dn_layers; // [layers][h][w], batched passes only (rt_pixel.h)
 };
+
+// per-layer part of AccumParams for a batched pass
+struct AccumLayer {
+    int iteration;
+    float mix_factor, half_mix_factor;
+    int is_class_a;
+    float variance_threshold;
+};
+constexpr int MAX_BATCH = 32;
+struct AccumLayers {
+    AccumLayer l[MAX_BATCH];
+};
+
+__device__ __forceinline__ uint32_t layer_rand_seed(const int iteration) { return hash(uint32_t((iteration - 1) / RAND_SAMPLES_COUNT)); }
 
 // ---- K1 ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint32_t *__restrict__ pmj,
                                                const float *__restrict__ filter_table,
                                                const uint16_t *__restrict__ required_samples, const RaySoA rays,
-                                               const HitSoA hits, const RayQueue out) {
+                                               const HitSoA hits, const RayQueue out, const Layering layers) {
     // one wavefront = one 8x8 pixel tile: primary rays of a wave start coherent in both directions, so they share
     // BVH nodes in K2 and materials in the primary shade (a 64x1 strip only is coherent along x)
     const uint32_t tiles_x = uint32_t(p.rect[2] + 7) / 8u, tiles_y = uint32_t(p.rect[3] + 7) / 8u;
-    const uint32_t n_chunks = tiles_x * tiles_y, waves_per_block = blockDim.x / WAVE;
+    const uint32_t tiles = tiles_x * tiles_y, n_chunks = tiles * uint32_t(layers.count), waves_per_block = blockDim.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
     // pixel chunk pc -> stripe pc % stripes: every stripe gets at most ceil(n_chunks / stripes) chunks
     for (uint32_t pc = blockIdx.x * waves_per_block + threadIdx.x / WAVE; pc < n_chunks; pc += gridDim.x * waves_per_block) {
-        const int lx = int((pc % tiles_x) * 8u + (lane & 7u)), ly = int((pc / tiles_x) * 8u + (lane >> 3));
+        const uint32_t layer = pc / tiles, tile = pc % tiles; // wave-uniform
+        const int lx = int((tile % tiles_x) * 8u + (lane & 7u)), ly = int((tile / tiles_x) * 8u + (lane >> 3));
         const bool in_rect = lx < p.rect[2] && ly < p.rect[3];
         const int x = p.rect[0] + (in_rect ? lx : 0), y = p.rect[1] + (in_rect ? ly : 0);
+        // (a batch is only formed when adaptive sampling is inert, so the check of the first iteration holds for all)
         const bool live = in_rect && pixel_owned(p.shard, p.w, x, y) && !(required_samples[y * p.w + x] < p.iteration);
         const uint32_t slot = out.alloc(pc % out.stripes, live);
         if (live) {
             Ray r;
             Hit h;
-            generate_primary_ray(p, pmj, filter_table, x, y, r, h);
+            if (layer == 0) {
+                generate_primary_ray(p, pmj, filter_table, x, y, r, h);
+            } else {
+                RayGenParams pl = p;
+                pl.iteration = p.iteration + int(layer);
+                pl.rand_seed = layer_rand_seed(pl.iteration);
+                generate_primary_ray(pl, pmj, filter_table, x, y, r, h);
+                r.xy += layer * uint32_t(layers.frame_h);
+            }
             store_ray(rays, slot, r);
             store_hit(hits, slot, h);
         }
@@ -240,7 +266,7 @@ template <bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest(const SceneView sc, const TraceParams tp, const RaySoA rays,
                                                        const HitSoA hits, const RayQueue queue,
                                                        const int init_hits, uint32_t *__restrict__ stack_spill,
-                                                       unsigned long long *__restrict__ counters) {
+                                                       unsigned long long *__restrict__ counters, const Layering layers) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t lane = threadIdx.x;
 #ifdef RT_PROFILE_TRACE
@@ -279,7 +305,17 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest(cons
         st.size = 0;
         TravCount tc = {0, 0, 0, 0};
         RT_PROF_T(25)
-        intersect_scene_closest<WIDE>(sc, tp, r, h, st, COUNT ? &tc : nullptr);
+        const uint32_t xy_virtual = r.xy, layer = xy_layer(xy_virtual, layers);
+        if (layer == 0) {
+            intersect_scene_closest<WIDE>(sc, tp, r, h, st, COUNT ? &tc : nullptr);
+        } else { // a later iteration of the batch: its own sample index / seed, random numbers keyed by the real pixel
+            TraceParams tpl = tp;
+            tpl.iteration = tp.iteration + int(layer);
+            tpl.rand_seed = layer_rand_seed(tpl.iteration);
+            r.xy = xy_real(xy_virtual, layers, layer);
+            intersect_scene_closest<WIDE>(sc, tpl, r, h, st, COUNT ? &tc : nullptr);
+            r.xy = xy_virtual;
+        }
         RT_PROF_T(26)
 
         store_hit(hits, i, h);
@@ -315,7 +351,7 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const
                                                       const int img_w, float4 *__restrict__ temp_buf,
                                                       float4 *__restrict__ out_rc, /* test hook, may be null */
                                                       uint32_t *__restrict__ stack_spill,
-                                                      unsigned long long *__restrict__ counters) {
+                                                      unsigned long long *__restrict__ counters, const Layering layers) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t lane = threadIdx.x;
     for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
@@ -330,7 +366,18 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const
         st.spill_base = stack_spill + size_t(blockIdx.x) * size_t(STACK_SPILL_DEPTH * WAVE) + lane;
         st.size = 0;
         TravCount tc = {0, 0, 0, 0};
-        const f3 rc = intersect_scene_shadow<WIDE>(sc, tp, r, st, COUNT ? &tc : nullptr);
+        f3 rc;
+        const uint32_t layer = xy_layer(r.xy, layers);
+        if (layer == 0) {
+            rc = intersect_scene_shadow<WIDE>(sc, tp, r, st, COUNT ? &tc : nullptr);
+        } else {
+            TraceParams tpl = tp;
+            tpl.iteration = tp.iteration + int(layer);
+            tpl.rand_seed = layer_rand_seed(tpl.iteration);
+            ShadowRay rl = r;
+            rl.xy = xy_real(r.xy, layers, layer);
+            rc = intersect_scene_shadow<WIDE>(sc, tpl, rl, st, COUNT ? &tc : nullptr);
+        }
         if (out_rc) {
             out_rc[i] = mkfloat4(rc.x, rc.y, rc.z, 0.0f);
         } else {
@@ -396,7 +443,8 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
                                                const HitSoA hits, const RayQueue in, const RaySoA rays_out,
                                                const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
                                                const DeferredSoA deferred_out, const RayQueue out_deferred,
-                                               const PixelBuffers px, const int img_w, const float mix_factor) {
+                                               const PixelBuffers px, const int img_w, const float mix_factor,
+                                               const Layering layers) {
 #ifdef RT_PROFILE_SHADE
     if (threadIdx.x < 32) {
         s_prof_acc[threadIdx.x] = 0;
@@ -420,13 +468,27 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
         res.emit_secondary = res.emit_shadow = false;
         uint32_t xy = 0;
         if (active) {
-            const Ray ray = load_ray(rays_in, i);
+            Ray ray = load_ray(rays_in, i);
             const Hit inter = load_hit(hits, i);
-            xy = ray.xy;
+            xy = ray.xy; // virtual (layered) pixel: what the pixel writes and the spawned rays carry
             RT_PROF(0)
-            res = shade_surface<!PRIMARY>(sc, sp, inter, ray, new_ray, sh_r);
+            const uint32_t layer = xy_layer(xy, layers);
+            if (layer == 0) {
+                res = shade_surface<!PRIMARY>(sc, sp, inter, ray, new_ray, sh_r);
+            } else {
+                ShadeParams spl = sp;
+                spl.iteration = sp.iteration + int(layer);
+                spl.rand_seed = layer_rand_seed(spl.iteration);
+                ray.xy = xy_real(xy, layers, layer);
+                res = shade_surface<!PRIMARY>(sc, spl, inter, ray, new_ray, sh_r);
+                new_ray.xy = xy, sh_r.xy = xy;
+            }
             if (PRIMARY) {
-                write_primary_pixel(res, xy, img_w, mix_factor, px.temp, px.base_color, px.depth_normals);
+                if (layers.count > 1) {
+                    write_primary_pixel_layered(res, xy, img_w, px.temp, px.aux_base_layers, px.aux_dn_layers);
+                } else {
+                    write_primary_pixel(res, xy, img_w, mix_factor, px.temp, px.base_color, px.depth_normals);
+                }
             } else {
                 add_secondary_pixel(res, xy, img_w, px.temp);
             }
@@ -519,14 +581,34 @@ __global__ void __launch_bounds__(256) k_reorder_rays(const RaySoA src, const Ra
 }
 
 // ---- K10 + K11 ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_accumulate(const AccumParams p, const PixelBuffers px) {
+__global__ void __launch_bounds__(256) k_accumulate(const AccumParams p, const PixelBuffers px, const Layering layers,
+                                                   const AccumLayers per_layer) {
     const int n = p.rect[2] * p.rect[3];
+    const size_t layer_px = size_t(p.w) * size_t(layers.frame_h);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int x = p.rect[0] + i % p.rect[2], y = p.rect[1] + i / p.rect[2];
         if (!pixel_owned(p.shard, p.w, x, y)) {
             continue; // another rank's pixel: stays zero here, filled in by the frame reduce
         }
-        accumulate_pixel(p, x, y, px.temp, px.full, px.half, px.raw, px.final_, px.required_samples);
+        if (layers.count <= 1) {
+            accumulate_pixel(p, x, y, px.temp, px.temp, px.full, px.half, px.raw, px.final_, px.required_samples);
+            continue;
+        }
+        // batched pass: fold the layers into the running means in iteration order (what one call per iteration does)
+        const int idx = y * p.w + x;
+        for (int l = 0; l < layers.count; ++l) {
+            AccumParams pl = p;
+            pl.iteration = per_layer.l[l].iteration;
+            pl.mix_factor = per_layer.l[l].mix_factor, pl.half_mix_factor = per_layer.l[l].half_mix_factor;
+            pl.is_class_a = per_layer.l[l].is_class_a, pl.variance_threshold = per_layer.l[l].variance_threshold;
+            // (a one-by-one run samples the pixel in this iteration iff the previous accumulate left it queued)
+            if (!(px.required_samples[idx] < pl.iteration)) {
+                blend_aux_pixel(idx, px.aux_base_layers[size_t(l) * layer_px + idx], px.aux_dn_layers[size_t(l) * layer_px + idx],
+                                pl.mix_factor, px.base_color, px.depth_normals);
+            }
+            accumulate_pixel(pl, x, y, px.temp + size_t(l) * layer_px, px.temp, px.full, px.half, px.raw, px.final_,
+                             px.required_samples);
+        }
     }
 }
 

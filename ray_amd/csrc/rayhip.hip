@@ -89,7 +89,8 @@ struct rayhip_ctx {
 
     // frame
     int w = 0, h = 0;
-    DevBuf px_temp, px_full, px_half, px_raw, px_final, px_base, px_dn, px_req;
+    DevBuf px_temp, px_full, px_half, px_raw, px_final, px_base, px_dn, px_req, px_aux_base, px_aux_dn;
+    int layers_cap = 1; // iterations a batched pass can hold with the current buffers (rayhip_render_batch grows it)
     PixelBuffers px = {};
 
     // wavefront state, sized w*h
@@ -155,9 +156,10 @@ int use_device(rayhip_ctx *c) {
 // wavefront-state slots a w x h rect needs: ray generation deals whole 8x8 pixel tiles (k_raygen)
 size_t tile_slots(int w, int h) { return size_t((w + 7) / 8) * size_t((h + 7) / 8) * 64u; }
 
-int alloc_frame(rayhip_ctx *c, int w, int h) {
+int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
     const size_t npix = size_t(w) * size_t(h);
-    if (c->px_temp.alloc(npix * 16) || c->px_full.alloc(npix * 16) || c->px_half.alloc(npix * 16) || c->px_raw.alloc(npix * 16) ||
+    if (c->px_temp.alloc(npix * 16 * size_t(layers)) ||
+        (layers > 1 && (c->px_aux_base.alloc(npix * 16 * size_t(layers)) || c->px_aux_dn.alloc(npix * 16 * size_t(layers)))) || c->px_full.alloc(npix * 16) || c->px_half.alloc(npix * 16) || c->px_raw.alloc(npix * 16) ||
         c->px_final.alloc(npix * 16) || c->px_base.alloc(npix * 16) || c->px_dn.alloc(npix * 16) || c->px_req.alloc(npix * 2)) {
         return 1;
     }
@@ -165,9 +167,11 @@ int alloc_frame(rayhip_ctx *c, int w, int h) {
     c->px.raw = c->px_raw.as<float4>(), c->px.final_ = c->px_final.as<float4>();
     c->px.base_color = c->px_base.as<float4>(), c->px.depth_normals = c->px_dn.as<float4>();
     c->px.required_samples = c->px_req.as<uint16_t>();
+    c->px.aux_base_layers = c->px_aux_base.as<float4>(), c->px.aux_dn_layers = c->px_aux_dn.as<float4>();
+    c->layers_cap = layers;
 
     // wavefront-state slots: one per pixel + the rounding of the striped queues (each stripe holds whole chunks)
-    const size_t n = tile_slots(w, h) + size_t(WAVE) * QUEUE_MAX_STRIPES;
+    const size_t n = tile_slots(w, h) * size_t(layers) + size_t(WAVE) * QUEUE_MAX_STRIPES;
     for (int k = 0; k < 2; ++k) {
         for (int pl = 0; pl < 5; ++pl) {
             if (c->ray_planes[k][pl].alloc(n * (pl == 4 ? 8 : 16))) {
@@ -347,7 +351,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
     DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
                      &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->nodes4, &c->blas_root4,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
-                     &c->px_dn, &c->px_req, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
+                     &c->px_dn, &c->px_req, &c->px_aux_base, &c->px_aux_dn, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
                      &c->shadow_planes[2], &c->deferred_planes[0], &c->deferred_planes[1], &c->counters, &c->trav_counters, &c->stack_spill,
                      &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->sort_temp};
     for (DevBuf *b : all) {
@@ -393,7 +397,7 @@ int rayhip_resize(rayhip_ctx *c, int w, int h) {
         return 0;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (alloc_frame(c, w, h)) {
+    if (alloc_frame(c, w, h, c->layers_cap)) {
         return 1;
     }
     c->w = w, c->h = h;
@@ -426,10 +430,18 @@ int rayhip_clear(rayhip_ctx *c, const float rgba[4]) {
     return 0;
 }
 
-int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
+#define UPLOAD_TRACE(msg)                                                                                              \
+    if (getenv("RAYHIP_TRACE_UPLOAD")) {                                                                               \
+        fprintf(stderr, "rayhip_scene_upload: %s\n", msg);                                                             \
+    }
+
+int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     if (use_device(c)) {
         return 1;
     }
+    UPLOAD_TRACE("begin")
+    const rayhip_layout::AlignedDesc aligned(*d_in); // see bvh_layout.h
+    const rayhip_scene_desc *d = &aligned.d;
     if (d->env.qtree_levels != 0) {
         return fail("env-map quadtree importance sampling is not supported (qtree_levels must be 0)");
     }
@@ -447,6 +459,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
             lay = rayhip_layout::optimize(*d);
         }
     }
+    UPLOAD_TRACE(lay.applied ? "layout applied" : lay.why_not)
     uint32_t tlas_root = d->tlas_root;
     if (lay.applied) {
         tlas_root = lay.tlas_root;
@@ -482,6 +495,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
             }
         }
     }
+    UPLOAD_TRACE(have_wide ? "bvh4 built" : "no bvh4")
     UP(tri_materials)
     UP(materials)
     UP(vertices)
@@ -541,6 +555,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d) {
         }
     }
     c->have_scene = true;
+    UPLOAD_TRACE("done")
     return 0;
 }
 
@@ -575,8 +590,10 @@ int rayhip_scene_upload_blob(rayhip_ctx *c, const void *blob, size_t size, rayhi
     return 0;
 }
 
-int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration, uint32_t flags,
-                  rayhip_stats *stats) {
+// One wavefront pass over `count` consecutive iterations of the rect (count == 1: the plain case; > 1: layered, see
+// Layering in rt_base.h).  The caller has checked that a batch is admissible.
+static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration, int count_iterations,
+                       uint32_t flags, rayhip_stats *stats) {
     if (use_device(c)) {
         return 1;
     }
@@ -603,7 +620,9 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
     const bool sort_rays = (flags & RAYHIP_FLAG_SORT_RAYS) != 0;
     hipStream_t s = c->stream;
     const size_t npix = size_t(rect[2]) * size_t(rect[3]);
-    const size_t nslots = tile_slots(rect[2], rect[3]); // ray slots of this rect (whole 8x8 tiles)
+    const Layering layers = {c->h, count_iterations};
+    // ray slots of this rect (whole 8x8 tiles), one set per iteration in flight
+    const size_t nslots = tile_slots(rect[2], rect[3]) * size_t(count_iterations);
     const int gw = c->grid_waves;
     const int gtrace = int(std::min<size_t>(size_t(gw), nslots / WAVE));
     unsigned long long *tc = c->trav_counters.as<unsigned long long>();
@@ -615,11 +634,11 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
     // K2 launcher (instrumented variant on request)
     auto launch_closest = [&](const RaySoA &r, const RayQueue &q, int init_hits) {
         if (count) {
-            k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
+            k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else if (c->sc.nodes4) {
-            k_trace_closest<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
+            k_trace_closest<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else {
-            k_trace_closest<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc);
+            k_trace_closest<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         }
     };
 
@@ -637,7 +656,7 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         return 1;
     }
     k_raygen<<<grid_for(c, nslots, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
-                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, stripes));
+                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, stripes), layers);
     if (tm.mark(ST_PTRACE, 0)) {
         return 1;
     }
@@ -677,12 +696,12 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
             k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
                                                   c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
                                                   c->shadow_queue(bounce, nslots, stripes), c->deferred,
-                                                  c->deferred_queue(bounce, nslots, stripes), c->px, c->w, mix_factor);
+                                                  c->deferred_queue(bounce, nslots, stripes), c->px, c->w, mix_factor, layers);
         } else {
             k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
                                                    c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
                                                    c->shadow_queue(bounce, nslots, stripes), c->deferred,
-                                                   c->deferred_queue(bounce, nslots, stripes), c->px, c->w, mix_factor);
+                                                   c->deferred_queue(bounce, nslots, stripes), c->px, c->w, mix_factor, layers);
             // emitter hits whose MIS weight was deferred (kernels.hip.h); an empty queue costs a few microseconds
             k_shade_emissive<<<std::min(gtrace, 2048), WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred,
                                                      c->deferred_queue(bounce, nslots, stripes), c->px, c->w);
@@ -696,13 +715,13 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         }
         if (count) {
             k_trace_shadow<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                c->w, c->px.temp, nullptr, spill, tc + 5);
+                                                                c->w, c->px.temp, nullptr, spill, tc + 5, layers);
         } else if (c->sc.nodes4) {
             k_trace_shadow<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                c->w, c->px.temp, nullptr, spill, tc + 5);
+                                                                c->w, c->px.temp, nullptr, spill, tc + 5, layers);
         } else {
             k_trace_shadow<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                 c->w, c->px.temp, nullptr, spill, tc + 5);
+                                                                 c->w, c->px.temp, nullptr, spill, tc + 5, layers);
         }
         cur ^= 1;
     }
@@ -710,7 +729,12 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         return 1;
     }
     const AccumParams ap = make_accum_params(*cam, c->w, rect, iteration, c->shard);
-    k_accumulate<<<grid_for(c, npix, 256), 256, 0, s>>>(ap, c->px);
+    AccumLayers per_layer = {};
+    for (int l = 0; l < count_iterations; ++l) {
+        const AccumParams al = make_accum_params(*cam, c->w, rect, iteration + l, c->shard);
+        per_layer.l[l] = AccumLayer{al.iteration, al.mix_factor, al.half_mix_factor, al.is_class_a, al.variance_threshold};
+    }
+    k_accumulate<<<grid_for(c, npix, 256), 256, 0, s>>>(ap, c->px, layers, per_layer);
     HIP_TRY(hipGetLastError());
     if (tm.mark(-1, -1)) {
         return 1;
@@ -728,6 +752,48 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         }
     }
     return 0;
+}
+
+int rayhip_render_batch(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int first_iteration, int count,
+                        uint32_t flags, rayhip_stats *stats) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (count < 1) {
+        return fail("batch of %d iterations", count);
+    }
+    if (!c->w) {
+        return fail("rayhip_render needs resize + upload_static + scene_upload + set_filter_table first");
+    }
+    // A batch is exact only while adaptive sampling is inert (the reference re-queues every pixel every iteration when
+    // variance_threshold == 0); the ray sort works on one dense ray array; pixel rows are 16-bit.
+    int max_layers = MAX_BATCH;
+    if (cam->pass_settings.variance_threshold != 0.0f || (flags & RAYHIP_FLAG_SORT_RAYS) != 0) {
+        max_layers = 1;
+    }
+    while (max_layers > 1 && size_t(c->h) * size_t(max_layers) > 65535u) {
+        --max_layers;
+    }
+    int done = 0;
+    while (done < count) {
+        const int n = std::min(count - done, max_layers);
+        if (n > c->layers_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (alloc_frame(c, c->w, c->h, n)) {
+                return 1;
+            }
+        }
+        if (render_pass(c, cam, rect, first_iteration + done, n, flags, stats)) {
+            return 1;
+        }
+        done += n;
+    }
+    return 0;
+}
+
+int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration, uint32_t flags,
+                  rayhip_stats *stats) {
+    return render_pass(c, cam, rect, iteration, 1, flags, stats);
 }
 
 int rayhip_set_shard(rayhip_ctx *c, int tile, int shard_count, int shard_index) {
@@ -866,7 +932,7 @@ int rayhip_k_generate_primary_rays(rayhip_ctx *c, const rayhip_camera *cam, cons
     const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
     // kernel-level hooks use one dense stripe so that the host sees a plain array
     k_raygen<<<grid_for(c, nslots, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
-                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, 1));
+                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, 1), Layering{c->h, 1});
     HIP_TRY(hipGetLastError());
     uint32_t n = 0;
     HIP_TRY(hipMemcpyAsync(&n, c->ray_count(0), 4, hipMemcpyDeviceToHost, s));
@@ -937,11 +1003,11 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     const RayQueue q = c->ray_queue(0, size_t(count), 1);
     if (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) { // instrumented walk of the reference's BVH2
-        k_trace_closest<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc);
+        k_trace_closest<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
     } else if (c->sc.nodes4) { // what rayhip_render launches
-        k_trace_closest<false, true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc);
+        k_trace_closest<false, true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
     } else {
-        k_trace_closest<false, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc);
+        k_trace_closest<false, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -1003,7 +1069,7 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     // results land in the (otherwise idle) hit plane
     k_trace_shadow<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
-                                                    c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc);
+                                                    c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpyAsync(after, tc, sizeof(after), hipMemcpyDeviceToHost, s));

@@ -32,8 +32,9 @@ RT_HD float tonemap_standard(float c) {
 // TonemapRef.h:7-9
 RT_HD f4 reversible_tonemap(f4 c) { return c / (fmaxf(c.x, fmaxf(c.y, c.z)) + 1.0f); }
 
-RT_HD void accumulate_pixel(const AccumParams &p, const int x, const int y, float4 *temp_buf, float4 *full_buf,
-                            float4 *half_buf, float4 *raw_buf, float4 *final_buf, uint16_t *required_samples) {
+// temp_buf: this iteration's radiance; variance_buf: where the variance estimate goes (the reference reuses temp_buf)
+RT_HD void accumulate_pixel(const AccumParams &p, const int x, const int y, const float4 *temp_buf, float4 *variance_buf,
+                            float4 *full_buf, float4 *half_buf, float4 *raw_buf, float4 *final_buf, uint16_t *required_samples) {
     const int idx = y * p.w + x;
 
     if (!(required_samples[idx] < p.iteration)) {
@@ -81,7 +82,7 @@ RT_HD void accumulate_pixel(const AccumParams &p, const int x, const int y, floa
     const f4 p1 = reversible_tonemap(d);
     const f4 p2 = reversible_tonemap(half_val);
     const f4 variance = 0.5f * (p1 - p2) * (p1 - p2);
-    temp_buf[idx] = mkfloat4(variance.x, variance.y, variance.z, variance.w);
+    variance_buf[idx] = mkfloat4(variance.x, variance.y, variance.z, variance.w);
 
     if (variance.x >= p.variance_threshold || variance.y >= p.variance_threshold || variance.z >= p.variance_threshold ||
         variance.w >= p.variance_threshold) {

@@ -301,6 +301,21 @@ RT_HD f3 tangent_from_world(f3 T, f3 B, f3 N, f3 V) { return f3{dot(V, T), dot(V
 // The frame is cut into `tile` x `tile` squares walked row-major and dealt round-robin to `count` ranks; every
 // rank owns the pixels of its tiles for the whole render.  Pixels are independent (RNG is keyed by x,y,iteration:
 // CoreRef.cpp:1477-1478), so the union of the ranks' images is bit-identical to a single-GPU render.
+// Iteration batching.  Several iterations (samples per pixel) of the same rect can be in flight in ONE wavefront pass:
+// iteration first + l lives on "layer" l of a virtual frame of height layers * frame_h, i.e. a ray of pixel (x, y) on
+// layer l carries xy = (x << 16) | (y + l * frame_h) and every per-iteration buffer (temp, primary aux outputs) has
+// one frame per layer.  Whatever depends on the iteration (sample index, rand_seed, running-mean weights) is derived
+// per ray from its layer, the random-number hash from the REAL pixel, and k_accumulate folds the layers into the
+// running means in iteration order -- so a batch is bit-identical to the same iterations rendered one by one, but a
+// launch carries layers x more rays: small frames (a GPU's share of a tile-sharded frame, 256x256 previews) fill the
+// machine and the fixed cost of a launch (tail of its longest rays) is paid once per batch.
+struct Layering {
+    int frame_h; // height of the real frame
+    int count;   // layers in this pass (1 = plain single-iteration pass)
+};
+RT_HD uint32_t xy_layer(const uint32_t xy, const Layering L) { return L.count > 1 ? (xy & 0xffffu) / uint32_t(L.frame_h) : 0u; }
+RT_HD uint32_t xy_real(const uint32_t xy, const Layering L, const uint32_t layer) { return xy - layer * uint32_t(L.frame_h); }
+
 struct Shard {
     int tile, count, index;
 };

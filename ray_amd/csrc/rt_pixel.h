@@ -31,6 +31,37 @@ RT_HD void write_primary_pixel(const ShadeResult &r, const uint32_t xy, const in
     }
 }
 
+// Batched form (Layering): the aux blends depend on the iteration order, so the primary shade only stores what it
+// would have blended (the normalised base colour, depth + normal) on its layer; k_accumulate blends them in order.
+RT_HD void write_primary_pixel_layered(const ShadeResult &r, const uint32_t xy_virtual, const int img_w, float4 *temp_buf,
+                                       float4 *aux_base_layers, float4 *aux_dn_layers) {
+    const int x = int((xy_virtual >> 16) & 0x0000ffff), y = int(xy_virtual & 0x0000ffff);
+    const int idx = y * img_w + x;
+    temp_buf[idx] = mkfloat4(r.col.x, r.col.y, r.col.z, r.col.w);
+    f4 new_val = {r.base_color.x, r.base_color.y, r.base_color.z, 0.0f};
+    const float norm_factor = fmaxf(fmaxf(new_val.x, new_val.y), fmaxf(new_val.z, 1.0f));
+    new_val = new_val / norm_factor;
+    aux_base_layers[idx] = mkfloat4(new_val.x, new_val.y, new_val.z, new_val.w);
+    aux_dn_layers[idx] = mkfloat4(r.depth_normal.x, r.depth_normal.y, r.depth_normal.z, r.depth_normal.w);
+}
+RT_HD void blend_aux_pixel(const int idx, const float4 new_base, const float4 new_dn, const float mix_factor, float4 *base_color_buf,
+                           float4 *depth_normals_buf) {
+    {
+        const float4 o = base_color_buf[idx];
+        f4 old_val = {o.x, o.y, o.z, o.w};
+        const f4 new_val = {new_base.x, new_base.y, new_base.z, new_base.w};
+        old_val += (new_val - old_val) * mix_factor;
+        base_color_buf[idx] = mkfloat4(old_val.x, old_val.y, old_val.z, old_val.w);
+    }
+    {
+        const float4 o = depth_normals_buf[idx];
+        f4 old_val = {o.x, o.y, o.z, o.w};
+        const f4 new_val = {new_dn.x, new_dn.y, new_dn.z, new_dn.w};
+        old_val += (new_val - old_val) * mix_factor;
+        depth_normals_buf[idx] = mkfloat4(old_val.x, old_val.y, old_val.z, old_val.w);
+    }
+}
+
 // ShadeSecondary, ShadeRef.cpp:1713-1729: temp += rgb (alpha untouched)
 RT_HD void add_secondary_pixel(const ShadeResult &r, const uint32_t xy, const int img_w, float4 *temp_buf) {
     const int x = int((xy >> 16) & 0x0000ffff), y = int(xy & 0x0000ffff);

@@ -73,7 +73,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 # every symbol include/rayhip.h declares (tests check that the built library exports all of them)
 ENTRY_POINTS = (
     "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
-    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "readback", "readback_device", "set_raw_device",
+    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "render_batch", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand",
 )
@@ -106,6 +106,7 @@ class Library:
         f("scene_upload_blob").argtypes = [vp, vp, C.c_size_t, C.POINTER(Camera)]
         f("set_filter_table").argtypes = [vp, vp, C.c_int]
         f("render").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_uint32, C.POINTER(Stats)]
+        f("render_batch").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_int, C.c_uint32, C.POINTER(Stats)]
         f("readback").argtypes = [vp, C.c_int, vp, C.c_int]
         f("sync").argtypes = [vp]
         f("set_shard").argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -183,6 +184,15 @@ class Context:
         cam = cam or self.cam
         self.L.check(self.L.fn("render")(self._ctx, C.byref(cam), C.byref(r), iteration, flags,
                                          C.byref(stats) if stats is not None else None))
+
+    def render_batch(self, first_iteration: int, count: int, rect=None, cam: Camera = None, flags: int = 0, stats: Stats = None):
+        """iterations first_iteration .. first_iteration + count - 1 in as few wavefront passes as possible (same pixels as
+        `count` render() calls, bit for bit)"""
+        rect = (0, 0, self.w, self.h) if rect is None else rect
+        r = (C.c_int * 4)(*rect)
+        cam = cam or self.cam
+        self.L.check(self.L.fn("render_batch")(self._ctx, C.byref(cam), C.byref(r), first_iteration, count, flags,
+                                               C.byref(stats) if stats is not None else None))
 
     def readback(self, which: int = BUF_RAW) -> np.ndarray:
         out = np.empty((self.h, self.w, 4), dtype=np.float32)

@@ -84,6 +84,24 @@ class Renderer final : public RendererBase {
     std::mutex mtx_;
 
     // host mirrors handed out by get_*_pixels_ref (valid until the next mutating call, like RendererVK.cpp:1698-1757)
+    // Deferred iterations: consecutive RenderScene calls on an unchanged scene / camera / rect are only counted and
+    // then rendered together by rayhip_render_batch (up to max_batch_ iterations per wavefront pass) the moment
+    // anything could observe them -- bit-identical to rendering them one by one, much fuller launches.
+    mutable int pending_count_ = 0, pending_first_ = 0;
+    mutable rayhip_camera pending_cam_ = {};
+    mutable int pending_rect_[4] = {};
+    int max_batch_ = 32;
+
+    void Flush() const {
+        if (pending_count_ > 0) {
+            const int n = pending_count_;
+            pending_count_ = 0;
+            check(rayhip_render_batch(ctx_, &pending_cam_, pending_rect_, pending_first_, n,
+                                      collect_stats_ ? RAYHIP_FLAG_TIME_STAGES : 0u, nullptr),
+                  "rayhip_render_batch");
+        }
+    }
+
     mutable std::vector<color_rgba_t> host_[4];
     mutable bool host_dirty_[4] = {true, true, true, true};
 
@@ -94,6 +112,7 @@ class Renderer final : public RendererBase {
     }
 
     color_data_rgba_t fetch(const int which) const {
+        Flush();
         if (host_dirty_[which]) {
             host_[which].resize(size_t(w_) * h_);
             check(rayhip_readback(ctx_, which, &host_[which][0].v[0], w_), "rayhip_readback");
@@ -147,6 +166,9 @@ class Renderer final : public RendererBase {
         rayhip_ctx_device_name(ctx_, name, sizeof(name));
         device_name_ = name;
         collect_stats_ = getenv("RAY_HIP_NO_STATS") == nullptr;
+        if (const char *e = getenv("RAY_HIP_BATCH")) { // 1 = render every iteration in its own pass
+            max_batch_ = atoi(e) > 0 ? atoi(e) : 1;
+        }
 
         log->Info("============================================================================");
         log->Info("Device       is %s", device_name_.c_str());
@@ -161,7 +183,10 @@ class Renderer final : public RendererBase {
         }
         Resize(s.w, s.h);
     }
-    ~Renderer() override { rayhip_ctx_destroy(ctx_); }
+    ~Renderer() override {
+        pending_count_ = 0; // nobody can look at them any more
+        rayhip_ctx_destroy(ctx_);
+    }
 
     eRendererType type() const override { return RendererTypeHIP; }
     ILog *log() const override { return log_; }
@@ -181,6 +206,7 @@ class Renderer final : public RendererBase {
     const shl1_data_t *get_sh_data_ref() const override { return nullptr; }
 
     void Resize(const int w, const int h) override {
+        Flush();
         if (w_ != w || h_ != h) {
             check(rayhip_resize(ctx_, w, h), "rayhip_resize");
             w_ = w, h_ = h;
@@ -190,6 +216,7 @@ class Renderer final : public RendererBase {
         }
     }
     void Clear(const color_rgba_t &c) override {
+        Flush();
         check(rayhip_clear(ctx_, c.v), "rayhip_clear");
         for (bool &d : host_dirty_) {
             d = true;
@@ -207,6 +234,7 @@ class Renderer final : public RendererBase {
         std::shared_lock<std::shared_timed_mutex> scene_lock(SceneAccess::Mutex(*s));
 
         if (uploaded_scene_ != s || uploaded_version_ != s->version()) {
+            Flush(); // pending iterations belong to the scene that is on the device now
             try {
                 FlatScene flat;
                 SceneAccess::Export(*s, flat);
@@ -221,6 +249,7 @@ class Renderer final : public RendererBase {
 
         const camera_t &cam = SceneAccess::CurrentCamera(*s);
         if (cam.filter != filter_table_filter_ || cam.filter_width != filter_table_width_) {
+            Flush();
             UpdateFilterTable(cam.filter, cam.filter_width);
             filter_table_filter_ = cam.filter;
             filter_table_width_ = cam.filter_width;
@@ -234,8 +263,18 @@ class Renderer final : public RendererBase {
         const int r[4] = {rect.x, rect.y, rect.w, rect.h};
         // stage times come from HIP events recorded on the stream and are resolved lazily in GetStats -- the
         // counterpart of the timestamp queries RendererVK reads back one frame later (RendererVK.cpp:452-487)
-        check(rayhip_render(ctx_, &rc, r, region.iteration, collect_stats_ ? RAYHIP_FLAG_TIME_STAGES : 0u, nullptr),
-              "rayhip_render");
+        const bool extends = pending_count_ > 0 && region.iteration == pending_first_ + pending_count_ &&
+                             memcmp(&rc, &pending_cam_, sizeof(rc)) == 0 && memcmp(r, pending_rect_, sizeof(r)) == 0;
+        if (!extends) {
+            Flush();
+            pending_cam_ = rc;
+            memcpy(pending_rect_, r, sizeof(r));
+            pending_first_ = region.iteration;
+        }
+        ++pending_count_;
+        if (pending_count_ >= max_batch_) {
+            Flush();
+        }
         for (bool &d : host_dirty_) {
             d = true;
         }
@@ -250,12 +289,14 @@ class Renderer final : public RendererBase {
 
     void GetStats(stats_t &st) override {
         std::lock_guard<std::mutex> _(mtx_);
+        Flush();
         rayhip_stats rs = {};
         check(rayhip_get_stage_times(ctx_, &rs, 0), "rayhip_get_stage_times");
         memcpy(&st, &rs, sizeof(st));
     }
     void ResetStats() override {
         std::lock_guard<std::mutex> _(mtx_);
+        Flush();
         rayhip_stats rs = {};
         check(rayhip_get_stage_times(ctx_, &rs, 1), "rayhip_get_stage_times");
     }

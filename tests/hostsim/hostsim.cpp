@@ -106,7 +106,9 @@ HS_API int hostsim_clear(hostsim_ctx *c, const float rgba[4]) { // RendererCPU.h
     std::fill(c->required_samples.begin(), c->required_samples.end(), uint16_t(0xffff));
     return 0;
 }
-HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d) {
+HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
+    const rayhip_layout::AlignedDesc aligned(*d_in);
+    const rayhip_scene_desc *d = &aligned.d;
     HostScene &s = c->hs;
 #define CP(field) s.field.assign(d->field, d->field + d->field##_count)
     CP(nodes);
@@ -316,7 +318,7 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
             if (!pixel_owned(c->shard, w, x, y)) {
                 continue;
             }
-            accumulate_pixel(ap, x, y, c->temp.data(), c->full.data(), c->half.data(), c->raw.data(), c->final_.data(),
+            accumulate_pixel(ap, x, y, c->temp.data(), c->temp.data(), c->full.data(), c->half.data(), c->raw.data(), c->final_.data(),
                              c->required_samples.data());
         }
     }
@@ -348,6 +350,15 @@ HS_API int hostsim_readback(hostsim_ctx *c, int which, float *dst, int pitch_px)
     return 0;
 }
 HS_API int hostsim_sync(hostsim_ctx *) { return 0; }
+// the reference has no batching: iterations one by one (what rayhip_render_batch must reproduce bit for bit)
+HS_API int hostsim_render_batch(hostsim_ctx *c, const rayhip_camera *cam, const int rect[4], int first_iteration, int count,
+                                uint32_t flags, rayhip_stats *st) {
+    for (int i = 0; i < count; ++i) {
+        hostsim_render(c, cam, rect, first_iteration + i, flags, st);
+    }
+    return 0;
+}
+
 HS_API int hostsim_set_shard(hostsim_ctx *c, int tile, int shard_count, int shard_index) {
     c->shard = Shard{tile, shard_count, shard_index};
     return 0;
