@@ -17,9 +17,9 @@ echo "== rocprofv3 --kernel-trace --stats of the default bench command (CPU base
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bistro -- python $REPO/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 grep '"metric"' $OUT/stats.log | tail -c 600
 for f in $(find $OUT/stats -name '*kernel_stats.csv' | head -1); do cp $f $OUT/bistro_kernel_stats.csv; head -14 $f; done
-echo "== PMC: FETCH_SIZE, WRITE_SIZE (separate passes), bistro 8 steps"
+echo "== PMC: FETCH_SIZE, WRITE_SIZE (separate passes), the default bench command"
 for pmc in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/pmc_$pmc -o bistro -- python $REPO/bench.py --no-cpu-baseline --steps 8 --warmup 1 > $OUT/pmc_$pmc.log 2>&1
+  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/pmc_$pmc -o bistro -- python $REPO/bench.py --no-cpu-baseline > $OUT/pmc_$pmc.log 2>&1
 done
 echo "== PMC calibration on a known gather: tools/gather_bench (64-byte random node reads)"
 timeout -k 5 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_gather -o gather -- $REPO/tools/_build/gather_bench > $OUT/gather_bench.txt 2>&1
