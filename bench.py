@@ -248,6 +248,9 @@ def main():
                 "bound": "hbm", "kernel": "k_trace_closest<false,true> (closest-hit traversal, K2); algorithmic bytes = "
                                           "reference BVH2 visit counts on the same rays (SURVEY 8d)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "frac_note": "algorithmic bytes are those of the reference's BVH2 walk (64 B/node visit, 48 B/triangle test); the "
+                             "kernel walks a 4-wide quantised tree out of L1/L2, so frac > 1 means it finishes the reference's "
+                             "traversal faster than HBM could stream it -- see traffic for what actually left L2",
                 "traffic": measured_traffic(args.workload),
                 "alg_bytes_per_launch": k2_bytes / max(k2_launches, 1), "avg_launch_ms": k2_ms / max(k2_launches, 1),
                 "launches": k2_launches,
