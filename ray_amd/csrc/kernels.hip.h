@@ -93,7 +93,7 @@ namespace rt {
 #define RT_LDS_STACK_DEPTH 24
 #endif
 #ifndef RT_TRACE_MIN_WAVES
-#define RT_TRACE_MIN_WAVES 5 // 96 VGPRs: the 4-wide node visit spills badly at 80 (6 waves: K2 7.9 ms vs 5.7 ms at 5 or 4)
+#define RT_TRACE_MIN_WAVES 6 // 80 VGPRs.  Sweep with the final kernels, 32-iteration passes: 4 waves 289, 5 waves 319, 6 waves 328 Msamples/s
 #endif
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 3 // 168 VGPRs (80 B scratch): 2.98 ms/frame vs 3.17 at 201 VGPRs / 2 waves and at 128 / 4 waves

@@ -315,10 +315,10 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false, true>, WAVE, 0) != hipSuccess || per_cu <= 0) {
         per_cu = 8;
     }
-    // 4x more blocks than are resident: each block then owns ~1/4 of the chunks a resident wave would, and the
-    // hardware dispatcher hands the next block to whichever CU drains first.  Measured on the Bistro-class scene:
-    // K2 5.47 -> 5.18 ms, shade 4.81 -> 4.43 ms per frame (x1 -> x4; x8 gives nothing more).  RAYHIP_GRID_MULT overrides.
-    int grid_mult = 4;
+    // 16x more blocks than are resident: each block then owns 1/16 of the chunks a resident wave would, and the
+    // hardware dispatcher hands the next block to whichever CU drains first.  Measured on the Bistro-class scene,
+    // 32-iteration passes: x1 295, x2 306, x4 326, x8 338, x16 342, x32 342 Msamples/s.  RAYHIP_GRID_MULT overrides.
+    int grid_mult = 16;
     if (const char *e = getenv("RAYHIP_GRID_MULT")) {
         const int m = atoi(e);
         if (m >= 1 && m <= 64) {

@@ -98,8 +98,17 @@ def run1(name, workload="sponza", K=16):
         ctx.stage_times()
         t0 = time.perf_counter()
         rflags = (hip.FLAG_SORT_RAYS if "+sort" in VARIANTS[name] else 0)
-        for it in range(3, 3 + K):
-            ctx.render(it, flags=hip.FLAG_TIME_STAGES | rflags)
+        batch = int(os.environ.get("RT_BATCH", "1"))
+        if batch > 1:
+            ctx.render_batch(3, K, flags=hip.FLAG_TIME_STAGES | rflags)  # warm-up pass of the same shape (allocations)
+            ctx.sync()
+            ctx.trav_timing()
+            ctx.stage_times()
+            t0 = time.perf_counter()
+            ctx.render_batch(3 + K, K, flags=hip.FLAG_TIME_STAGES | rflags)
+        else:
+            for it in range(3, 3 + K):
+                ctx.render(it, flags=hip.FLAG_TIME_STAGES | rflags)
         ctx.sync()
         dt = time.perf_counter() - t0
         (k2, n2), (k3, n3) = ctx.trav_timing()
