@@ -143,7 +143,7 @@ typedef struct rayhip_environment {
     float back_map_rotation;
     uint32_t light_index;
     float sky_map_spread_angle;
-    int32_t qtree_levels; /* importance-sampled HDRI quadtree: not supported yet, must be 0 */
+    int32_t qtree_levels; /* levels of the env-map importance quadtree (rayhip_scene_desc::env_qtree), 0 = none */
     uint32_t _pad[3];
 } rayhip_environment;
 
@@ -201,6 +201,11 @@ typedef struct rayhip_scene_desc {
     uint32_t light_cwnodes_count;
     const rayhip_texture *textures;
     uint32_t textures_count;
+    /* env-map importance quadtree (reference environment_t::qtree_mips, Core.h:400; built by
+     * Scene::PrepareEnvMapQTree): the env.qtree_levels mips concatenated, lod 0 (finest) first; mip `lod` holds
+     * 4^(levels-1-lod) quads of 4 floats (luminance of the four sub-cells), row-major.  Count in floats. */
+    const float *env_qtree;
+    uint32_t env_qtree_count;
     const uint32_t *texels; /* RGBA8 pool */
     uint32_t texels_count;
     uint32_t tex_table[8]; /* first `textures` entry of each reference storage (RGBA,RGB,RG,R,BC1,BC3,BC4,BC5) */

@@ -81,7 +81,7 @@ struct rayhip_ctx {
     DevBuf pmj, filter_table;
     // scene
     DevBuf nodes, tris, tri_indices, tri_materials, materials, vertices, vtx_indices, mesh_instances, lights, li_indices,
-        light_cwnodes, light_children, textures, texels, nodes4, blas_root4;
+        light_cwnodes, light_children, textures, texels, nodes4, blas_root4, env_qtree;
     SceneView sc = {};
     float bbox_min[3] = {}, bbox_max[3] = {};
     bool have_scene = false;
@@ -349,7 +349,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         (void)hipEventDestroy(e);
     }
     DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
-                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->nodes4, &c->blas_root4,
+                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->nodes4, &c->blas_root4, &c->env_qtree,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
                      &c->px_dn, &c->px_req, &c->px_aux_base, &c->px_aux_dn, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
                      &c->shadow_planes[2], &c->deferred_planes[0], &c->deferred_planes[1], &c->counters, &c->trav_counters, &c->stack_spill,
@@ -442,8 +442,17 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     UPLOAD_TRACE("begin")
     const rayhip_layout::AlignedDesc aligned(*d_in); // see bvh_layout.h
     const rayhip_scene_desc *d = &aligned.d;
-    if (d->env.qtree_levels != 0) {
-        return fail("env-map quadtree importance sampling is not supported (qtree_levels must be 0)");
+    if (d->env.qtree_levels < 0 || d->env.qtree_levels > 16) {
+        return fail("bad env-map quadtree depth %d", d->env.qtree_levels);
+    }
+    {
+        size_t quads = 0;
+        for (int lod = 0; lod < d->env.qtree_levels; ++lod) {
+            quads += size_t(1) << (2 * (d->env.qtree_levels - 1 - lod));
+        }
+        if (size_t(d->env_qtree_count) != quads * 4) {
+            return fail("env_qtree holds %u floats, %d levels need %zu", d->env_qtree_count, d->env.qtree_levels, quads * 4);
+        }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
 #define UP(field)                                                                                                      \
@@ -519,6 +528,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     }
     UP(textures)
     UP(texels)
+    UP(env_qtree)
 #undef UP
     HIP_TRY(hipStreamSynchronize(c->stream)); // host arrays may go away after this call
     SceneView &v = c->sc;
@@ -528,6 +538,13 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     v.vtx_indices = c->vtx_indices.as<uint32_t>(), v.mesh_instances = c->mesh_instances.as<rayhip_mesh_instance>();
     v.lights = c->lights.as<rayhip_light>(), v.li_indices = c->li_indices.as<uint32_t>();
     v.light_children = c->light_children.as<float4>();
+    v.env_qtree = c->env_qtree.as<float4>();
+    for (int lod = 0, off = 0; lod < 16; ++lod) {
+        v.env_qtree_offset[lod] = uint32_t(off);
+        if (lod < d->env.qtree_levels) {
+            off += 1 << (2 * (d->env.qtree_levels - 1 - lod));
+        }
+    }
     v.nodes4 = have_wide ? c->nodes4.as<Bvh4Node>() : nullptr;
     v.blas_root4 = have_wide ? c->blas_root4.as<uint32_t>() : nullptr;
     v.light_cwnodes = c->light_cwnodes.as<rayhip_light_cwbvh_node>(), v.textures = c->textures.as<rayhip_texture>();

@@ -356,6 +356,130 @@ RT_HD float total_importance8(const float imp[8]) {
     return (((imp[0] + imp[4]) + (imp[1] + imp[5])) + (imp[2] + imp[6])) + (imp[3] + imp[7]);
 }
 
+// ---- env-map importance quadtree -----------------------------------------------------------------------
+// Core.cpp:110-141 (libm sinf / cosf / atan2f there, i.e. the device's versions here: last-ulp differences)
+RT_HD f3 canonical_to_dir(const f2 p, const float y_rotation) {
+    const float cos_theta = 2 * p.x - 1;
+    float phi = 2 * PI * p.y + y_rotation;
+    if (phi < 0) {
+        phi += 2 * PI;
+    }
+    if (phi > 2 * PI) {
+        phi -= 2 * PI;
+    }
+    const float sin_theta = sqrtf(1 - cos_theta * cos_theta);
+    const float sin_phi = sinf(phi);
+    const float cos_phi = cosf(phi);
+    return f3{sin_theta * cos_phi, cos_theta, -sin_theta * sin_phi};
+}
+RT_HD f2 dir_to_canonical(const f3 d, const float y_rotation) {
+    const float cos_theta = fminf(fmaxf(d.y, -1.0f), 1.0f);
+    float phi = -atan2f(d.z, d.x) + y_rotation;
+    if (phi < 0) {
+        phi += 2 * PI;
+    }
+    if (phi > 2 * PI) {
+        phi -= 2 * PI;
+    }
+    return f2{(cos_theta + 1.0f) / 2.0f, phi / (2.0f * PI)};
+}
+RT_HD float quad_at(const float4 q, const int i) { return i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w)); }
+
+// pdf of direction L under the quadtree, CoreRef.cpp:4738-4771
+RT_HD float evaluate_env_qtree(const SceneView &sc, const float y_rotation, const f3 L) {
+    const int qtree_levels = sc.env.qtree_levels;
+    int res = 2;
+    int lod = qtree_levels - 1;
+
+    const f2 p = dir_to_canonical(L, -y_rotation);
+    float factor = 1.0f;
+
+    while (lod >= 0) {
+        const int x = clampi(int(p.x * float(res)), 0, res - 1);
+        const int y = clampi(int(p.y * float(res)), 0, res - 1);
+
+        int index = 0;
+        index |= (x & 1) << 0;
+        index |= (y & 1) << 1;
+
+        const int qx = x / 2;
+        const int qy = y / 2;
+
+        const float4 quad = sc.env_qtree[sc.env_qtree_offset[lod] + uint32_t(qy * res / 2 + qx)];
+        const float total = quad.x + quad.y + quad.z + quad.w;
+        if (total <= 0.0f) {
+            break;
+        }
+        factor *= 4.0f * quad_at(quad, index) / total;
+
+        --lod;
+        res *= 2;
+    }
+    return factor / (4.0f * PI);
+}
+
+// importance-sampled direction + pdf, CoreRef.cpp:4773-4839
+RT_HD f4 sample_env_qtree(const SceneView &sc, const float y_rotation, const float rand, const float rx, const float ry) {
+    const int qtree_levels = sc.env.qtree_levels;
+    int res = 2;
+    float step = 1.0f / float(res);
+
+    float sample = rand;
+    int lod = qtree_levels - 1;
+
+    f2 origin = {0.0f, 0.0f};
+    float factor = 1.0f;
+
+    while (lod >= 0) {
+        const int qx = int(origin.x * float(res)) / 2;
+        const int qy = int(origin.y * float(res)) / 2;
+
+        const float4 quad = sc.env_qtree[sc.env_qtree_offset[lod] + uint32_t(qy * res / 2 + qx)];
+
+        const float top_left = quad.x;
+        const float top_right = quad.y;
+        float partial = top_left + quad.z;
+        const float total = partial + top_right + quad.w;
+        if (total <= 0.0f) {
+            break;
+        }
+
+        float boundary = partial / total;
+
+        int index = 0;
+        if (sample < boundary) {
+            sample /= boundary;
+            boundary = top_left / partial;
+        } else {
+            partial = total - partial;
+            origin.x = origin.x + step;
+            sample = (sample - boundary) / (1.0f - boundary);
+            boundary = top_right / partial;
+            index |= (1 << 0);
+        }
+
+        if (sample < boundary) {
+            sample /= boundary;
+        } else {
+            origin.y = origin.y + step;
+            sample = (sample - boundary) / (1.0f - boundary);
+            index |= (1 << 1);
+        }
+
+        factor *= 4.0f * quad_at(quad, index) / total;
+
+        --lod;
+        res *= 2;
+        step *= 0.5f;
+    }
+
+    origin.x += 2 * step * rx;
+    origin.y += 2 * step * ry;
+
+    const f3 dir = canonical_to_dir(origin, y_rotation);
+    return f4{dir.x, dir.y, dir.z, factor / (4.0f * PI)};
+}
+
 // CoreRef.cpp:2995-3039 (stochastic branch)
 RT_HD f3 sample_latlong_rgbe(const SceneView &sc, const uint32_t handle, const f3 dir, const float y_rotation, const f2 rnd) {
     const float theta = acosf(clampf(dir.y, -1.0f, 1.0f)) / PI;
@@ -689,15 +813,24 @@ RT_HD void sample_light_source(const SceneView &sc, const f3 P, const f3 T, cons
     } else if (ltype == LIGHT_TYPE_ENV) {
         const float rx = rand_light_uv.x, ry = rand_light_uv.y;
 
-        // Sample environment as hemishpere (qtree importance sampling is not supported: env.qtree_levels == 0)
-        const float phi = 2 * PI * ry;
-        const f2 sincos_phi = portable_sincos(phi);
-        const float cos_phi = sincos_phi.y, sin_phi = sincos_phi.x;
+        float env_pdf;
+        if (sc.env.qtree_levels) {
+            // Sample environment using quadtree
+            const f4 dir_and_pdf = sample_env_qtree(sc, sc.env.env_map_rotation, u1, rx, ry);
+            ls.L = f3{dir_and_pdf.x, dir_and_pdf.y, dir_and_pdf.z};
+            env_pdf = dir_and_pdf.w;
+        } else {
+            // Sample environment as hemishpere
+            const float phi = 2 * PI * ry;
+            const f2 sincos_phi = portable_sincos(phi);
+            const float cos_phi = sincos_phi.y, sin_phi = sincos_phi.x;
 
-        const float dir = sqrtf(1.0f - rx * rx);
-        const f3 V = {dir * cos_phi, dir * sin_phi, rx}; // in tangent-space
+            const float dir = sqrtf(1.0f - rx * rx);
+            const f3 V = {dir * cos_phi, dir * sin_phi, rx}; // in tangent-space
 
-        ls.L = world_from_tangent(T, B, N, V);
+            ls.L = world_from_tangent(T, B, N, V);
+            env_pdf = 0.5f / PI;
+        }
         ls.col *= mk3(sc.env.env_col);
 
         if (sc.env.env_map != 0xffffffff) {
@@ -707,7 +840,7 @@ RT_HD void sample_light_source(const SceneView &sc, const f3 P, const f3 T, cons
         ls.area = 1.0f;
         ls.lp = P + ls.L;
         ls.dist_mul = MAX_DIST;
-        ls.pdf = 0.5f / PI;
+        ls.pdf = env_pdf;
         ls.from_env = true;
         ls.ray_flags = light_ray_visibility(l);
     }

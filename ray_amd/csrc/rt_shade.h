@@ -86,12 +86,19 @@ RT_HD f4 Evaluate_EnvColor(const SceneView &sc, const Ray &ray, const float pdf_
     }
 
     if (env.light_index != 0xffffffff && pdf_factor >= 0.0f && is_indirect(ray.depth)) {
-        // (no qtree) uniform hemisphere pdf
-        const float light_pdf = safe_div_pos(0.5f, PI * pdf_factor);
-        const float bsdf_pdf = ray.pdf;
+        if (env.qtree_levels) {
+            const float light_pdf = safe_div_pos(evaluate_env_qtree(sc, env_map_rotation, I), pdf_factor);
+            const float bsdf_pdf = ray.pdf;
 
-        const float mis_weight = power_heuristic(bsdf_pdf, light_pdf);
-        env_col *= mis_weight;
+            const float mis_weight = power_heuristic(bsdf_pdf, light_pdf);
+            env_col *= mis_weight;
+        } else {
+            const float light_pdf = safe_div_pos(0.5f, PI * pdf_factor);
+            const float bsdf_pdf = ray.pdf;
+
+            const float mis_weight = power_heuristic(bsdf_pdf, light_pdf);
+            env_col *= mis_weight;
+        }
     }
 
     env_col *= is_indirect(ray.depth) ? mk4(env.env_col[0], env.env_col[1], env.env_col[2], 1.0f)

@@ -36,6 +36,8 @@ struct SceneView {
     const float4 *light_children; // 24 float4 per light-tree node: decode_lnode_child of its 8 children (rt_lights.h)
     const rayhip_texture *textures;
     const uint32_t *texels;
+    const float4 *env_qtree;       // env-map importance quadtree: quads of all lods, lod 0 first (rayhip.h)
+    uint32_t env_qtree_offset[16]; // first quad of each lod
     const uint32_t *pmj; // 32 dims x 4096 samples x 2 (u32), reference Core.h:363-368
     uint32_t tex_table[8];
     uint32_t li_indices_count;

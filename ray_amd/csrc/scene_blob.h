@@ -73,6 +73,7 @@ inline std::vector<uint8_t> serialize(const rayhip_scene_desc &d, const rayhip_c
     ARR(light_cwnodes)
     ARR(textures)
     ARR(texels)
+    ARR(env_qtree)
 #undef ARR
     Scalars sc = {};
     memcpy(sc.tex_table, d.tex_table, sizeof(sc.tex_table));
@@ -149,6 +150,7 @@ inline bool deserialize(const void *blob, size_t size, rayhip_scene_desc &d, ray
         ARR(light_cwnodes, rayhip_light_cwbvh_node)
         ARR(textures, rayhip_texture)
         ARR(texels, uint32_t)
+        ARR(env_qtree, float)
 #undef ARR
         if (name == "scalars" && s.size == sizeof(Scalars)) {
             Scalars sc;

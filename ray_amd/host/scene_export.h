@@ -45,6 +45,7 @@ struct FlatScene {
     rayhip_scene_desc desc = {};
     std::vector<rayhip_texture> textures;
     std::vector<uint32_t> texels;
+    std::vector<float> env_qtree;
 };
 
 // Access to Cpu::Scene / SceneCommon protected members through a derived class (legal: the member pointers
@@ -143,9 +144,17 @@ class SceneAccess : public Cpu::Scene {
         d.texels_count = uint32_t(out.texels.size());
 
         const environment_t &e = s.env_;
-        if (e.qtree_levels != 0) {
-            throw std::runtime_error("SceneHIP: importance-sampled env maps (qtree) are not supported yet");
+        out.env_qtree.clear();
+        for (int lod = 0; lod < e.qtree_levels; ++lod) {
+            const size_t quads = size_t(1) << (2 * (e.qtree_levels - 1 - lod));
+            if (s.env_map_qtree_.mips[lod].size() < quads) {
+                throw std::runtime_error("SceneHIP: unexpected env-map quadtree layout");
+            }
+            const float *src = reinterpret_cast<const float *>(s.env_map_qtree_.mips[lod].data());
+            out.env_qtree.insert(out.env_qtree.end(), src, src + quads * 4);
         }
+        d.env_qtree = out.env_qtree.data();
+        d.env_qtree_count = uint32_t(out.env_qtree.size());
         memcpy(d.env.env_col, e.env_col, 12);
         d.env.env_map = e.env_map;
         memcpy(d.env.back_col, e.back_col, 12);
@@ -154,7 +163,7 @@ class SceneAccess : public Cpu::Scene {
         d.env.back_map_rotation = e.back_map_rotation;
         d.env.light_index = e.light_index;
         d.env.sky_map_spread_angle = e.sky_map_spread_angle;
-        d.env.qtree_levels = 0;
+        d.env.qtree_levels = e.qtree_levels;
 
         d.tlas_root = s.tlas_root_;
         d.visible_lights_count = s.visible_lights_count_;

@@ -81,9 +81,9 @@ def _block_quads(kind: str):
     ]
 
 
-def cornell_mesh_arrays() -> Tuple[np.ndarray, np.ndarray]:
-    """(attrs [64, 8] = pos3 nrm3 uv2, indices [96]) of the Cornell box mesh."""
-    quads = _CORNELL_QUADS + _block_quads("short") + _block_quads("tall")
+def cornell_mesh_arrays(quads=None) -> Tuple[np.ndarray, np.ndarray]:
+    """(attrs [64, 8] = pos3 nrm3 uv2, indices [96]) of the Cornell box mesh (or of the given subset of its quads)."""
+    quads = (_CORNELL_QUADS + _block_quads("short") + _block_quads("tall")) if quads is None else quads
     attrs, idx = [], []
     for qi, (corners, n, uvs, pat) in enumerate(quads):
         for c, uv in zip(corners, uvs):
@@ -202,6 +202,47 @@ def cornell_lights(scene, **cam_overrides):
                    xform=_translate(-0.545, 0.30, -0.30, rot_z_deg=-90.0))
     scene.AddLight("line", color=(7.0, 2.0, 2.0), radius=0.006, height=0.25, xform=_translate(-0.02, 0.35, -0.30, rot_x_deg=90.0))
     scene.AddLight("directional", color=(1.2, 1.1, 1.0), direction=(0.25, -0.45, -1.0), angle=4.0)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
+def rgbe_sky(w: int = 128, h: int = 64) -> np.ndarray:
+    """small latlong HDR sky in RGBE8 (what Ray's env maps are: RGBA8888 bytes = mantissas + shared exponent): blue-ish
+    gradient, warm horizon band and a sun 3 orders of magnitude brighter -- something worth importance sampling"""
+    v, u = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+    theta, phi = v * math.pi, u * 2 * math.pi
+    up = np.cos(theta)
+    sky = np.stack([0.25 + 0.2 * (1 - up), 0.35 + 0.25 * (1 - up), 0.7 + 0.1 * up], axis=-1) * np.clip(up * 0.5 + 0.6, 0.05, None)[..., None]
+    horizon = np.exp(-((theta - math.pi / 2) / 0.12) ** 2)[..., None] * np.array([0.9, 0.55, 0.3])
+    d = np.stack([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)], axis=-1)
+    sun_dir = _unit((0.35, 0.75, 0.55))
+    sun = (np.clip((d * np.asarray(sun_dir)).sum(-1), 0, 1) ** 600)[..., None] * np.array([900.0, 820.0, 640.0])
+    rgb = (sky + horizon + sun).astype(np.float64)
+    m = rgb.max(axis=-1)
+    e = np.where(m > 1e-32, np.ceil(np.log2(np.maximum(m, 1e-32))), 0.0)
+    scale = np.where(m > 1e-32, 256.0 / np.exp2(e), 0.0)
+    img = np.zeros((h, w, 4), dtype=np.uint8)
+    img[..., :3] = np.clip(np.floor(rgb * scale[..., None]), 0, 255).astype(np.uint8)
+    img[..., 3] = np.where(m > 1e-32, np.clip(e + 128, 0, 255), 0).astype(np.uint8)
+    return img
+
+
+def cornell_env(scene, **cam_overrides):
+    """Cornell box without its ceiling, lit only by an importance-sampled HDR environment (env-map quadtree, SURVEY 8
+    a11): Scene::PrepareEnvMapQTree builds the tree on the host, SampleLightSource / Evaluate_EnvColor use it."""
+    sky = scene.AddTexture(rgbe_sky(), is_srgb=False)
+    scene.SetEnvironment(env_col=(1.0, 1.0, 1.0), back_col=(1.0, 1.0, 1.0), env_map=sky, back_map=sky,
+                         env_map_rotation=0.3, back_map_rotation=0.3, importance_sample=True)
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.05, 0.05)))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.05, 0.5, 0.05)))
+    shiny = scene.AddMaterial(PrincipledMat(base_color=(0.8, 0.8, 0.85), metallic=1.0, roughness=0.15))
+    # floor, back wall, left wall, right wall (no ceiling, no light quad), then the two blocks
+    q = _CORNELL_QUADS
+    attrs, idx = cornell_mesh_arrays([q[0], q[1], q[3], q[4]] + _block_quads("short") + _block_quads("tall"))
+    groups = [(grey, None, 0, 12), (red, None, 12, 6), (green, None, 18, 6), (grey, None, 24, 30), (shiny, None, 54, 30)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
     _cornell_camera(scene, **cam_overrides)
     scene.Finalize()
 
@@ -370,4 +411,5 @@ SCENES = {
     "cornell_basic": cornell_basic,
     "cornell_principled": cornell_principled,
     "cornell_lights": cornell_lights,
+    "cornell_env": cornell_env,
 }

@@ -43,6 +43,7 @@ struct HostScene {
     std::vector<uint32_t> li_indices;
     std::vector<rayhip_light_cwbvh_node> light_cwnodes;
     std::vector<float4> light_children;
+    std::vector<float> env_qtree;
     std::vector<Bvh4Node> nodes4;
     std::vector<uint32_t> blas_root4;
     std::vector<rayhip_texture> textures;
@@ -132,6 +133,7 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     }
     CP(textures);
     CP(texels);
+    CP(env_qtree);
 #undef CP
     // the same HBM layout pass librayhip applies at upload (results must not depend on it); HOSTSIM_NO_LAYOUT=1 skips
     uint32_t tlas_root = d->tlas_root;
@@ -172,6 +174,13 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     v.tri_materials = s.tri_materials.data(), v.materials = s.materials.data(), v.vertices = s.vertices.data();
     v.vtx_indices = s.vtx_indices.data(), v.mesh_instances = s.mesh_instances.data(), v.lights = s.lights.data();
     v.light_children = s.light_children.data();
+    v.env_qtree = reinterpret_cast<const float4 *>(s.env_qtree.data());
+    for (int lod = 0, off = 0; lod < 16; ++lod) {
+        v.env_qtree_offset[lod] = uint32_t(off);
+        if (lod < d->env.qtree_levels) {
+            off += 1 << (2 * (d->env.qtree_levels - 1 - lod));
+        }
+    }
     v.li_indices = s.li_indices.data(), v.light_cwnodes = s.light_cwnodes.data(), v.textures = s.textures.data();
     v.texels = s.texels.data();
     memcpy(v.tex_table, d->tex_table, sizeof(v.tex_table));

@@ -16,7 +16,7 @@ from ray_amd import hip
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["cornell_basic", "cornell_principled", "cornell_lights"]
+SCENES = ["cornell_basic", "cornell_principled", "cornell_lights", "cornell_env"]
 
 
 @pytest.fixture(scope="module")
