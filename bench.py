@@ -83,13 +83,16 @@ def get_scene_blob(name, wl, rank, world, barrier):
     return blob, info
 
 
-def measured_traffic(workload):
+def measured_traffic(workload, batch):
     """HBM bytes per K2 launch from the committed rocprofv3 PMC passes (profiles/r01/k2_traffic.json: FETCH_SIZE + WRITE_SIZE,
-    collected in separate runs of this command under the profiler); None for workloads that were not profiled"""
+    collected in separate runs of this command under the profiler; scaled by the ray count if this run puts a different
+    number of iterations into a pass than the profiled one); None for workloads that were not profiled"""
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "k2_traffic.json")) as f:
             t = json.load(f).get(workload)
-        return None if t is None else float(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"])
+        if t is None:
+            return None
+        return float(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) * batch / float(t.get("iterations_per_pass", batch))
     except (OSError, ValueError, KeyError):
         return None
 
@@ -127,8 +130,8 @@ def cpu_baseline(wl, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=32)  # one full pass of 32 iterations, the shape of the timed passes
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=60)  # one full pass of 60 iterations (1080p), the shape of the timed passes
     ap.add_argument("--workload", default=os.environ.get("RAY_AMD_WORKLOAD", "bistro"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -169,7 +172,7 @@ def main():
     ctx.set_shard(TILE, world, rank)
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
 
-    batch = int(os.environ.get("RAY_AMD_BATCH", "0")) or multigpu.batch_size(W * H // world)
+    batch = int(os.environ.get("RAY_AMD_BATCH", "0")) or multigpu.batch_size(W * H // world, ctx.max_batch(), K)
     it = 0
     if Wm > 0:  # untimed warm-up with the same pass shape (allocates the layered buffers)
         done = 0
@@ -251,7 +254,7 @@ def main():
                 "frac_note": "algorithmic bytes are those of the reference's BVH2 walk (64 B/node visit, 48 B/triangle test); the "
                              "kernel walks a 4-wide quantised tree out of L1/L2, so frac > 1 means it finishes the reference's "
                              "traversal faster than HBM could stream it -- see traffic for what actually left L2",
-                "traffic": measured_traffic(args.workload),
+                "traffic": measured_traffic(args.workload, batch),
                 "alg_bytes_per_launch": k2_bytes / max(k2_launches, 1), "avg_launch_ms": k2_ms / max(k2_launches, 1),
                 "launches": k2_launches,
                 "alg_bytes_per_ray": k2_bytes / scale / max(c2["rays"], 1),

@@ -325,11 +325,16 @@ RAYHIP_API int rayhip_set_filter_table(rayhip_ctx *ctx, const float *table, int 
 RAYHIP_API int rayhip_render(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int iteration,
                              uint32_t flags, rayhip_stats *stats);
 /* The same for `count` consecutive iterations first_iteration .. first_iteration + count - 1 of the rect -- what `count`
- * RenderScene calls with an unchanged scene and camera produce, bit for bit -- but up to 32 of them share one
+ * RenderScene calls with an unchanged scene and camera produce, bit for bit -- but up to rayhip_max_batch() of them share one
  * wavefront pass (more rays per launch: small frames and tile shards fill the GPU).  Falls back to one pass per
  * iteration when adaptive sampling is active (variance_threshold != 0) or RAYHIP_FLAG_SORT_RAYS is set. */
 RAYHIP_API int rayhip_render_batch(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int first_iteration,
                                    int count, uint32_t flags, rayhip_stats *stats);
+/* Largest number of iterations one wavefront pass of the current frame can carry: min(64, 65535 / frame height) (the
+ * layers of a pass are stacked into one virtual frame whose rows must fit the 16-bit pixel coordinate of ray_data_t::xy,
+ * internal/Core.h).  rayhip_render_batch splits longer runs itself; callers that choose the run length (RendererHIP's
+ * deferred RenderScene calls, bench.py) use this to cut a render into passes of equal size.  0 before rayhip_resize. */
+RAYHIP_API int rayhip_max_batch(rayhip_ctx *ctx);
 
 /* Multi-GPU tile sharding (new): this context renders only the pixels of the tile x tile
  * squares (row-major walk over the frame) whose ordinal % shard_count == shard_index; all other pixels of its

@@ -215,7 +215,10 @@ struct AccumLayer {
     int is_class_a;
     float variance_threshold;
 };
-constexpr int MAX_BATCH = 32;
+#ifndef RT_MAX_BATCH
+#define RT_MAX_BATCH 64
+#endif
+constexpr int MAX_BATCH = RT_MAX_BATCH;
 struct AccumLayers {
     AccumLayer l[MAX_BATCH];
 };

@@ -771,6 +771,13 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     return 0;
 }
 
+int rayhip_max_batch(rayhip_ctx *c) {
+    if (!c || !c->h) {
+        return 0;
+    }
+    return int(std::max<size_t>(1, std::min<size_t>(size_t(MAX_BATCH), 65535u / size_t(c->h))));
+}
+
 int rayhip_render_batch(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int first_iteration, int count,
                         uint32_t flags, rayhip_stats *stats) {
     if (use_device(c)) {
@@ -784,12 +791,9 @@ int rayhip_render_batch(rayhip_ctx *c, const rayhip_camera *cam, const int rect[
     }
     // A batch is exact only while adaptive sampling is inert (the reference re-queues every pixel every iteration when
     // variance_threshold == 0); the ray sort works on one dense ray array; pixel rows are 16-bit.
-    int max_layers = MAX_BATCH;
+    int max_layers = rayhip_max_batch(c);
     if (cam->pass_settings.variance_threshold != 0.0f || (flags & RAYHIP_FLAG_SORT_RAYS) != 0) {
         max_layers = 1;
-    }
-    while (max_layers > 1 && size_t(c->h) * size_t(max_layers) > 65535u) {
-        --max_layers;
     }
     int done = 0;
     while (done < count) {

@@ -73,7 +73,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 # every symbol include/rayhip.h declares (tests check that the built library exports all of them)
 ENTRY_POINTS = (
     "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
-    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "render_batch", "readback", "readback_device", "set_raw_device",
+    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "render_batch", "max_batch", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand",
 )
@@ -107,6 +107,7 @@ class Library:
         f("set_filter_table").argtypes = [vp, vp, C.c_int]
         f("render").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_uint32, C.POINTER(Stats)]
         f("render_batch").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_int, C.c_uint32, C.POINTER(Stats)]
+        f("max_batch").argtypes = [vp]
         f("readback").argtypes = [vp, C.c_int, vp, C.c_int]
         f("sync").argtypes = [vp]
         f("set_shard").argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -193,6 +194,10 @@ class Context:
         cam = cam or self.cam
         self.L.check(self.L.fn("render_batch")(self._ctx, C.byref(cam), C.byref(r), first_iteration, count, flags,
                                                C.byref(stats) if stats is not None else None))
+
+    def max_batch(self) -> int:
+        """largest number of iterations one wavefront pass of the current frame can carry"""
+        return int(self.L.fn("max_batch")(self._ctx))
 
     def readback(self, which: int = BUF_RAW) -> np.ndarray:
         out = np.empty((self.h, self.w, 4), dtype=np.float32)

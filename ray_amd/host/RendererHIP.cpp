@@ -10,6 +10,7 @@
 // RendererCPU.h:368-371) whose flat arrays are uploaded after every mutation.
 #include "RendererHIP.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -90,7 +91,7 @@ class Renderer final : public RendererBase {
     mutable int pending_count_ = 0, pending_first_ = 0;
     mutable rayhip_camera pending_cam_ = {};
     mutable int pending_rect_[4] = {};
-    int max_batch_ = 32;
+    int max_batch_ = 64; // further limited by rayhip_max_batch() (frame height)
 
     void Flush() const {
         if (pending_count_ > 0) {
@@ -272,7 +273,7 @@ class Renderer final : public RendererBase {
             pending_first_ = region.iteration;
         }
         ++pending_count_;
-        if (pending_count_ >= max_batch_) {
+        if (pending_count_ >= std::min(max_batch_, std::max(1, rayhip_max_batch(ctx_)))) {
             Flush();
         }
         for (bool &d : host_dirty_) {

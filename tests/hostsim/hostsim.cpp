@@ -368,6 +368,7 @@ HS_API int hostsim_render_batch(hostsim_ctx *c, const rayhip_camera *cam, const 
     return 0;
 }
 
+HS_API int hostsim_max_batch(hostsim_ctx *) { return 64; }
 HS_API int hostsim_set_shard(hostsim_ctx *c, int tile, int shard_count, int shard_index) {
     c->shard = Shard{tile, shard_count, shard_index};
     return 0;

@@ -229,7 +229,7 @@ def test_full_size_properties(gpu_lib):
 
 @pytest.mark.parametrize("name", SCENES)
 def test_iteration_batching_is_bit_identical(gpu_lib, name):
-    """rayhip_render_batch: up to 16 iterations share one wavefront pass (layered virtual frame); every buffer must equal
+    """rayhip_render_batch: up to max_batch() iterations share one wavefront pass (layered virtual frame); every buffer must equal
     what the same iterations give one by one"""
     w, h = 96, 80
     one = util.make_context(gpu_lib, name, w, h)
@@ -249,6 +249,21 @@ def test_iteration_batching_is_bit_identical(gpu_lib, name):
         a.render(it, rect=(8, 16, 80, 48))
     b.render_batch(1, 5, rect=(8, 16, 80, 48))
     assert np.array_equal(a.readback(hip.BUF_RAW), b.readback(hip.BUF_RAW))
+
+
+def test_maximal_batch_and_row_limit_split(gpu_lib):
+    """a full 64-layer pass, and a frame tall enough that the 16-bit row limit cuts the pass (rayhip_max_batch): both must
+    equal the iterations rendered one by one"""
+    name = "cornell_basic"
+    for (w, h, n) in ((64, 48, 70), (16, 2000, 40)):
+        one = util.make_context(gpu_lib, name, w, h)
+        for it in range(1, n + 1):
+            one.render(it)
+        bat = util.make_context(gpu_lib, name, w, h)
+        assert bat.max_batch() == min(64, 65535 // h)
+        bat.render_batch(1, n)
+        assert np.array_equal(one.readback(hip.BUF_RAW), bat.readback(hip.BUF_RAW)), (w, h)
+        assert np.array_equal(one.readback(hip.BUF_FINAL), bat.readback(hip.BUF_FINAL)), (w, h)
 
 
 def test_renderer_hip_through_the_ray_api(gpu_lib):
