@@ -77,6 +77,7 @@ struct rayhip_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t props = {};
     int grid_waves = 0; // resident-ish grid for the wave-per-block kernels
+    int refill_waves = 0; // exactly-resident grid of the persistent closest-hit kernel; 0 = kernel switched off
 
     DevBuf pmj, filter_table;
     // scene
@@ -326,6 +327,19 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         }
     }
     c->grid_waves = c->props.multiProcessorCount * per_cu * grid_mult;
+    // the persistent ray-refill form of the closest-hit kernel (opt-in, RAYHIP_REFILL=1: measured equal or slower, see
+    // kernels.hip.h) runs one block per resident wave slot
+    if (getenv("RAYHIP_REFILL") != nullptr && atoi(getenv("RAYHIP_REFILL")) != 0) {
+        int per_cu_refill = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_refill, k_trace_closest_refill, WAVE, 0) != hipSuccess || per_cu_refill <= 0) {
+            per_cu_refill = per_cu;
+        }
+        int refill_mult = 1;
+        if (const char *e = getenv("RAYHIP_REFILL_MULT")) {
+            refill_mult = std::max(1, std::min(64, atoi(e)));
+        }
+        c->refill_waves = std::min(c->grid_waves, c->props.multiProcessorCount * per_cu_refill * refill_mult);
+    }
     if (c->stack_spill.alloc(size_t(c->grid_waves) * STACK_SPILL_DEPTH * WAVE * sizeof(uint32_t))) {
         delete c;
         return 1;
@@ -652,6 +666,8 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     auto launch_closest = [&](const RaySoA &r, const RayQueue &q, int init_hits) {
         if (count) {
             k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
+        } else if (c->sc.nodes4 && c->refill_waves) {
+            k_trace_closest_refill<<<std::min(gtrace, c->refill_waves), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
         } else if (c->sc.nodes4) {
             k_trace_closest<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else {
@@ -1025,7 +1041,9 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     const RayQueue q = c->ray_queue(0, size_t(count), 1);
     if (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) { // instrumented walk of the reference's BVH2
         k_trace_closest<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
-    } else if (c->sc.nodes4) { // what rayhip_render launches
+    } else if (c->sc.nodes4 && c->refill_waves) { // what rayhip_render launches
+        k_trace_closest_refill<<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), Layering{c->h, 1});
+    } else if (c->sc.nodes4) {
         k_trace_closest<false, true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
     } else {
         k_trace_closest<false, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});

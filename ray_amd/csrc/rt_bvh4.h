@@ -96,6 +96,36 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
     RT_PROF_T(18)
 }
 
+// One node visit of the ordered walk with the stack update (see "stack discipline" below): tests the four children of
+// `cur`, continues with the nearest one that was hit and pushes the others (farthest first), or pops when none was hit.
+template <class Stack>
+RT_HD void bvh4_visit(const Bvh4Node *nodes4, const f3 ro, const f3 inv_d, const float t, Stack &st, uint32_t &cur, uint32_t &tos,
+                      uint32_t &size) {
+    uint32_t ref[4], n_hit;
+    bvh4_test_node(nodes4, cur, ro, inv_d, t, ref, n_hit);
+    if (n_hit == 0) {
+        cur = tos;
+        tos = st.read_at(--size);
+    } else {
+        cur = ref[0];
+        // bottom -> top: old tos, farthest ... third nearest; the second nearest becomes the new tos
+        const uint32_t s1 = (n_hit == 4) ? ref[3] : ref[2];
+        if (st.fast_range(size + 3)) {
+            st.write3_fast(size, tos, s1, ref[2]);
+        } else if (n_hit > 1) {
+            st.write_at(size, tos);
+            if (n_hit > 2) {
+                st.write_at(size + 1, s1);
+            }
+            if (n_hit > 3) {
+                st.write_at(size + 2, ref[2]);
+            }
+        }
+        size += n_hit - 1;
+        tos = (n_hit > 1) ? ref[1] : tos;
+    }
+}
+
 // Ordered walk over a 4-wide BLAS.  `leaf(word)` gets a reference leaf word and returns true to stop (any-hit early
 // out).  `t_ref` is re-read at every node so that hits found in earlier leaves prune.
 //
@@ -130,30 +160,14 @@ RT_HD bool walk_bvh4(const Bvh4Node *nodes4, const uint32_t root, const f3 ro, c
         if (n_node == 0 && n_leaf == 0) {
             break;
         }
+#ifdef RT_PROFILE_TRACE
+        if (int(__lane_id()) == __ffsll((long long)__ballot(1)) - 1) { // lanes waiting for a node / a leaf, loop iterations
+            ::rt::s_prof_acc[6] += (unsigned long long)n_node, ::rt::s_prof_acc[7] += (unsigned long long)n_leaf, ::rt::s_prof_acc[8] += 1ull;
+        }
+#endif
         if (n_node >= n_leaf) { // weights 2:1, 3:2, 2:3, 1:2 measured: all within 1 % or slower
             if (at_node) {
-                uint32_t ref[4], n_hit;
-                bvh4_test_node(nodes4, cur, ro, inv_d, t_ref, ref, n_hit);
-                if (n_hit == 0) {
-                    cur = tos;
-                    tos = st.read_at(--size);
-                } else {
-                    cur = ref[0];
-                    const uint32_t s1 = (n_hit == 4) ? ref[3] : ref[2];
-                    if (st.fast_range(size + 3)) {
-                        st.write3_fast(size, tos, s1, ref[2]);
-                    } else if (n_hit > 1) {
-                        st.write_at(size, tos);
-                        if (n_hit > 2) {
-                            st.write_at(size + 1, s1);
-                        }
-                        if (n_hit > 3) {
-                            st.write_at(size + 2, ref[2]);
-                        }
-                    }
-                    size += n_hit - 1;
-                    tos = (n_hit > 1) ? ref[1] : tos;
-                }
+                bvh4_visit(nodes4, ro, inv_d, t_ref, st, cur, tos, size);
             }
         } else if (at_leaf) {
             if (leaf(cur)) {
@@ -172,29 +186,7 @@ RT_HD bool walk_bvh4(const Bvh4Node *nodes4, const uint32_t root, const f3 ro, c
 #else // one ray at a time (host build of the same walk; tests/hostsim)
     for (;;) {
         while ((cur & BVH2_PRIM_COUNT_BITS) == 0 && cur != BVH4_SENTINEL) {
-            uint32_t ref[4], n_hit;
-            bvh4_test_node(nodes4, cur, ro, inv_d, t_ref, ref, n_hit);
-            if (n_hit == 0) {
-                cur = tos;
-                tos = st.read_at(--size);
-            } else {
-                cur = ref[0];
-                // bottom -> top: old tos, farthest ... third nearest; the second nearest becomes the new tos
-                const uint32_t s1 = (n_hit == 4) ? ref[3] : ref[2];
-                if (st.fast_range(size + 3)) {
-                    st.write3_fast(size, tos, s1, ref[2]);
-                } else if (n_hit > 1) {
-                    st.write_at(size, tos);
-                    if (n_hit > 2) {
-                        st.write_at(size + 1, s1);
-                    }
-                    if (n_hit > 3) {
-                        st.write_at(size + 2, ref[2]);
-                    }
-                }
-                size += n_hit - 1;
-                tos = (n_hit > 1) ? ref[1] : tos;
-            }
+            bvh4_visit(nodes4, ro, inv_d, t_ref, st, cur, tos, size);
             RT_PROF_T(19)
         }
         if (cur == BVH4_SENTINEL) {

@@ -251,6 +251,23 @@ def test_iteration_batching_is_bit_identical(gpu_lib, name):
     assert np.array_equal(a.readback(hip.BUF_RAW), b.readback(hip.BUF_RAW))
 
 
+def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
+    """RAYHIP_REFILL=1: the persistent ray-refill form of the closest-hit kernel (kernels.hip.h) performs the same node
+    visits and triangle tests per ray, only interleaved differently between lanes -- hits and frames must be the same
+    bits, transparency rounds (cornell_principled) and all analytic lights (cornell_lights) included"""
+    for name in ("cornell_principled", "cornell_lights"):
+        g = util.golden_ref(name)
+        base = util.make_context(gpu_lib, name)
+        monkeypatch.setenv("RAYHIP_REFILL", "1")
+        ref = util.make_context(gpu_lib, name)
+        monkeypatch.delenv("RAYHIP_REFILL")
+        _, h0, _ = base.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
+        _, h1, _ = ref.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
+        assert h0.tobytes() == h1.tobytes()
+        base.render_batch(1, 6), ref.render_batch(1, 6)
+        assert np.array_equal(base.readback(hip.BUF_RAW), ref.readback(hip.BUF_RAW))
+
+
 def test_maximal_batch_and_row_limit_split(gpu_lib):
     """a full 64-layer pass, and a frame tall enough that the 16-bit row limit cuts the pass (rayhip_max_batch): both must
     equal the iterations rendered one by one"""

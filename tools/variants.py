@@ -42,7 +42,7 @@ def build_one(name, flags):
     for line in r.stderr.splitlines():
         if "Function Name:" in line:
             cur = line.split("Function Name:")[1].split("[")[0].strip()
-            cur = "closest" if "k_trace_closestILb0" in cur else "shadow" if "k_trace_shadowILb0" in cur else \
+            cur = "refill" if "k_trace_closest_refill" in cur else "closest" if "k_trace_closestILb0" in cur else "shadow" if "k_trace_shadowILb0" in cur else \
                 "shade" if "k_shadeILb0" in cur else None
         elif cur and any(k in line for k in ("VGPRs:", "ScratchSize", "Occupancy", "LDS Size")):
             body = line.split("remark:")[1].rsplit("[-Rpass", 1)[0]
@@ -82,6 +82,10 @@ def run1(name, workload="sponza", K=16):
     pmj = np.load(os.path.join(ROOT, "tests", "golden", "pmj02_samples.npy"))
     ref_path = f"/tmp/variants_ref_{workload}_{K}_{os.environ.get('RT_RES_SCALE', '1')}.npy"
     ref_img = np.load(ref_path) if os.path.exists(ref_path) else None
+    for f in VARIANTS[name]:  # "+env:NAME=VALUE" pseudo-flags: run-time switches of librayhip for this variant
+        if f.startswith("+env:"):
+            k, v = f[5:].split("=", 1)
+            os.environ[k] = v
     if True:
         path = os.path.join(VDIR, name, "librayhip.so")
         L = hip.Library(path)
@@ -130,9 +134,16 @@ def run1(name, workload="sponza", K=16):
             f.argtypes, f.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong * 32), ctypes.c_int], ctypes.c_int
             buf = (ctypes.c_ulonglong * 32)()
             f(ctx._ctx, ctypes.byref(buf), 1)
-            for it in range(100, 100 + K):
-                ctx.render(it)
+            if os.environ.get("RT_PROF_RAW"):
+                print("  raw (timed passes):", list(buf))
+            if batch > 1:
+                ctx.render_batch(100, K)
+            else:
+                for it in range(100, 100 + K):
+                    ctx.render(it)
             f(ctx._ctx, ctypes.byref(buf), 1)
+            if os.environ.get("RT_PROF_RAW"):
+                print("  raw:", list(buf))
             names = {0: "load ray+hit", 1: "miss/env", 2: "light hit", 3: "surface setup (verts, TBN, lod)", 4: "mix + normal map + tangent",
                      5: "NEE: per-type light sample", 15: "NEE: light-tree descent", 6: "textures + ray init", 7: "diffuse eval+sample", 8: "glossy eval+sample",
                      9: "refractive eval+sample", 10: "emissive", 11: "principled setup", 12: "principled eval",
@@ -142,10 +153,18 @@ def run1(name, workload="sponza", K=16):
                      19: "K2 node: push/pop (LDS)", 20: "K2 leaf: before tri fetch", 21: "K2 leaf: wait for first tri",
                      22: "K2 leaf: tri tests (+prefetch waits)", 23: "K2 TLAS: instance transform", 24: "K2 chunk fetch",
                      25: "K2 ray load", 26: "K2 scene walk residue", 27: "K2 store + exit"}
+            if buf[11] + buf[12] + buf[13] + buf[14]:
+                names.update({24: "refill: phase selection", 19: "refill: phase A (node visits)", 26: "refill: phase B (leaves)", 23: "refill: phase C (TLAS)", 25: "refill: phase D (finish + refill)"})
             if buf[1] and "PROFILE_TRACE" in " ".join(VARIANTS[name]):
                 print(f"  lane utilisation: node visits {buf[0] / buf[1] / 64:.3f} ({buf[1]} wave-level visits), "
                       f"triangle tests {buf[2] / max(buf[3], 1) / 64:.3f} ({buf[3]}), instance entries {buf[4] / max(buf[5], 1) / 64:.3f} ({buf[5]})")
-                for k in range(8):
+                if buf[8]:
+                    print(f"  majority loop: {buf[8]} iterations; lanes at a node {buf[6] / buf[8] / 64:.3f}, at a leaf {buf[7] / buf[8] / 64:.3f}, "
+                          f"done or idle {1 - (buf[6] + buf[7]) / buf[8] / 64:.3f}")
+                if buf[11] + buf[12] + buf[13] + buf[14]:
+                    print(f"  refill kernel: lanes at TLAS work {buf[9] / buf[8] / 64:.3f}, finishing or idle {buf[10] / buf[8] / 64:.3f}; "
+                          f"phases A {buf[11]} B {buf[12]} C {buf[13]} D {buf[14]}")
+                for k in range(16):
                     buf[k] = 0
             tot = float(sum(buf)) or 1.0
             print("  wave time by section:")
