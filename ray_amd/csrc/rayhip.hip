@@ -527,13 +527,9 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     UP(li_indices)
     UP(light_cwnodes)
     { // node-only half of the light-tree importance, evaluated once per scene (rt_lights.h: decode_lnode_child)
-        std::vector<float4> lc(size_t(d->light_cwnodes_count) * 24);
+        std::vector<float4> lc(size_t(d->light_cwnodes_count) * LIGHT_CHILDREN_STRIDE);
         for (uint32_t n = 0; n < d->light_cwnodes_count; ++n) {
-            for (int i = 0; i < 8; ++i) {
-                const LNodeChild ch = decode_lnode_child(d->light_cwnodes[n], i);
-                float4 *o = &lc[(size_t(n) * 8 + size_t(i)) * 3];
-                o[0] = ch.axis_extent, o[1] = ch.pc_valid, o[2] = ch.cosines;
-            }
+            fill_light_children(d->light_cwnodes[n], &lc[size_t(n) * LIGHT_CHILDREN_STRIDE]);
         }
         if (upload(c, c->light_children, lc.data(), lc.size() * sizeof(float4))) {
             return 1;

@@ -357,13 +357,33 @@ RT_HD float lnode_child_importance(const LNodeChild &ch, const f3 P) {
     return imp;
 }
 
-// importance of the eight children of light-tree node `node_index` (through the table decode_lnode_child filled)
-RT_HD void calc_lnode_importance(const SceneView &sc, const uint32_t node_index, const f3 P, float importance[8]) {
-    const float4 *t = sc.light_children + size_t(node_index) * 24;
+// `light_children` table: LIGHT_CHILDREN_STRIDE float4 per light-tree node -- [0..1] the eight fluxes, then three float4
+// (LNodeChild) per child.  The fluxes come first because the reference's 8-wide tree is sparsely filled (Sponza-class
+// scene: 31 of 41 nodes hold two children, 57 % of all slots are empty) and an empty or black slot needs nothing else:
+// two loads tell a lane which of the 24 others to issue.  The descent is bound by the texture addresser, not by
+// arithmetic (384 B per lane and level before), so the loads not issued are the saving.
+constexpr int LIGHT_CHILDREN_STRIDE = 26;
+RT_HD void fill_light_children(const rayhip_light_cwbvh_node &n, float4 *out /* [LIGHT_CHILDREN_STRIDE] */) {
+    out[0] = mkfloat4(n.flux[0], n.flux[1], n.flux[2], n.flux[3]);
+    out[1] = mkfloat4(n.flux[4], n.flux[5], n.flux[6], n.flux[7]);
     for (int i = 0; i < 8; ++i) {
-        LNodeChild ch;
-        ch.axis_extent = t[3 * i + 0], ch.pc_valid = t[3 * i + 1], ch.cosines = t[3 * i + 2];
-        importance[i] = lnode_child_importance(ch, P);
+        const LNodeChild ch = decode_lnode_child(n, i);
+        out[2 + 3 * i + 0] = ch.axis_extent, out[2 + 3 * i + 1] = ch.pc_valid, out[2 + 3 * i + 2] = ch.cosines;
+    }
+}
+
+// importance of the eight children of light-tree node `node_index` (through the table fill_light_children filled)
+RT_HD void calc_lnode_importance(const SceneView &sc, const uint32_t node_index, const f3 P, float importance[8]) {
+    const float4 *t = sc.light_children + size_t(node_index) * LIGHT_CHILDREN_STRIDE;
+    const float4 f0 = t[0], f1 = t[1];
+    const float flux[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    for (int i = 0; i < 8; ++i) {
+        importance[i] = flux[i]; // (zero flux: lnode_child_importance returns the flux itself)
+        if (flux[i] != 0.0f) {
+            LNodeChild ch;
+            ch.axis_extent = t[2 + 3 * i + 0], ch.pc_valid = t[2 + 3 * i + 1], ch.cosines = t[2 + 3 * i + 2];
+            importance[i] = lnode_child_importance(ch, P);
+        }
     }
 }
 // hsum(fvec4{imp[0..3]} + fvec4{imp[4..7]}), SSE2 hsum order

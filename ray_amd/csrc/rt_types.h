@@ -33,7 +33,7 @@ struct SceneView {
     const rayhip_light *lights;
     const uint32_t *li_indices;
     const rayhip_light_cwbvh_node *light_cwnodes;
-    const float4 *light_children; // 24 float4 per light-tree node: decode_lnode_child of its 8 children (rt_lights.h)
+    const float4 *light_children; // LIGHT_CHILDREN_STRIDE float4 per light-tree node (rt_lights.h: fill_light_children)
     const rayhip_texture *textures;
     const uint32_t *texels;
     const float4 *env_qtree;       // env-map importance quadtree: quads of all lods, lod 0 first (rayhip.h)

@@ -123,13 +123,9 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     CP(lights);
     CP(li_indices);
     CP(light_cwnodes);
-    s.light_children.resize(size_t(d->light_cwnodes_count) * 24);
+    s.light_children.resize(size_t(d->light_cwnodes_count) * LIGHT_CHILDREN_STRIDE);
     for (uint32_t n = 0; n < d->light_cwnodes_count; ++n) {
-        for (int i = 0; i < 8; ++i) {
-            const LNodeChild ch = decode_lnode_child(d->light_cwnodes[n], i);
-            float4 *o = &s.light_children[(size_t(n) * 8 + size_t(i)) * 3];
-            o[0] = ch.axis_extent, o[1] = ch.pc_valid, o[2] = ch.cosines;
-        }
+        fill_light_children(d->light_cwnodes[n], &s.light_children[size_t(n) * LIGHT_CHILDREN_STRIDE]);
     }
     CP(textures);
     CP(texels);
