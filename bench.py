@@ -130,7 +130,7 @@ def cpu_baseline(wl, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--steps", type=int, default=480)  # 8 passes of 60 iterations on one GPU, 1 pass of 480 on each of 8
     ap.add_argument("--warmup", type=int, default=60)  # one full pass of 60 iterations (1080p), the shape of the timed passes
     ap.add_argument("--workload", default=os.environ.get("RAY_AMD_WORKLOAD", "bistro"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,6 +173,7 @@ def main():
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
 
     batch = int(os.environ.get("RAY_AMD_BATCH", "0")) or multigpu.batch_size(W * H // world, ctx.max_batch(), K)
+    ctx.reserve_batch(batch)  # (the shard is set: a rank's buffers are sized for its share of the frame)
     it = 0
     if Wm > 0:  # untimed warm-up with the same pass shape (allocates the layered buffers)
         done = 0

@@ -330,11 +330,16 @@ RAYHIP_API int rayhip_render(rayhip_ctx *ctx, const rayhip_camera *cam, const in
  * iteration when adaptive sampling is active (variance_threshold != 0) or RAYHIP_FLAG_SORT_RAYS is set. */
 RAYHIP_API int rayhip_render_batch(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int first_iteration,
                                    int count, uint32_t flags, rayhip_stats *stats);
-/* Largest number of iterations one wavefront pass of the current frame can carry: min(64, 65535 / frame height) (the
- * layers of a pass are stacked into one virtual frame whose rows must fit the 16-bit pixel coordinate of ray_data_t::xy,
- * internal/Core.h).  rayhip_render_batch splits longer runs itself; callers that choose the run length (RendererHIP's
- * deferred RenderScene calls, bench.py) use this to cut a render into passes of equal size.  0 before rayhip_resize. */
+/* Largest number of iterations one wavefront pass of the current frame can carry:
+ * min(512, (65535 / width) * (65535 / height)) -- the layers of a pass are stacked side by side and on top of each other
+ * in one virtual frame whose coordinates must fit the two 16-bit halves of ray_data_t::xy (internal/Core.h).
+ * rayhip_render_batch splits longer runs itself; callers that choose the run length (RendererHIP's deferred RenderScene
+ * calls, bench.py) use this to cut a render into passes of equal size.  Memory: about 0.3 KB of wavefront state per ray
+ * in flight plus 48 B per pixel and layer.  0 before rayhip_resize. */
 RAYHIP_API int rayhip_max_batch(rayhip_ctx *ctx);
+/* Allocate now what passes of `count` iterations over the whole frame need under the current shard (otherwise the
+ * first such rayhip_render_batch does it, synchronising the stream). */
+RAYHIP_API int rayhip_reserve_batch(rayhip_ctx *ctx, int count);
 
 /* Multi-GPU tile sharding (new): this context renders only the pixels of the tile x tile
  * squares (row-major walk over the frame) whose ordinal % shard_count == shard_index; all other pixels of its

@@ -225,22 +225,63 @@ struct AccumLayers {
 
 __device__ __forceinline__ uint32_t layer_rand_seed(const int iteration) { return hash(uint32_t((iteration - 1) / RAND_SAMPLES_COUNT)); }
 
+// which 8x8 pixel tiles the ray generator walks (see k_raygen)
+struct RayGenTiling {
+    uint32_t tiles;         // 8x8 tiles per layer
+    uint32_t tiles_x;       // unsharded: tiles per row of the rect
+    uint32_t owned_only;    // 1: walk only the shard tiles this rank owns
+    uint32_t sub;           // 8x8 tiles per shard-tile side (shard.tile / 8)
+    uint32_t shard_tiles_x; // shard tiles per frame row
+};
+// host and device: the tiling of a rect under a shard (owned_only needs shard tiles that are whole 8x8 tiles)
+__host__ __device__ inline RayGenTiling make_raygen_tiling(const int frame_w, const int frame_h, const int rect_w, const int rect_h, const Shard sh) {
+    RayGenTiling t;
+    t.tiles_x = uint32_t(rect_w + 7) / 8u;
+    t.tiles = t.tiles_x * (uint32_t(rect_h + 7) / 8u);
+    t.owned_only = 0, t.sub = 1, t.shard_tiles_x = 1;
+    if (sh.count > 1 && sh.tile % 8 == 0) {
+        const uint32_t stx = uint32_t(frame_w + sh.tile - 1) / uint32_t(sh.tile), sty = uint32_t(frame_h + sh.tile - 1) / uint32_t(sh.tile);
+        const uint32_t total = stx * sty;
+        const uint32_t owned = total > uint32_t(sh.index) ? (total - uint32_t(sh.index) + uint32_t(sh.count) - 1u) / uint32_t(sh.count) : 0u;
+        t.owned_only = 1, t.sub = uint32_t(sh.tile) / 8u, t.shard_tiles_x = stx;
+        t.tiles = owned * t.sub * t.sub;
+    }
+    return t;
+}
+
 // ---- K1 ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint32_t *__restrict__ pmj,
                                                const float *__restrict__ filter_table,
                                                const uint16_t *__restrict__ required_samples, const RaySoA rays,
-                                               const HitSoA hits, const RayQueue out, const Layering layers) {
+                                               const HitSoA hits, const RayQueue out, const Layering layers,
+                                               const RayGenTiling tiling) {
     // one wavefront = one 8x8 pixel tile: primary rays of a wave start coherent in both directions, so they share
     // BVH nodes in K2 and materials in the primary shade (a 64x1 strip only is coherent along x)
-    const uint32_t tiles_x = uint32_t(p.rect[2] + 7) / 8u, tiles_y = uint32_t(p.rect[3] + 7) / 8u;
-    const uint32_t tiles = tiles_x * tiles_y, n_chunks = tiles * uint32_t(layers.count), waves_per_block = blockDim.x / WAVE;
+    //
+    // Which 8x8 tiles a pass walks (RayGenTiling, computed on the host):
+    //   * unsharded: the tiles of the rect, row-major from the rect's corner;
+    //   * tile-sharded (rayhip_set_shard): only the 8x8 tiles inside the shard tiles this rank owns, frame-aligned --
+    //     owned shard tile j is frame tile shard.index + j * shard.count -- so that the chunk numbering, the stripes and
+    //     the wavefront-state buffers are as dense as the rank's share of the frame, not as the frame.
+    const uint32_t tiles = tiling.tiles, n_chunks = tiles * uint32_t(layers.count), waves_per_block = blockDim.x / WAVE;
     const uint32_t lane = threadIdx.x % WAVE;
     // pixel chunk pc -> stripe pc % stripes: every stripe gets at most ceil(n_chunks / stripes) chunks
     for (uint32_t pc = blockIdx.x * waves_per_block + threadIdx.x / WAVE; pc < n_chunks; pc += gridDim.x * waves_per_block) {
         const uint32_t layer = pc / tiles, tile = pc % tiles; // wave-uniform
-        const int lx = int((tile % tiles_x) * 8u + (lane & 7u)), ly = int((tile / tiles_x) * 8u + (lane >> 3));
-        const bool in_rect = lx < p.rect[2] && ly < p.rect[3];
-        const int x = p.rect[0] + (in_rect ? lx : 0), y = p.rect[1] + (in_rect ? ly : 0);
+        int x, y;
+        bool in_rect;
+        if (tiling.owned_only) {
+            const uint32_t sub_n = tiling.sub * tiling.sub, owned = tile / sub_n, sub = tile % sub_n;
+            const uint32_t t = uint32_t(p.shard.index) + owned * uint32_t(p.shard.count); // frame shard-tile ordinal
+            x = int((t % tiling.shard_tiles_x) * uint32_t(p.shard.tile) + (sub % tiling.sub) * 8u + (lane & 7u));
+            y = int((t / tiling.shard_tiles_x) * uint32_t(p.shard.tile) + (sub / tiling.sub) * 8u + (lane >> 3));
+            in_rect = x >= p.rect[0] && y >= p.rect[1] && x < p.rect[0] + p.rect[2] && y < p.rect[1] + p.rect[3];
+            x = in_rect ? x : p.rect[0], y = in_rect ? y : p.rect[1];
+        } else {
+            const int lx = int((tile % tiling.tiles_x) * 8u + (lane & 7u)), ly = int((tile / tiling.tiles_x) * 8u + (lane >> 3));
+            in_rect = lx < p.rect[2] && ly < p.rect[3];
+            x = p.rect[0] + (in_rect ? lx : 0), y = p.rect[1] + (in_rect ? ly : 0);
+        }
         // (a batch is only formed when adaptive sampling is inert, so the check of the first iteration holds for all)
         const bool live = in_rect && pixel_owned(p.shard, p.w, x, y) && !(required_samples[y * p.w + x] < p.iteration);
         const uint32_t slot = out.alloc(pc % out.stripes, live);
@@ -254,7 +295,7 @@ __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint
                 pl.iteration = p.iteration + int(layer);
                 pl.rand_seed = layer_rand_seed(pl.iteration);
                 generate_primary_ray(pl, pmj, filter_table, x, y, r, h);
-                r.xy += layer * uint32_t(layers.frame_h);
+                r.xy += layer_offset_xy(layers, layer);
             }
             store_ray(rays, slot, r);
             store_hit(hits, slot, h);
@@ -854,33 +895,36 @@ __global__ void __launch_bounds__(256) k_reorder_rays(const RaySoA src, const Ra
 }
 
 // ---- K10 + K11 ----------------------------------------------------------------------------------------------
+// Batched passes: `per_layer` describes layers [layer_base, layer_base + layer_count) (kernel arguments hold at most
+// MAX_BATCH of them; longer passes fold their layers in several launches, in order).
 __global__ void __launch_bounds__(256) k_accumulate(const AccumParams p, const PixelBuffers px, const Layering layers,
-                                                   const AccumLayers per_layer) {
+                                                   const AccumLayers per_layer, const int layer_base, const int layer_count) {
     const int n = p.rect[2] * p.rect[3];
-    const size_t layer_px = size_t(p.w) * size_t(layers.frame_h);
+    const size_t pitch = size_t(virtual_width(layers));
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int x = p.rect[0] + i % p.rect[2], y = p.rect[1] + i / p.rect[2];
         if (!pixel_owned(p.shard, p.w, x, y)) {
             continue; // another rank's pixel: stays zero here, filled in by the frame reduce
         }
         if (layers.count <= 1) {
-            accumulate_pixel(p, x, y, px.temp, px.temp, px.full, px.half, px.raw, px.final_, px.required_samples);
+            accumulate_pixel(p, x, y, px.temp + (y * p.w + x), px.temp + (y * p.w + x), px.full, px.half, px.raw, px.final_, px.required_samples);
             continue;
         }
         // batched pass: fold the layers into the running means in iteration order (what one call per iteration does)
         const int idx = y * p.w + x;
-        for (int l = 0; l < layers.count; ++l) {
+        for (int k = 0; k < layer_count; ++k) {
             AccumParams pl = p;
-            pl.iteration = per_layer.l[l].iteration;
-            pl.mix_factor = per_layer.l[l].mix_factor, pl.half_mix_factor = per_layer.l[l].half_mix_factor;
-            pl.is_class_a = per_layer.l[l].is_class_a, pl.variance_threshold = per_layer.l[l].variance_threshold;
+            pl.iteration = per_layer.l[k].iteration;
+            pl.mix_factor = per_layer.l[k].mix_factor, pl.half_mix_factor = per_layer.l[k].half_mix_factor;
+            pl.is_class_a = per_layer.l[k].is_class_a, pl.variance_threshold = per_layer.l[k].variance_threshold;
+            // this pixel on layer layer_base + k of the virtual frame
+            const uint32_t off = layer_offset_xy(layers, uint32_t(layer_base + k));
+            const size_t vidx = (size_t(off & 0xffffu) + size_t(y)) * pitch + size_t(off >> 16) + size_t(x);
             // (a one-by-one run samples the pixel in this iteration iff the previous accumulate left it queued)
             if (!(px.required_samples[idx] < pl.iteration)) {
-                blend_aux_pixel(idx, px.aux_base_layers[size_t(l) * layer_px + idx], px.aux_dn_layers[size_t(l) * layer_px + idx],
-                                pl.mix_factor, px.base_color, px.depth_normals);
+                blend_aux_pixel(idx, px.aux_base_layers[vidx], px.aux_dn_layers[vidx], pl.mix_factor, px.base_color, px.depth_normals);
             }
-            accumulate_pixel(pl, x, y, px.temp + size_t(l) * layer_px, px.temp, px.full, px.half, px.raw, px.final_,
-                             px.required_samples);
+            accumulate_pixel(pl, x, y, px.temp + vidx, px.temp + vidx, px.full, px.half, px.raw, px.final_, px.required_samples);
         }
     }
 }

@@ -91,7 +91,7 @@ struct rayhip_ctx {
     // frame
     int w = 0, h = 0;
     DevBuf px_temp, px_full, px_half, px_raw, px_final, px_base, px_dn, px_req, px_aux_base, px_aux_dn;
-    int layers_cap = 1; // iterations a batched pass can hold with the current buffers (rayhip_render_batch grows it)
+    size_t slots_cap = 0; // wavefront-state slots allocated
     PixelBuffers px = {};
 
     // wavefront state, sized w*h
@@ -157,10 +157,33 @@ int use_device(rayhip_ctx *c) {
 // wavefront-state slots a w x h rect needs: ray generation deals whole 8x8 pixel tiles (k_raygen)
 size_t tile_slots(int w, int h) { return size_t((w + 7) / 8) * size_t((h + 7) / 8) * 64u; }
 
+// Most iterations one pass can carry (Layering, rt_base.h): layers are stacked `cols` wide and `rows` high in a virtual
+// frame whose coordinates must fit the two 16-bit halves of ray_data_t::xy.
+constexpr int MAX_LAYERS = 512;
+int max_layers_for(int w, int h) {
+    if (w <= 0 || h <= 0) {
+        return 0;
+    }
+    return int(std::max<size_t>(1, std::min<size_t>(size_t(MAX_LAYERS), size_t(65535 / w) * size_t(65535 / h))));
+}
+// the virtual frame of a pass of `layers` iterations: as few columns as the row limit allows
+Layering make_layering(int w, int h, int layers) {
+    const int max_rows = std::max(1, 65535 / h);
+    const int cols = (layers + max_rows - 1) / max_rows;
+    return Layering{h, layers, w, std::max(1, cols)};
+}
+int layer_rows(const Layering &L) { return (L.count + L.cols - 1) / L.cols; }
+// slots a pass of `layers` iterations over a rect needs under the context's shard (k_raygen's tiling)
+size_t pass_slots(const rayhip_ctx *c, int frame_w, int frame_h, int rect_w, int rect_h, int layers) {
+    return size_t(make_raygen_tiling(frame_w, frame_h, rect_w, rect_h, c->shard).tiles) * 64u * size_t(layers);
+}
+
 int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
     const size_t npix = size_t(w) * size_t(h);
-    if (c->px_temp.alloc(npix * 16 * size_t(layers)) ||
-        (layers > 1 && (c->px_aux_base.alloc(npix * 16 * size_t(layers)) || c->px_aux_dn.alloc(npix * 16 * size_t(layers)))) || c->px_full.alloc(npix * 16) || c->px_half.alloc(npix * 16) || c->px_raw.alloc(npix * 16) ||
+    const Layering L = make_layering(w, h, layers);
+    const size_t vpix = npix * size_t(L.cols) * size_t(layer_rows(L)); // the virtual frame (>= npix * layers)
+    if (c->px_temp.alloc(vpix * 16) ||
+        (layers > 1 && (c->px_aux_base.alloc(vpix * 16) || c->px_aux_dn.alloc(vpix * 16))) || c->px_full.alloc(npix * 16) || c->px_half.alloc(npix * 16) || c->px_raw.alloc(npix * 16) ||
         c->px_final.alloc(npix * 16) || c->px_base.alloc(npix * 16) || c->px_dn.alloc(npix * 16) || c->px_req.alloc(npix * 2)) {
         return 1;
     }
@@ -169,10 +192,12 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
     c->px.base_color = c->px_base.as<float4>(), c->px.depth_normals = c->px_dn.as<float4>();
     c->px.required_samples = c->px_req.as<uint16_t>();
     c->px.aux_base_layers = c->px_aux_base.as<float4>(), c->px.aux_dn_layers = c->px_aux_dn.as<float4>();
-    c->layers_cap = layers;
 
-    // wavefront-state slots: one per pixel + the rounding of the striped queues (each stripe holds whole chunks)
-    const size_t n = tile_slots(w, h) * size_t(layers) + size_t(WAVE) * QUEUE_MAX_STRIPES;
+    // wavefront-state slots: one per pixel this context renders (its shard's share when the frame is tile-sharded, but
+    // never less than one full frame: the kernel-level hooks and single-iteration passes of any shard fit) + the
+    // rounding of the striped queues (each stripe holds whole chunks)
+    const size_t n = std::max(tile_slots(w, h), pass_slots(c, w, h, w, h, layers)) + size_t(WAVE) * QUEUE_MAX_STRIPES;
+    c->slots_cap = std::max(c->slots_cap, n); // (DevBuf never shrinks)
     for (int k = 0; k < 2; ++k) {
         for (int pl = 0; pl < 5; ++pl) {
             if (c->ray_planes[k][pl].alloc(n * (pl == 4 ? 8 : 16))) {
@@ -198,12 +223,14 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
         return 1;
     }
     c->deferred.a = c->deferred_planes[0].as<float4>(), c->deferred.b = c->deferred_planes[1].as<float4>();
+    // the ray sort only runs on single-iteration passes
+    const size_t n_sort = tile_slots(w, h) + size_t(WAVE) * QUEUE_MAX_STRIPES;
     size_t temp_bytes = 0;
-    if (sort_pairs_temp_bytes(n, SORT_KEY_BITS, &temp_bytes) != hipSuccess) {
+    if (sort_pairs_temp_bytes(n_sort, SORT_KEY_BITS, &temp_bytes) != hipSuccess) {
         return fail("rocPRIM temp-size query failed");
     }
-    if (c->sort_keys[0].alloc(n * 4) || c->sort_keys[1].alloc(n * 4) || c->sort_idx[0].alloc(n * 4) ||
-        c->sort_idx[1].alloc(n * 4) || c->sort_temp.alloc(temp_bytes)) {
+    if (c->sort_keys[0].alloc(n_sort * 4) || c->sort_keys[1].alloc(n_sort * 4) || c->sort_idx[0].alloc(n_sort * 4) ||
+        c->sort_idx[1].alloc(n_sort * 4) || c->sort_temp.alloc(temp_bytes)) {
         return 1;
     }
     return 0;
@@ -411,7 +438,7 @@ int rayhip_resize(rayhip_ctx *c, int w, int h) {
         return 0;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (alloc_frame(c, w, h, c->layers_cap)) {
+    if (alloc_frame(c, w, h, 1)) {
         return 1;
     }
     c->w = w, c->h = h;
@@ -617,6 +644,24 @@ int rayhip_scene_upload_blob(rayhip_ctx *c, const void *blob, size_t size, rayhi
     return 0;
 }
 
+// do the allocated per-iteration pixel buffers and wavefront state hold a pass of `n` iterations over `rect`?
+static bool pass_fits(const rayhip_ctx *c, const int rect[4], int n) {
+    const Layering L = make_layering(c->w, c->h, n);
+    const size_t vbytes = size_t(c->w) * size_t(c->h) * size_t(L.cols) * size_t(layer_rows(L)) * 16u;
+    return vbytes <= c->px_temp.bytes && (n <= 1 || (vbytes <= c->px_aux_base.bytes && vbytes <= c->px_aux_dn.bytes)) &&
+           pass_slots(c, c->w, c->h, rect[2], rect[3], n) + size_t(WAVE) * QUEUE_MAX_STRIPES <= c->slots_cap;
+}
+// grow the per-iteration pixel buffers / the wavefront state if a pass of `n` iterations over `rect` needs more
+static int ensure_pass(rayhip_ctx *c, const int rect[4], int n) {
+    if (!pass_fits(c, rect, n)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (alloc_frame(c, c->w, c->h, n)) {
+            return 1;
+        }
+    }
+    return 0;
+}
+
 // One wavefront pass over `count` consecutive iterations of the rect (count == 1: the plain case; > 1: layered, see
 // Layering in rt_base.h).  The caller has checked that a batch is admissible.
 static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration, int count_iterations,
@@ -647,9 +692,14 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     const bool sort_rays = (flags & RAYHIP_FLAG_SORT_RAYS) != 0;
     hipStream_t s = c->stream;
     const size_t npix = size_t(rect[2]) * size_t(rect[3]);
-    const Layering layers = {c->h, count_iterations};
-    // ray slots of this rect (whole 8x8 tiles), one set per iteration in flight
-    const size_t nslots = tile_slots(rect[2], rect[3]) * size_t(count_iterations);
+    const Layering layers = make_layering(c->w, c->h, count_iterations);
+    const int vw = virtual_width(layers); // row pitch of the per-iteration pixel buffers
+    // ray slots: the 8x8 tiles the ray generator walks (this rank's share under a shard), one set per iteration in flight
+    const RayGenTiling tiling = make_raygen_tiling(c->w, c->h, rect[2], rect[3], c->shard);
+    const size_t nslots = size_t(tiling.tiles) * 64u * size_t(count_iterations);
+    if (!pass_fits(c, rect, count_iterations)) {
+        return fail("internal: pass of %d iterations exceeds the allocated wavefront state", count_iterations);
+    }
     const int gw = c->grid_waves;
     const int gtrace = int(std::min<size_t>(size_t(gw), nslots / WAVE));
     unsigned long long *tc = c->trav_counters.as<unsigned long long>();
@@ -685,7 +735,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         return 1;
     }
     k_raygen<<<grid_for(c, nslots, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
-                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, stripes), layers);
+                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, stripes), layers, tiling);
     if (tm.mark(ST_PTRACE, 0)) {
         return 1;
     }
@@ -725,15 +775,15 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
                                                   c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
                                                   c->shadow_queue(bounce, nslots, stripes), c->deferred,
-                                                  c->deferred_queue(bounce, nslots, stripes), c->px, c->w, mix_factor, layers);
+                                                  c->deferred_queue(bounce, nslots, stripes), c->px, vw, mix_factor, layers);
         } else {
             k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
                                                    c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
                                                    c->shadow_queue(bounce, nslots, stripes), c->deferred,
-                                                   c->deferred_queue(bounce, nslots, stripes), c->px, c->w, mix_factor, layers);
+                                                   c->deferred_queue(bounce, nslots, stripes), c->px, vw, mix_factor, layers);
             // emitter hits whose MIS weight was deferred (kernels.hip.h); an empty queue costs a few microseconds
             k_shade_emissive<<<std::min(gtrace, 2048), WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred,
-                                                     c->deferred_queue(bounce, nslots, stripes), c->px, c->w);
+                                                     c->deferred_queue(bounce, nslots, stripes), c->px, vw);
         }
         if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
             return 1;
@@ -744,13 +794,13 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         }
         if (count) {
             k_trace_shadow<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                c->w, c->px.temp, nullptr, spill, tc + 5, layers);
+                                                                vw, c->px.temp, nullptr, spill, tc + 5, layers);
         } else if (c->sc.nodes4) {
             k_trace_shadow<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                c->w, c->px.temp, nullptr, spill, tc + 5, layers);
+                                                                vw, c->px.temp, nullptr, spill, tc + 5, layers);
         } else {
             k_trace_shadow<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                 c->w, c->px.temp, nullptr, spill, tc + 5, layers);
+                                                                 vw, c->px.temp, nullptr, spill, tc + 5, layers);
         }
         cur ^= 1;
     }
@@ -758,12 +808,15 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         return 1;
     }
     const AccumParams ap = make_accum_params(*cam, c->w, rect, iteration, c->shard);
-    AccumLayers per_layer = {};
-    for (int l = 0; l < count_iterations; ++l) {
-        const AccumParams al = make_accum_params(*cam, c->w, rect, iteration + l, c->shard);
-        per_layer.l[l] = AccumLayer{al.iteration, al.mix_factor, al.half_mix_factor, al.is_class_a, al.variance_threshold};
+    for (int base = 0; base < count_iterations; base += MAX_BATCH) { // the layers are folded in iteration order
+        const int n = std::min(MAX_BATCH, count_iterations - base);
+        AccumLayers per_layer = {};
+        for (int k = 0; k < n; ++k) {
+            const AccumParams al = make_accum_params(*cam, c->w, rect, iteration + base + k, c->shard);
+            per_layer.l[k] = AccumLayer{al.iteration, al.mix_factor, al.half_mix_factor, al.is_class_a, al.variance_threshold};
+        }
+        k_accumulate<<<grid_for(c, npix, 256), 256, 0, s>>>(ap, c->px, layers, per_layer, base, n);
     }
-    k_accumulate<<<grid_for(c, npix, 256), 256, 0, s>>>(ap, c->px, layers, per_layer);
     HIP_TRY(hipGetLastError());
     if (tm.mark(-1, -1)) {
         return 1;
@@ -787,7 +840,18 @@ int rayhip_max_batch(rayhip_ctx *c) {
     if (!c || !c->h) {
         return 0;
     }
-    return int(std::max<size_t>(1, std::min<size_t>(size_t(MAX_BATCH), 65535u / size_t(c->h))));
+    return max_layers_for(c->w, c->h);
+}
+
+int rayhip_reserve_batch(rayhip_ctx *c, int count) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->w) {
+        return fail("rayhip_reserve_batch before rayhip_resize");
+    }
+    const int rect[4] = {0, 0, c->w, c->h};
+    return ensure_pass(c, rect, std::max(1, std::min(count, rayhip_max_batch(c))));
 }
 
 int rayhip_render_batch(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int first_iteration, int count,
@@ -810,11 +874,8 @@ int rayhip_render_batch(rayhip_ctx *c, const rayhip_camera *cam, const int rect[
     int done = 0;
     while (done < count) {
         const int n = std::min(count - done, max_layers);
-        if (n > c->layers_cap) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (alloc_frame(c, c->w, c->h, n)) {
-                return 1;
-            }
+        if (ensure_pass(c, rect, n)) {
+            return 1;
         }
         if (render_pass(c, cam, rect, first_iteration + done, n, flags, stats)) {
             return 1;
@@ -826,6 +887,12 @@ int rayhip_render_batch(rayhip_ctx *c, const rayhip_camera *cam, const int rect[
 
 int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration, uint32_t flags,
                   rayhip_stats *stats) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (c->w && ensure_pass(c, rect, 1)) {
+        return 1;
+    }
     return render_pass(c, cam, rect, iteration, 1, flags, stats);
 }
 
@@ -958,14 +1025,15 @@ int rayhip_k_generate_primary_rays(rayhip_ctx *c, const rayhip_camera *cam, cons
         return fail("k_generate_primary_rays needs resize + upload_static + set_filter_table first");
     }
     hipStream_t s = c->stream;
-    const size_t nslots = tile_slots(rect[2], rect[3]);
+    const RayGenTiling tiling = make_raygen_tiling(c->w, c->h, rect[2], rect[3], c->shard);
+    const size_t nslots = size_t(tiling.tiles) * 64u;
     if (c->clear_queues(1, s)) {
         return fail("queue counter clear failed");
     }
     const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
     // kernel-level hooks use one dense stripe so that the host sees a plain array
     k_raygen<<<grid_for(c, nslots, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
-                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, 1), Layering{c->h, 1});
+                                                      c->rays[0], c->hits, c->ray_queue(0, nslots, 1), single_layer(c->w, c->h), tiling);
     HIP_TRY(hipGetLastError());
     uint32_t n = 0;
     HIP_TRY(hipMemcpyAsync(&n, c->ray_count(0), 4, hipMemcpyDeviceToHost, s));
@@ -1036,13 +1104,13 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     const RayQueue q = c->ray_queue(0, size_t(count), 1);
     if (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) { // instrumented walk of the reference's BVH2
-        k_trace_closest<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
+        k_trace_closest<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
     } else if (c->sc.nodes4 && c->refill_waves) { // what rayhip_render launches
-        k_trace_closest_refill<<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), Layering{c->h, 1});
+        k_trace_closest_refill<<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
     } else if (c->sc.nodes4) {
-        k_trace_closest<false, true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
+        k_trace_closest<false, true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
     } else {
-        k_trace_closest<false, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
+        k_trace_closest<false, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -1104,7 +1172,7 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     // results land in the (otherwise idle) hit plane
     k_trace_shadow<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
-                                                    c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc, Layering{c->h, 1});
+                                                    c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpyAsync(after, tc, sizeof(after), hipMemcpyDeviceToHost, s));

@@ -32,13 +32,14 @@ RT_HD float tonemap_standard(float c) {
 // TonemapRef.h:7-9
 RT_HD f4 reversible_tonemap(f4 c) { return c / (fmaxf(c.x, fmaxf(c.y, c.z)) + 1.0f); }
 
-// temp_buf: this iteration's radiance; variance_buf: where the variance estimate goes (the reference reuses temp_buf)
-RT_HD void accumulate_pixel(const AccumParams &p, const int x, const int y, const float4 *temp_buf, float4 *variance_buf,
+// temp_px: this pixel's radiance of the iteration; variance_px: where its variance estimate goes (the reference reuses
+// the temp buffer's element)
+RT_HD void accumulate_pixel(const AccumParams &p, const int x, const int y, const float4 *temp_px, float4 *variance_px,
                             float4 *full_buf, float4 *half_buf, float4 *raw_buf, float4 *final_buf, uint16_t *required_samples) {
     const int idx = y * p.w + x;
 
     if (!(required_samples[idx] < p.iteration)) {
-        const float4 t = temp_buf[idx];
+        const float4 t = *temp_px;
         // new_val = temp * {exposure, exposure, exposure, 1}
         const f4 new_val = {t.x * p.exposure, t.y * p.exposure, t.z * p.exposure, t.w * 1.0f};
         const float4 ff = full_buf[idx];
@@ -82,7 +83,7 @@ RT_HD void accumulate_pixel(const AccumParams &p, const int x, const int y, cons
     const f4 p1 = reversible_tonemap(d);
     const f4 p2 = reversible_tonemap(half_val);
     const f4 variance = 0.5f * (p1 - p2) * (p1 - p2);
-    variance_buf[idx] = mkfloat4(variance.x, variance.y, variance.z, variance.w);
+    *variance_px = mkfloat4(variance.x, variance.y, variance.z, variance.w);
 
     if (variance.x >= p.variance_threshold || variance.y >= p.variance_threshold || variance.z >= p.variance_threshold ||
         variance.w >= p.variance_threshold) {

@@ -302,9 +302,11 @@ RT_HD f3 tangent_from_world(f3 T, f3 B, f3 N, f3 V) { return f3{dot(V, T), dot(V
 // rank owns the pixels of its tiles for the whole render.  Pixels are independent (RNG is keyed by x,y,iteration:
 // CoreRef.cpp:1477-1478), so the union of the ranks' images is bit-identical to a single-GPU render.
 // Iteration batching.  Several iterations (samples per pixel) of the same rect can be in flight in ONE wavefront pass:
-// iteration first + l lives on "layer" l of a virtual frame of height layers * frame_h, i.e. a ray of pixel (x, y) on
-// layer l carries xy = (x << 16) | (y + l * frame_h) and every per-iteration buffer (temp, primary aux outputs) has
-// one frame per layer.  Whatever depends on the iteration (sample index, rand_seed, running-mean weights) is derived
+// iteration first + l lives on "layer" l of a virtual frame that is `cols` real frames wide and ceil(count / cols) high:
+// layer l sits at column l % cols, row l / cols, i.e. a ray of pixel (x, y) on layer l carries
+// xy = ((x + (l % cols) * frame_w) << 16) | (y + (l / cols) * frame_h) -- both halves of ray_data_t::xy are 16 bits, which
+// bounds a pass to (65535 / frame_w) * (65535 / frame_h) layers -- and every per-iteration buffer (temp, primary aux
+// outputs) is one such virtual frame.  Whatever depends on the iteration (sample index, rand_seed, running-mean weights) is derived
 // per ray from its layer, the random-number hash from the REAL pixel, and k_accumulate folds the layers into the
 // running means in iteration order -- so a batch is bit-identical to the same iterations rendered one by one, but a
 // launch carries layers x more rays: small frames (a GPU's share of a tile-sharded frame, 256x256 previews) fill the
@@ -312,9 +314,21 @@ RT_HD f3 tangent_from_world(f3 T, f3 B, f3 N, f3 V) { return f3{dot(V, T), dot(V
 struct Layering {
     int frame_h; // height of the real frame
     int count;   // layers in this pass (1 = plain single-iteration pass)
+    int frame_w; // width of the real frame
+    int cols;    // layers side by side in the virtual frame (>= 1)
 };
-RT_HD uint32_t xy_layer(const uint32_t xy, const Layering L) { return L.count > 1 ? (xy & 0xffffu) / uint32_t(L.frame_h) : 0u; }
-RT_HD uint32_t xy_real(const uint32_t xy, const Layering L, const uint32_t layer) { return xy - layer * uint32_t(L.frame_h); }
+RT_HD Layering single_layer(const int w, const int h) { return Layering{h, 1, w, 1}; }
+// offset of layer `layer` inside the virtual frame, in the packed form of ray_data_t::xy
+RT_HD uint32_t layer_offset_xy(const Layering L, const uint32_t layer) {
+    const uint32_t lx = layer % uint32_t(L.cols), ly = layer / uint32_t(L.cols);
+    return ((lx * uint32_t(L.frame_w)) << 16) + ly * uint32_t(L.frame_h);
+}
+RT_HD uint32_t xy_layer(const uint32_t xy, const Layering L) {
+    return L.count > 1 ? ((xy & 0xffffu) / uint32_t(L.frame_h)) * uint32_t(L.cols) + (xy >> 16) / uint32_t(L.frame_w) : 0u;
+}
+RT_HD uint32_t xy_real(const uint32_t xy, const Layering L, const uint32_t layer) { return xy - layer_offset_xy(L, layer); }
+// width of the virtual frame = row pitch of the per-iteration buffers
+RT_HD int virtual_width(const Layering L) { return L.frame_w * L.cols; }
 
 struct Shard {
     int tile, count, index;

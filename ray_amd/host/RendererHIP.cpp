@@ -91,7 +91,7 @@ class Renderer final : public RendererBase {
     mutable int pending_count_ = 0, pending_first_ = 0;
     mutable rayhip_camera pending_cam_ = {};
     mutable int pending_rect_[4] = {};
-    int max_batch_ = 64; // further limited by rayhip_max_batch() (frame height)
+    int max_batch_ = 64; // further limited by rayhip_max_batch() (frame size)
 
     void Flush() const {
         if (pending_count_ > 0) {

@@ -323,7 +323,7 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
             if (!pixel_owned(c->shard, w, x, y)) {
                 continue;
             }
-            accumulate_pixel(ap, x, y, c->temp.data(), c->temp.data(), c->full.data(), c->half.data(), c->raw.data(), c->final_.data(),
+            accumulate_pixel(ap, x, y, c->temp.data() + (size_t(y) * w + x), c->temp.data() + (size_t(y) * w + x), c->full.data(), c->half.data(), c->raw.data(), c->final_.data(),
                              c->required_samples.data());
         }
     }
@@ -365,6 +365,7 @@ HS_API int hostsim_render_batch(hostsim_ctx *c, const rayhip_camera *cam, const 
 }
 
 HS_API int hostsim_max_batch(hostsim_ctx *) { return 64; }
+HS_API int hostsim_reserve_batch(hostsim_ctx *, int) { return 0; }
 HS_API int hostsim_set_shard(hostsim_ctx *c, int tile, int shard_count, int shard_index) {
     c->shard = Shard{tile, shard_count, shard_index};
     return 0;

@@ -178,6 +178,27 @@ def test_tile_sharding_is_bit_identical(gpu_lib):
     assert np.array_equal(acc, full)
 
 
+@pytest.mark.parametrize("w,h,tile,n", [(100, 72, 32, 3), (100, 72, 64, 2), (65, 65, 64, 2), (96, 80, 12, 2), (160, 96, 8, 5)])
+def test_sharded_batches_walk_owned_tiles_only(gpu_lib, w, h, tile, n):
+    """a rank of a tile-sharded render generates rays (and sizes its wavefront state) for its own shard tiles only,
+    frames that are not whole tiles and tile sizes that are not whole 8x8 ray-generation tiles included; batched, with a
+    rect, the shards must still add up to the unsharded frame bit for bit"""
+    name = "cornell_basic"
+    one = util.make_context(gpu_lib, name, w, h)
+    for it in range(1, 6):
+        one.render(it)
+    one.render(6, rect=(8, 16, w - 20, h - 24))
+    full = one.readback(hip.BUF_RAW)
+    acc = np.zeros_like(full)
+    for r in range(n):
+        ctx = util.make_context(gpu_lib, name, w, h)
+        ctx.set_shard(tile, n, r)
+        ctx.render_batch(1, 5)
+        ctx.render_batch(6, 1, rect=(8, 16, w - 20, h - 24))
+        acc += ctx.readback(hip.BUF_RAW)
+    assert np.array_equal(acc, full)
+
+
 def test_rect_render(gpu_lib):
     """RegionContext rect: rendering two half-frame rects == rendering the full frame"""
     name = "cornell_basic"
@@ -269,15 +290,16 @@ def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
 
 
 def test_maximal_batch_and_row_limit_split(gpu_lib):
-    """a full 64-layer pass, and a frame tall enough that the 16-bit row limit cuts the pass (rayhip_max_batch): both must
-    equal the iterations rendered one by one"""
+    """a pass of more layers than one accumulate launch folds (64), a frame tall enough that the layers are stacked in
+    several columns of the virtual frame, and one so large that the 16-bit coordinate limit cuts the pass
+    (rayhip_max_batch): all must equal the iterations rendered one by one"""
     name = "cornell_basic"
-    for (w, h, n) in ((64, 48, 70), (16, 2000, 40)):
+    for (w, h, n) in ((64, 48, 70), (16, 2000, 40), (24, 30000, 5)):
         one = util.make_context(gpu_lib, name, w, h)
         for it in range(1, n + 1):
             one.render(it)
         bat = util.make_context(gpu_lib, name, w, h)
-        assert bat.max_batch() == min(64, 65535 // h)
+        assert bat.max_batch() == min(512, (65535 // w) * (65535 // h))
         bat.render_batch(1, n)
         assert np.array_equal(one.readback(hip.BUF_RAW), bat.readback(hip.BUF_RAW)), (w, h)
         assert np.array_equal(one.readback(hip.BUF_FINAL), bat.readback(hip.BUF_FINAL)), (w, h)

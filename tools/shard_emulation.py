@@ -1,0 +1,50 @@
+"""One rank of an N-GPU tile-sharded render, timed on ONE GPU: what each GPU of the node would do (the ranks do not
+communicate until the final frame reduce), hence the scaling efficiency the tile sharding can reach.
+
+    python tools/shard_emulation.py [workload] [steps]
+
+Prints, per world size N: iterations per pass, time of rank 0's share, projected whole-job Msamples/s (N x rank rate)
+and the efficiency against the N = 1 run of the same process.
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401  (first: librayhip shares torch's HIP runtime)
+
+import bench
+from ray_amd import api, hip, multigpu
+
+
+def main():
+    workload = sys.argv[1] if len(sys.argv) > 1 else "bistro"
+    K = int(sys.argv[2]) if len(sys.argv) > 2 else 480
+    wl = bench.WORKLOADS[workload]
+    W, H = wl["w"], wl["h"]
+    blob, _ = bench.get_scene_blob(workload, wl, 0, 1, lambda: None)
+    base = None
+    for world in (1, 2, 4, 8):
+        for limit in ((60, None) if world > 1 else (None,)):  # 60 = the old one-column limit at 1080p
+            ctx = hip.Context(0)
+            ctx.upload_static(api.pmj_table())
+            ctx.resize(W, H)
+            ctx.upload_scene_blob(blob)
+            ctx.set_shard(bench.TILE, world, 0)
+            batch = multigpu.batch_size(W * H // world, min(ctx.max_batch(), limit or 1 << 30), K)
+            ctx.reserve_batch(batch)
+            ctx.render_batch(1, batch)  # warm-up pass of the timed shape
+            ctx.sync()
+            t0 = time.perf_counter()
+            multigpu.render_sharded(ctx, range(batch + 1, batch + 1 + K), 0, world, batch=batch)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            rate = W * H * K / world / dt / 1e6 * world
+            base = base or rate
+            print(f"N={world} iterations/pass {batch:4d}  rank time {dt * 1e3:8.1f} ms  projected {rate:7.1f} Msamples/s  "
+                  f"efficiency {rate / (base * world):5.3f}", flush=True)
+            ctx.close()
+
+
+if __name__ == "__main__":
+    main()
