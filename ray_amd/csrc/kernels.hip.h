@@ -177,6 +177,18 @@ struct RayQueue {
     uint32_t chunks_per_stripe; // stripe capacity / 64
 
     __device__ __forceinline__ uint32_t total_chunks() const { return stripes * chunks_per_stripe; }
+    // Chunk indices that can hold rays: chunks are numbered stripe-minor, so nothing lives beyond the fullest stripe's
+    // last chunk.  A consumer that walks [0, live_chunks()) instead of [0, total_chunks()) does not poll the empty tail of
+    // the queue (late bounces fill a few per cent of it; with a 16x oversubscribed grid the polling was 16 % of the shade
+    // kernel's wave time).  Wavefront-collective: call with all 64 lanes active.
+    __device__ __forceinline__ uint32_t live_chunks() const {
+        const uint32_t lane = __lane_id();
+        uint32_t fill = lane < stripes ? counts[lane * QUEUE_COUNTER_STRIDE] : 0u;
+        for (int m = 32; m >= 1; m >>= 1) {
+            fill = max(fill, uint32_t(__shfl_xor(int(fill), m)));
+        }
+        return uint32_t(__builtin_amdgcn_readfirstlane(int(min(total_chunks(), stripes * ((fill + WAVE - 1) / WAVE)))));
+    }
     // chunk c (wave-uniform) -> its stripe, first slot and number of live lanes; false if the chunk is empty.
     // Chunks are numbered stripe-minor so that consecutive wavefronts work on different stripes.
     __device__ __forceinline__ bool chunk(const uint32_t c, uint32_t &stripe, uint32_t &slot0, uint32_t &n_live) const {
@@ -323,7 +335,8 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_closest(cons
         }
     }
 #endif
-    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+    const uint32_t n_live_chunks = queue.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
@@ -449,12 +462,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
     float t_val = 0.0f;
     // wavefront state (uniform): the chunk being handed out, the next chunk index of this wavefront
     uint32_t pool_slot = 0, pool_left = 0, next_chunk = blockIdx.x;
-    // chunks are numbered stripe-minor: nothing lives beyond the fullest stripe's last chunk
-    uint32_t fill = lane < queue.stripes ? queue.counts[lane * QUEUE_COUNTER_STRIDE] : 0u;
-    for (int m = 32; m >= 1; m >>= 1) {
-        fill = max(fill, uint32_t(__shfl_xor(int(fill), m)));
-    }
-    const uint32_t total_chunks = uint32_t(__builtin_amdgcn_readfirstlane(int(min(queue.total_chunks(), queue.stripes * ((fill + WAVE - 1) / WAVE)))));
+    const uint32_t total_chunks = queue.live_chunks();
 
     auto begin_round = [&]() { // IntersectScene loop head + walk prologue at TLAS level
         t_val = h.t;
@@ -668,7 +676,8 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const
                                                       unsigned long long *__restrict__ counters, const Layering layers) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t lane = threadIdx.x;
-    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+    const uint32_t n_live_chunks = queue.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
@@ -713,7 +722,8 @@ __global__ void __launch_bounds__(WAVE, RT_TRACE_MIN_WAVES) k_trace_shadow(const
 __global__ void __launch_bounds__(WAVE) k_intersect_area_lights(const SceneView sc, const RaySoA rays, const HitSoA hits,
                                                                const RayQueue queue) {
     const uint32_t lane = threadIdx.x;
-    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+    const uint32_t n_live_chunks = queue.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
@@ -736,7 +746,8 @@ __global__ void __launch_bounds__(WAVE) k_intersect_area_lights(const SceneView 
 // any-hit walk and adds 0 to its pixel, bit for bit what the reference adds.
 __global__ void __launch_bounds__(WAVE) k_shadow_blockers(const SceneView sc, const ShadowSoA shadow, const RayQueue queue) {
     const uint32_t lane = threadIdx.x;
-    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+    const uint32_t n_live_chunks = queue.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
@@ -767,7 +778,8 @@ __global__ void __launch_bounds__(WAVE, RT_SHADE_MIN_WAVES) k_shade(const SceneV
         s_prof_last = __builtin_readcyclecounter();
     }
 #endif
-    for (uint32_t c = blockIdx.x; c < in.total_chunks(); c += gridDim.x) {
+    const uint32_t n_live_chunks = in.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
         uint32_t stripe, slot0, n_live;
         if (!in.chunk(c, stripe, slot0, n_live)) {
             continue;
@@ -845,7 +857,8 @@ __global__ void __launch_bounds__(WAVE) k_shade_emissive(const SceneView sc, con
                                                         const DeferredSoA deferred, const RayQueue queue, const PixelBuffers px,
                                                         const int img_w) {
     const uint32_t lane = threadIdx.x;
-    for (uint32_t c = blockIdx.x; c < queue.total_chunks(); c += gridDim.x) {
+    const uint32_t n_live_chunks = queue.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
