@@ -341,6 +341,13 @@ RAYHIP_API int rayhip_max_batch(rayhip_ctx *ctx);
  * first such rayhip_render_batch does it, synchronising the stream). */
 RAYHIP_API int rayhip_reserve_batch(rayhip_ctx *ctx, int count);
 
+/* Look-up table of the non-Standard view transforms (camera_desc_t::view_transform: AgX, Filmic_*): dims^3 entries,
+ * RGB10_A2, x fastest -- the reference's precomputed tables (internal/TonemapRef.cpp:15-26, uploaded by its GPU
+ * back-ends as a 3-D texture, RendererVK.cpp:404-415); arithmetic of the look-up: TonemapRef.cpp:29-80.  The table is
+ * copied.  A camera with view_transform != Standard renders only after the table of THAT transform has been set (the
+ * caller owns the transform -> table mapping); scene blobs carry the table of their camera. */
+RAYHIP_API int rayhip_set_tonemap_lut(rayhip_ctx *ctx, int view_transform, const uint32_t *lut, int dims);
+
 /* Multi-GPU tile sharding (new): this context renders only the pixels of the tile x tile
  * squares (row-major walk over the frame) whose ordinal % shard_count == shard_index; all other pixels of its
  * buffers stay zero, so that summing the RAW buffers of all ranks (one RCCL reduce) yields the full frame,

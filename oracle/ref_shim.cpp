@@ -22,6 +22,12 @@ struct ray_scene {
     std::unique_ptr<Ray::SceneBase> s;
 };
 
+namespace Ray {
+// the reference's precomputed view-transform tables (internal/TonemapRef.cpp:4-26), indexed by eViewTransform
+extern const int LUT_DIMS;
+extern const uint32_t *transform_luts[];
+} // namespace Ray
+
 namespace {
 using namespace Ray;
 
@@ -124,7 +130,9 @@ int refk_export_scene(ray_scene *s, void **out_blob, size_t *out_size) {
         rayhip_camera rc;
         memcpy(&rc, &cam, sizeof(rc));
         const std::vector<float> ft = make_filter_table(cam.filter, cam.filter_width);
-        const std::vector<uint8_t> blob = rayhip_blob::serialize(flat.desc, rc, ft.data(), int(ft.size()));
+        const bool lut = rc.view_transform != 0; // the blob carries the table of its camera's view transform
+        const std::vector<uint8_t> blob = rayhip_blob::serialize(flat.desc, rc, ft.data(), int(ft.size()),
+                                                                 lut ? transform_luts[rc.view_transform] : nullptr, lut ? LUT_DIMS : 0);
         void *p = nullptr;
         if (posix_memalign(&p, 64, blob.size() ? blob.size() : 64) != 0) {
             return 1;

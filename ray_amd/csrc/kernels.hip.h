@@ -948,13 +948,7 @@ __global__ void __launch_bounds__(256) k_retonemap(const AccumParams p, const Pi
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 ff = px.full[i];
         px.raw[i] = ff;
-        f4 c = {ff.x, ff.y, ff.z, ff.w};
-        c.x = tonemap_standard(c.x), c.y = tonemap_standard(c.y), c.z = tonemap_standard(c.z);
-        if (p.inv_gamma != 1.0f) {
-            c.x = powf(c.x, p.inv_gamma), c.y = powf(c.y, p.inv_gamma), c.z = powf(c.z, p.inv_gamma);
-        }
-        c.x = sse_max(0.0f, sse_min(c.x, 1.0f)), c.y = sse_max(0.0f, sse_min(c.y, 1.0f));
-        c.z = sse_max(0.0f, sse_min(c.z, 1.0f)), c.w = sse_max(0.0f, sse_min(c.w, 1.0f));
+        const f4 c = tonemap(p, f4{ff.x, ff.y, ff.z, ff.w});
         px.final_[i] = mkfloat4(c.x, c.y, c.z, c.w);
     }
 }

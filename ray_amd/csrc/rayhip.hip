@@ -92,6 +92,8 @@ struct rayhip_ctx {
     int w = 0, h = 0;
     DevBuf px_temp, px_full, px_half, px_raw, px_final, px_base, px_dn, px_req, px_aux_base, px_aux_dn;
     size_t slots_cap = 0; // wavefront-state slots allocated
+    DevBuf tonemap_lut;   // table of view transform `lut_transform` (rayhip_set_tonemap_lut)
+    int lut_transform = 0, lut_dims = 0;
     PixelBuffers px = {};
 
     // wavefront state, sized w*h
@@ -627,13 +629,35 @@ int rayhip_set_filter_table(rayhip_ctx *c, const float *table, int count) {
     return 0;
 }
 
+int rayhip_set_tonemap_lut(rayhip_ctx *c, int view_transform, const uint32_t *lut, int dims) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (view_transform <= 0 || !lut || dims < 2 || dims > 256) {
+        return fail("bad tonemap table (view transform %d, dims %d)", view_transform, dims);
+    }
+    const size_t bytes = size_t(dims) * size_t(dims) * size_t(dims) * sizeof(uint32_t);
+    HIP_TRY(hipStreamSynchronize(c->stream)); // a pass in flight may still read the old table
+    if (c->tonemap_lut.alloc(bytes)) {
+        return 1;
+    }
+    HIP_TRY(hipMemcpy(c->tonemap_lut.p, lut, bytes, hipMemcpyHostToDevice));
+    c->lut_transform = view_transform, c->lut_dims = dims;
+    return 0;
+}
+
 int rayhip_scene_upload_blob(rayhip_ctx *c, const void *blob, size_t size, rayhip_camera *out_cam) {
     rayhip_scene_desc d;
     const float *ft = nullptr;
     int ftn = 0;
     std::string err;
-    if (!rayhip_blob::deserialize(blob, size, d, *out_cam, &ft, &ftn, err)) {
+    rayhip_blob::Extras extras;
+    if (!rayhip_blob::deserialize(blob, size, d, *out_cam, &ft, &ftn, err, &extras)) {
         return fail("%s", err.c_str());
+    }
+    if (extras.tonemap_lut && out_cam->view_transform != 0 &&
+        rayhip_set_tonemap_lut(c, out_cam->view_transform, extras.tonemap_lut, extras.tonemap_lut_dims)) {
+        return 1;
     }
     if (rayhip_scene_upload(c, &d)) {
         return 1;
@@ -678,8 +702,8 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     if (cam->type != 0 /* eCamType::Persp */) {
         return fail("only perspective cameras are supported");
     }
-    if (cam->view_transform != 0 /* eViewTransform::Standard */) {
-        return fail("only the Standard view transform is supported");
+    if (cam->view_transform != 0 /* eViewTransform::Standard */ && cam->view_transform != c->lut_transform) {
+        return fail("view transform %d needs its look-up table: rayhip_set_tonemap_lut", int(cam->view_transform));
     }
     if (rect[0] < 0 || rect[1] < 0 || rect[2] <= 0 || rect[3] <= 0 || rect[0] + rect[2] > c->w || rect[1] + rect[3] > c->h) {
         return fail("rect outside the frame");
@@ -807,7 +831,8 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     if (tm.mark(-1, -1)) {
         return 1;
     }
-    const AccumParams ap = make_accum_params(*cam, c->w, rect, iteration, c->shard);
+    AccumParams ap = make_accum_params(*cam, c->w, rect, iteration, c->shard);
+    ap.lut = c->tonemap_lut.as<uint32_t>(), ap.lut_dims = c->lut_dims;
     for (int base = 0; base < count_iterations; base += MAX_BATCH) { // the layers are folded in iteration order
         const int n = std::min(MAX_BATCH, count_iterations - base);
         AccumLayers per_layer = {};
@@ -954,7 +979,11 @@ int rayhip_set_raw_device(rayhip_ctx *c, const void *src_device_rgba, int pitch_
     HIP_TRY(hipMemcpy2DAsync(c->px.full, size_t(c->w) * 16, src_device_rgba, size_t(pitch_px) * 16, size_t(c->w) * 16,
                              size_t(c->h), hipMemcpyDeviceToDevice, c->stream));
     const int rect[4] = {0, 0, c->w, c->h};
-    const AccumParams ap = make_accum_params(*cam, c->w, rect, 1);
+    if (cam->view_transform != 0 && cam->view_transform != c->lut_transform) {
+        return fail("view transform %d needs its look-up table: rayhip_set_tonemap_lut", int(cam->view_transform));
+    }
+    AccumParams ap = make_accum_params(*cam, c->w, rect, 1);
+    ap.lut = c->tonemap_lut.as<uint32_t>(), ap.lut_dims = c->lut_dims;
     k_retonemap<<<grid_for(c, size_t(c->w) * c->h, 256), 256, 0, c->stream>>>(ap, c->px, c->h);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));

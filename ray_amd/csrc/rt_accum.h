@@ -15,7 +15,9 @@ struct AccumParams {
     float mix_factor;      // 1 / iteration, :470
     float half_mix_factor; // 1 / ((iteration + 1) / 2), :608
     int is_class_a;        // popcount((iteration-1) & 0xaaaaaaaa) & 1, :607
-    int view_transform;    // only Standard (0) is supported
+    int view_transform;    // eViewTransform: 0 = Standard (sRGB curve), others = look-up through `lut`
+    const uint32_t *lut;   // [lut_dims^3] RGB10_A2 (the reference's precomputed tables, handed over through the C ABI)
+    int lut_dims;
     float inv_gamma;
     float variance_threshold;
     Shard shard;
@@ -27,6 +29,47 @@ RT_HD float tonemap_standard(float c) {
         return 12.92f * c;
     }
     return 1.055f * powf(c, (1.0f / 2.4f)) - 0.055f;
+}
+
+// TonemapFilmic + FetchLUT, TonemapRef.cpp:29-80: trilinear look-up in a dims^3 RGB10_A2 table addressed by c / (c + 1)
+RT_HD f4 fetch_lut(const uint32_t *lut, const int dims, const int ix, const int iy, const int iz) {
+    const uint32_t v = lut[(iz * dims + iy) * dims + ix];
+    return f4{float(int(v & 0x3ffu)) * (1.0f / 1023.0f), float(int((v >> 10) & 0x3ffu)) * (1.0f / 1023.0f),
+              float(int((v >> 20) & 0x3ffu)) * (1.0f / 1023.0f), float(int((v >> 30) & 0x3u)) * (1.0f / 3.0f)};
+}
+RT_HD f4 tonemap_filmic(const uint32_t *lut, const int dims, const f4 color) {
+    const f4 encoded = color / (color + f4{1.0f, 1.0f, 1.0f, 1.0f});
+    const f4 uv = encoded * float(dims - 1);
+    const int ix = int(uv.x), iy = int(uv.y), iz = int(uv.z); // (ivec4(fvec4): truncation)
+    const float fx = fractf(uv.x), fy = fractf(uv.y), fz = fractf(uv.z);
+    const int jx = (ix + 1 < dims - 1) ? ix + 1 : dims - 1, jy = (iy + 1 < dims - 1) ? iy + 1 : dims - 1,
+              jz = (iz + 1 < dims - 1) ? iz + 1 : dims - 1;
+    const f4 c000 = fetch_lut(lut, dims, ix, iy, iz), c001 = fetch_lut(lut, dims, jx, iy, iz),
+             c010 = fetch_lut(lut, dims, ix, jy, iz), c011 = fetch_lut(lut, dims, jx, jy, iz),
+             c100 = fetch_lut(lut, dims, ix, iy, jz), c101 = fetch_lut(lut, dims, jx, iy, jz),
+             c110 = fetch_lut(lut, dims, ix, jy, jz), c111 = fetch_lut(lut, dims, jx, jy, jz);
+    const f4 c00x = (1.0f - fx) * c000 + fx * c001, c01x = (1.0f - fx) * c010 + fx * c011,
+             c10x = (1.0f - fx) * c100 + fx * c101, c11x = (1.0f - fx) * c110 + fx * c111;
+    const f4 c0xx = (1.0f - fy) * c00x + fy * c01x, c1xx = (1.0f - fy) * c10x + fy * c11x;
+    f4 cxxx = (1.0f - fz) * c0xx + fz * c1xx;
+    cxxx.w = color.w;
+    return cxxx;
+}
+// Tonemap(), TonemapRef.h:33-45
+RT_HD f4 tonemap(const AccumParams &p, f4 c) {
+    if (p.view_transform == 0) {
+        c.x = tonemap_standard(c.x), c.y = tonemap_standard(c.y), c.z = tonemap_standard(c.z);
+    } else {
+        c = tonemap_filmic(p.lut, p.lut_dims, c);
+    }
+    if (p.inv_gamma != 1.0f) {
+        c.x = powf(c.x, p.inv_gamma), c.y = powf(c.y, p.inv_gamma), c.z = powf(c.z, p.inv_gamma);
+        c.w = powf(c.w, 1.0f);
+    }
+    // saturate = max(0, min(c, 1)) with SSE operand order
+    c.x = sse_max(0.0f, sse_min(c.x, 1.0f)), c.y = sse_max(0.0f, sse_min(c.y, 1.0f));
+    c.z = sse_max(0.0f, sse_min(c.z, 1.0f)), c.w = sse_max(0.0f, sse_min(c.w, 1.0f));
+    return c;
 }
 
 // TonemapRef.h:7-9
@@ -59,22 +102,7 @@ RT_HD void accumulate_pixel(const AccumParams &p, const int x, const int y, cons
 
     raw_buf[idx] = ff;
 
-    // Tonemap(), TonemapRef.h:33-45 (Standard view transform)
-    f4 c = full_val;
-    c.x = tonemap_standard(c.x);
-    c.y = tonemap_standard(c.y);
-    c.z = tonemap_standard(c.z);
-    if (p.inv_gamma != 1.0f) {
-        c.x = powf(c.x, p.inv_gamma);
-        c.y = powf(c.y, p.inv_gamma);
-        c.z = powf(c.z, p.inv_gamma);
-        c.w = powf(c.w, 1.0f);
-    }
-    // saturate = max(0, min(c, 1)) with SSE operand order
-    c.x = sse_max(0.0f, sse_min(c.x, 1.0f));
-    c.y = sse_max(0.0f, sse_min(c.y, 1.0f));
-    c.z = sse_max(0.0f, sse_min(c.z, 1.0f));
-    c.w = sse_max(0.0f, sse_min(c.w, 1.0f));
+    const f4 c = tonemap(p, full_val);
     final_buf[idx] = mkfloat4(c.x, c.y, c.z, c.w);
 
     // variance estimate from the two half-sample images, RendererCPU.h:641-645

@@ -106,6 +106,7 @@ inline AccumParams make_accum_params(const rayhip_camera &cam, int w, const int 
     p.half_mix_factor = 1.0f / float((iteration + 1) / 2);           // :608
     p.is_class_a = popcount32(uint32_t(iteration - 1) & 0xaaaaaaaa) & 1; // :607
     p.view_transform = cam.view_transform;
+    p.lut = nullptr, p.lut_dims = 0; // the caller points these at the table of cam.view_transform
     p.inv_gamma = (1.0f / cam.gamma);
     p.variance_threshold = iteration > cam.pass_settings.min_samples
                                ? 0.5f * cam.pass_settings.variance_threshold * cam.pass_settings.variance_threshold

@@ -55,8 +55,9 @@ inline void add_section(std::vector<Section> &secs, std::vector<uint8_t> &payloa
     secs.push_back(s);
 }
 
+// `tonemap_lut`: the dims^3 table of cam.view_transform (nullptr for the Standard transform)
 inline std::vector<uint8_t> serialize(const rayhip_scene_desc &d, const rayhip_camera &cam, const float *filter_table,
-                                      int filter_table_count) {
+                                      int filter_table_count, const uint32_t *tonemap_lut = nullptr, int tonemap_lut_dims = 0) {
     std::vector<Section> secs;
     std::vector<uint8_t> payload;
 #define ARR(field) add_section(secs, payload, #field, d.field, size_t(d.field##_count) * sizeof(*d.field));
@@ -84,6 +85,10 @@ inline std::vector<uint8_t> serialize(const rayhip_scene_desc &d, const rayhip_c
     add_section(secs, payload, "scalars", &sc, sizeof(sc));
     add_section(secs, payload, "camera", &cam, sizeof(cam));
     add_section(secs, payload, "filter_table", filter_table, size_t(filter_table_count) * sizeof(float));
+    if (tonemap_lut && tonemap_lut_dims > 0) {
+        add_section(secs, payload, "tonemap_lut", tonemap_lut,
+                    size_t(tonemap_lut_dims) * size_t(tonemap_lut_dims) * size_t(tonemap_lut_dims) * sizeof(uint32_t));
+    }
 
     Header h = {};
     memcpy(h.magic, MAGIC, 8);
@@ -103,8 +108,12 @@ inline std::vector<uint8_t> serialize(const rayhip_scene_desc &d, const rayhip_c
 }
 
 // Pointers in `d` alias `blob` (which must stay alive and be at least 16-byte aligned).
+struct Extras {
+    const uint32_t *tonemap_lut = nullptr; // table of cam.view_transform, if the blob carries one
+    int tonemap_lut_dims = 0;
+};
 inline bool deserialize(const void *blob, size_t size, rayhip_scene_desc &d, rayhip_camera &cam, const float **filter_table,
-                        int *filter_table_count, std::string &err) {
+                        int *filter_table_count, std::string &err, Extras *extras = nullptr) {
     const uint8_t *b = static_cast<const uint8_t *>(blob);
     if (size < sizeof(Header)) {
         err = "scene blob too small";
@@ -152,6 +161,20 @@ inline bool deserialize(const void *blob, size_t size, rayhip_scene_desc &d, ray
         ARR(texels, uint32_t)
         ARR(env_qtree, float)
 #undef ARR
+        if (name == "tonemap_lut") {
+            int dims = 1;
+            while (size_t(dims) * size_t(dims) * size_t(dims) * sizeof(uint32_t) < s.size) {
+                ++dims;
+            }
+            if (size_t(dims) * size_t(dims) * size_t(dims) * sizeof(uint32_t) != s.size) {
+                err = "tonemap_lut section is not a cube";
+                return false;
+            }
+            if (extras) {
+                extras->tonemap_lut = reinterpret_cast<const uint32_t *>(p), extras->tonemap_lut_dims = dims;
+            }
+            continue;
+        }
         if (name == "scalars" && s.size == sizeof(Scalars)) {
             Scalars sc;
             memcpy(&sc, p, sizeof(sc));

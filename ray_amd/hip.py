@@ -73,7 +73,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 # every symbol include/rayhip.h declares (tests check that the built library exports all of them)
 ENTRY_POINTS = (
     "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
-    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "readback", "readback_device", "set_raw_device",
+    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand",
 )
@@ -109,6 +109,7 @@ class Library:
         f("render_batch").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_int, C.c_uint32, C.POINTER(Stats)]
         f("max_batch").argtypes = [vp]
         f("reserve_batch").argtypes = [vp, C.c_int]
+        f("set_tonemap_lut").argtypes = [vp, C.c_int, vp, C.c_int]
         f("readback").argtypes = [vp, C.c_int, vp, C.c_int]
         f("sync").argtypes = [vp]
         f("set_shard").argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -199,6 +200,13 @@ class Context:
     def max_batch(self) -> int:
         """largest number of iterations one wavefront pass of the current frame can carry"""
         return int(self.L.fn("max_batch")(self._ctx))
+
+    def set_tonemap_lut(self, view_transform: int, lut: np.ndarray):
+        """dims^3 RGB10_A2 table of a non-Standard view transform (uint32, x fastest)"""
+        lut = np.ascontiguousarray(lut, dtype=np.uint32).reshape(-1)
+        dims = round(lut.size ** (1.0 / 3.0))
+        assert dims ** 3 == lut.size, "the table must be a cube"
+        self.L.check(self.L.fn("set_tonemap_lut")(self._ctx, view_transform, lut.ctypes.data, dims))
 
     def reserve_batch(self, count: int):
         """allocate the buffers passes of `count` iterations need (under the current shard) ahead of time"""

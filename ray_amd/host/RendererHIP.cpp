@@ -31,6 +31,10 @@
 #include "scene_export.h"
 
 namespace Ray {
+// the reference's precomputed view-transform tables (internal/TonemapRef.cpp:4-26), indexed by eViewTransform
+extern const int LUT_DIMS;
+extern const uint32_t *transform_luts[];
+
 namespace Hip {
 
 class Scene final : public Cpu::Scene {
@@ -91,6 +95,7 @@ class Renderer final : public RendererBase {
     mutable int pending_count_ = 0, pending_first_ = 0;
     mutable rayhip_camera pending_cam_ = {};
     mutable int pending_rect_[4] = {};
+    int lut_transform_ = 0; // view transform whose look-up table is on the device
     int max_batch_ = 64; // further limited by rayhip_max_batch() (frame size)
 
     void Flush() const {
@@ -256,6 +261,19 @@ class Renderer final : public RendererBase {
             filter_table_width_ = cam.filter_width;
         }
 
+        if (cam.view_transform != eViewTransform::Standard && int(cam.view_transform) != lut_transform_) {
+            // what RendererVK::RenderScene does with its 3-D texture (RendererVK.cpp:404-415)
+            Flush();
+            try {
+                check(rayhip_set_tonemap_lut(ctx_, int(cam.view_transform), transform_luts[int(cam.view_transform)], LUT_DIMS),
+                      "rayhip_set_tonemap_lut");
+            } catch (std::exception &e) {
+                log_->Error("RendererHIP: %s", e.what());
+                return;
+            }
+            lut_transform_ = int(cam.view_transform);
+        }
+
         ++region.iteration; // RendererCPU.h:384
 
         rayhip_camera rc;
@@ -344,7 +362,9 @@ std::vector<uint8_t> ExportSceneBlob(const SceneBase &scene) {
     }
     const std::vector<float> table = Ray::CDFInverted(FILTER_TABLE_SIZE, 0.0f, filter_width * 0.5f,
                                                       std::bind(filter_func, std::placeholders::_1, filter_width), true);
-    return rayhip_blob::serialize(flat.desc, rc, table.data(), int(table.size()));
+    const bool lut = rc.view_transform != 0;
+    return rayhip_blob::serialize(flat.desc, rc, table.data(), int(table.size()), lut ? transform_luts[rc.view_transform] : nullptr,
+                                  lut ? LUT_DIMS : 0);
 }
 
 } // namespace Hip

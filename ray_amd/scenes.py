@@ -126,6 +126,14 @@ def cornell_basic(scene, **cam_overrides):
     scene.Finalize()
 
 
+def cornell_filmic(scene, **cam_overrides):
+    """cornell_basic through a look-up-table view transform (eViewTransform.Filmic_HighContrast = 8, TonemapRef.cpp:15-26)
+    and a display gamma: exercises TonemapFilmic + the pow() branch of Tonemap()"""
+    kw = dict(view_transform=8, gamma=2.2, exposure=-1.0)
+    kw.update(cam_overrides)
+    cornell_basic(scene, **kw)
+
+
 def cornell_principled(scene, **cam_overrides):
     """reference samples/03_principled/main.cpp:30-205"""
     scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
@@ -412,4 +420,5 @@ SCENES = {
     "cornell_principled": cornell_principled,
     "cornell_lights": cornell_lights,
     "cornell_env": cornell_env,
+    "cornell_filmic": cornell_filmic,
 }

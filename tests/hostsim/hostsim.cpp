@@ -64,6 +64,8 @@ struct hostsim_ctx {
     Shard shard = {64, 1, 0};
     bool layout_applied = false;
     bool wide = false; // walk the 4-wide BLAS (HOSTSIM_BVH4=1)
+    std::vector<uint32_t> tonemap_lut;
+    int lut_transform = 0, lut_dims = 0;
 };
 
 // test hook: did the last scene upload go through the HBM layout pass?
@@ -194,14 +196,24 @@ HS_API int hostsim_set_filter_table(hostsim_ctx *c, const float *t, int count) {
     return 0;
 }
 
+HS_API int hostsim_set_tonemap_lut(hostsim_ctx *c, int view_transform, const uint32_t *lut, int dims) {
+    c->tonemap_lut.assign(lut, lut + size_t(dims) * dims * dims);
+    c->lut_transform = view_transform, c->lut_dims = dims;
+    return 0;
+}
+
 HS_API int hostsim_scene_upload_blob(hostsim_ctx *c, const void *blob, size_t size, rayhip_camera *out_cam) {
     rayhip_scene_desc d;
     const float *ft = nullptr;
     int ftn = 0;
     std::string err;
-    if (!rayhip_blob::deserialize(blob, size, d, *out_cam, &ft, &ftn, err)) {
+    rayhip_blob::Extras extras;
+    if (!rayhip_blob::deserialize(blob, size, d, *out_cam, &ft, &ftn, err, &extras)) {
         g_err = err;
         return 1;
+    }
+    if (extras.tonemap_lut && out_cam->view_transform != 0) {
+        hostsim_set_tonemap_lut(c, out_cam->view_transform, extras.tonemap_lut, extras.tonemap_lut_dims);
     }
     hostsim_scene_upload(c, &d);
     if (ft) {
@@ -317,7 +329,12 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
         rays.swap(next_rays);
     }
     // K10+K11
-    const AccumParams ap = make_accum_params(*cam, w, rect, iteration, c->shard);
+    if (cam->view_transform != 0 && cam->view_transform != c->lut_transform) {
+        g_err = "view transform needs its look-up table";
+        return 1;
+    }
+    AccumParams ap = make_accum_params(*cam, w, rect, iteration, c->shard);
+    ap.lut = c->tonemap_lut.data(), ap.lut_dims = c->lut_dims;
     for (int y = rect[1]; y < rect[1] + rect[3]; ++y) {
         for (int x = rect[0]; x < rect[0] + rect[2]; ++x) {
             if (!pixel_owned(c->shard, w, x, y)) {

@@ -16,7 +16,7 @@ from ray_amd import hip
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["cornell_basic", "cornell_principled", "cornell_lights", "cornell_env"]
+SCENES = ["cornell_basic", "cornell_principled", "cornell_lights", "cornell_env", "cornell_filmic"]
 
 
 @pytest.fixture(scope="module")
@@ -305,7 +305,8 @@ def test_maximal_batch_and_row_limit_split(gpu_lib):
         assert np.array_equal(one.readback(hip.BUF_FINAL), bat.readback(hip.BUF_FINAL)), (w, h)
 
 
-def test_renderer_hip_through_the_ray_api(gpu_lib):
+@pytest.mark.parametrize("name", ["cornell_lights", "cornell_filmic"])
+def test_renderer_hip_through_the_ray_api(gpu_lib, name):
     """the drop-in itself: Ray::CreateRenderer(HIP) -> SceneHIP mutators -> RenderScene x N -> get_*_pixels_ref.  The live
     scene's arrays reach librayhip unserialised (alignment as the reference allocates them), and consecutive RenderScene
     calls are batched behind the API -- the pixels must equal the low-level path's, bit for bit."""
@@ -313,7 +314,7 @@ def test_renderer_hip_through_the_ray_api(gpu_lib):
     from ray_amd import api, scenes
     if not os.path.exists(api.HIP_HOST_LIB):
         pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
-    name = "cornell_lights"
+    # (cornell_filmic: RendererHIP hands the reference's view-transform table to rayhip_set_tonemap_lut)
     r = api.CreateRenderer(api.Settings(64, 64), "HIP")
     assert r.type() == "HIP"
     s = r.CreateScene()
@@ -333,4 +334,6 @@ def test_renderer_hip_through_the_ray_api(gpu_lib):
     assert np.array_equal(r.get_pixels_ref(), ctx.readback(hip.BUF_FINAL))
     g = util.golden_ref(name)
     m = util.frame_metrics(r.get_raw_pixels_ref(), g["raw_spp8"])
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP
+    m = util.frame_metrics(r.get_pixels_ref(), g["final_spp8"])  # the tone-mapped image (8-bit display range)
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP
