@@ -89,6 +89,42 @@ def test_live_reference_other_sizes(lib, name, w, h, spp):
     assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
 
 
+CAMERAS = {
+    # thin-lens depth of field with a 6-blade rotated anamorphic aperture, shifted sensor (GeneratePrimaryRays :1493-1530)
+    "dof_blades": dict(fstop=1.4, focus_distance=0.6, focal_length=0.05, lens_blades=6, lens_rotation=0.3, lens_ratio=1.5,
+                       shift=(0.1, -0.05)),
+    "dof_disk_flength": dict(fstop=2.0, focus_distance=0.7, ltype=1, focal_length=0.035, sensor_height=0.024),
+    # pixel filters (Core.cpp filter tables through CDFInverted) and a clipped view range
+    "gaussian_clip": dict(filter=1, filter_width=2.0, clip_start=0.3, clip_end=1.2),
+    "blackman_harris": dict(filter=2, filter_width=1.5),
+    # pass flags / depth limits of camera_desc_t
+    "lighting_only": dict(lighting_only=1, max_diff_depth=2, max_total_depth=3, min_total_depth=1),
+    "no_direct_no_bg": dict(skip_direct_lighting=1, no_background=1),
+    "no_indirect": dict(skip_indirect_lighting=1),
+    "clamped": dict(clamp_direct=2.0, clamp_indirect=1.0, regularize_alpha=0.1),
+    # adaptive sampling: pixels drop out of the iteration once their variance estimate is below the threshold
+    "adaptive": dict(min_samples=2, variance_threshold=0.05),
+}
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("cam", sorted(CAMERAS))
+def test_camera_features_against_live_reference(lib, cam):
+    """camera_desc_t fields the fixtures do not cover, against the reference run live: lens model, sensor shift, pixel
+    filters, clip range, lighting flags, clamps"""
+    from ray_amd import api, scenes
+
+    name = "cornell_principled" if cam in ("lighting_only", "clamped") else "cornell_basic"
+    w, h, spp = 80, 64, (12 if cam == "adaptive" else 4)
+    r, s = O.render_ref(scenes.SCENES[name], w, h, spp, **CAMERAS[cam])
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    img = util.render_frames(ctx, spp)
+    assert np.array_equal(img, r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), r.get_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_layout_pass_is_exercised(lib, name):
     """librayhip re-orders nodes and triangles at upload (ray_amd/csrc/bvh_layout.h); the host build runs the same pass,
