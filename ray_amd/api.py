@@ -196,9 +196,13 @@ class SceneBase:
         d.allow_spatial_splits, d.use_fast_bvh_build = int(allow_spatial_splits), int(use_fast_bvh_build)
         return int(self._lib.ray_scene_add_mesh(self._ptr, C.byref(d)))
 
-    def AddMeshInstance(self, mesh: int, xform=None) -> int:
+    def AddMeshInstance(self, mesh: int, xform=None, camera=True, diffuse=True, specular=True, refraction=True, shadow=True) -> int:
+        """mesh_instance_desc_t (SceneBase.h:135-143); xform: 4x4, column-major as the reference takes it"""
         m = (C.c_float * 16)(*(np.eye(4, dtype=np.float32).ravel() if xform is None else np.asarray(xform, np.float32).ravel()))
-        return int(self._lib.ray_scene_add_mesh_instance(self._ptr, mesh, C.byref(m)))
+        vis = (1 if camera else 0) | (2 if diffuse else 0) | (4 if specular else 0) | (8 if refraction else 0) | (16 if shadow else 0)
+        if vis == 31:
+            return int(self._lib.ray_scene_add_mesh_instance(self._ptr, mesh, C.byref(m)))
+        return int(self._lib.ray_scene_add_mesh_instance_vis(self._ptr, mesh, C.byref(m), vis))
 
     def AddLight(self, kind: str, **kw) -> int:
         """kind: 'directional' | 'sphere' | 'spot' | 'rect' | 'disk' | 'line' (the six AddLight overloads)."""

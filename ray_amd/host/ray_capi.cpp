@@ -374,6 +374,16 @@ ray_handle ray_scene_add_mesh_instance(ray_scene *s, ray_handle mesh, const floa
     return from_handle(s->s->AddMeshInstance(to_handle<Ray::MeshHandle>(mesh), xform));
 }
 
+ray_handle ray_scene_add_mesh_instance_vis(ray_scene *s, ray_handle mesh, const float xform[16], unsigned visibility) {
+    Ray::mesh_instance_desc_t mi;
+    mi.xform = xform;
+    mi.mesh = to_handle<Ray::MeshHandle>(mesh);
+    mi.camera_visibility = (visibility & 1u) != 0, mi.diffuse_visibility = (visibility & 2u) != 0;
+    mi.specular_visibility = (visibility & 4u) != 0, mi.refraction_visibility = (visibility & 8u) != 0;
+    mi.shadow_visibility = (visibility & 16u) != 0;
+    return from_handle(s->s->AddMeshInstance(mi));
+}
+
 ray_handle ray_scene_add_light(ray_scene *s, const ray_light_desc *d) {
 #define COMMON(l)                                                                                                      \
     memcpy(l.color, d->color, 12);                                                                                     \

@@ -188,6 +188,9 @@ ray_handle ray_scene_add_material_node(ray_scene *s, const ray_shading_node_desc
 ray_handle ray_scene_add_material_principled(ray_scene *s, const ray_principled_mat_desc *d);
 ray_handle ray_scene_add_mesh(ray_scene *s, const ray_mesh_desc *d);                  /* SceneBase::AddMesh */
 ray_handle ray_scene_add_mesh_instance(ray_scene *s, ray_handle mesh, const float xform[16]);
+/* mesh_instance_desc_t with its visibility flags (SceneBase.h:135-143); bits: 1 camera, 2 diffuse, 4 specular,
+ * 8 refraction, 16 shadow */
+ray_handle ray_scene_add_mesh_instance_vis(ray_scene *s, ray_handle mesh, const float xform[16], unsigned visibility);
 ray_handle ray_scene_add_light(ray_scene *s, const ray_light_desc *d);                /* the six AddLight overloads */
 ray_handle ray_scene_add_camera(ray_scene *s, const ray_camera_desc *d);              /* SceneBase::AddCamera */
 void ray_scene_set_current_cam(ray_scene *s, ray_handle cam);

@@ -255,6 +255,54 @@ def cornell_env(scene, **cam_overrides):
     scene.Finalize()
 
 
+def _xform(translate=(0.0, 0.0, 0.0), rot_y_deg=0.0, rot_z_deg=0.0, scale=(1.0, 1.0, 1.0)) -> np.ndarray:
+    """4x4 T * Ry * Rz * S in the layout the reference takes (column vectors, translation in elements 12..14)"""
+    cy, sy = np.cos(np.radians(rot_y_deg)), np.sin(np.radians(rot_y_deg))
+    cz, sz = np.cos(np.radians(rot_z_deg)), np.sin(np.radians(rot_z_deg))
+    ry = np.array([[cy, 0, sy, 0], [0, 1, 0, 0], [-sy, 0, cy, 0], [0, 0, 0, 1]], dtype=np.float64)
+    rz = np.array([[cz, -sz, 0, 0], [sz, cz, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    sc = np.diag([scale[0], scale[1], scale[2], 1.0])
+    m = ry @ rz @ sc
+    m[:3, 3] = translate
+    return m.T.astype(np.float32).copy()  # row-major memory of the transpose == column-major memory of m
+
+
+def cornell_instances(scene, **cam_overrides):
+    """Two-level hierarchy: the room is one mesh instance, the short block is ONE mesh instanced five times (shared BLAS)
+    with translations, rotations and a non-uniform scale, three of them with restricted visibility (hidden from camera
+    rays / from shadow rays / from diffuse bounces), one made of a transparent-mix material, and the tall block is a
+    second instanced mesh.  Covers Traverse_TLAS_* over several leaves, TransformPoint/Direction/Normal, the ray-type
+    visibility masks (mesh_instance_t::ray_visibility) and transparency rounds across instances."""
+    scene.SetEnvironment(env_col=(0.02, 0.03, 0.05))
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.0, 0.0)))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.0, 0.5, 0.0)))
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=100.0, importance_sample=True))
+    shiny = scene.AddMaterial(PrincipledMat(base_color=(0.8, 0.7, 0.3), metallic=1.0, roughness=0.2))
+    glass = scene.AddMaterial(ShadingNode(type=eShadingNode.Transparent, base_color=(0.7, 0.9, 0.7)))
+    blue = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.1, 0.2, 0.7)))
+    veil = scene.AddMaterial(ShadingNode(type=eShadingNode.Mix, strength=0.5, mix_materials=(blue, glass)))
+    q = _CORNELL_QUADS
+    attrs, idx = cornell_mesh_arrays(q)  # floor, ceiling, back, left, right, light
+    room = scene.AddMesh(attrs, idx, [(grey, None, 0, 18), (red, None, 18, 6), (green, None, 24, 6), (emit, 0xFFFFFFFF, 30, 6)])
+    attrs, idx = cornell_mesh_arrays(_block_quads("short"))
+    block = scene.AddMesh(attrs, idx, [(grey, None, 0, 30)])
+    block_shiny = scene.AddMesh(attrs, idx, [(shiny, None, 0, 30)])
+    block_veil = scene.AddMesh(attrs, idx, [(veil, None, 0, 30)])
+    attrs, idx = cornell_mesh_arrays(_block_quads("tall"))
+    tall = scene.AddMesh(attrs, idx, [(grey, None, 0, 30)])
+    scene.AddMeshInstance(room)
+    scene.AddMeshInstance(block)                                                          # where the sample has it
+    scene.AddMeshInstance(block, _xform(translate=(-0.30, 0.0, 0.10), rot_y_deg=35.0, scale=(0.6, 1.8, 0.6)))
+    scene.AddMeshInstance(block, _xform(translate=(0.12, 0.30, -0.10), rot_y_deg=-20.0, rot_z_deg=25.0, scale=(0.5, 0.5, 0.5)),
+                          camera=False)                                                   # seen only through its shadow / bounces
+    scene.AddMeshInstance(block_shiny, _xform(translate=(-0.12, 0.165, -0.02), rot_y_deg=60.0, scale=(0.5, 0.6, 0.5)), shadow=False)
+    scene.AddMeshInstance(block_veil, _xform(translate=(-0.02, 0.0, 0.22), rot_y_deg=10.0, scale=(0.7, 1.2, 0.3)), diffuse=False)
+    scene.AddMeshInstance(tall, _xform(translate=(0.02, 0.0, 0.03), rot_y_deg=-8.0))
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
 # ---- procedural atrium ("Sponza / Bistro class") ---------------------------------------------------------------
 def _grid(nu: int, nv: int, fn, flip=False):
     """Tessellated parametric patch.  fn(u, v) -> (P[...,3], N[...,3]); returns attrs [n,8], tri indices."""
@@ -421,4 +469,5 @@ SCENES = {
     "cornell_lights": cornell_lights,
     "cornell_env": cornell_env,
     "cornell_filmic": cornell_filmic,
+    "cornell_instances": cornell_instances,
 }

@@ -16,7 +16,7 @@ from ray_amd import hip
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["cornell_basic", "cornell_principled", "cornell_lights", "cornell_env", "cornell_filmic"]
+SCENES = ["cornell_basic", "cornell_principled", "cornell_lights", "cornell_env", "cornell_filmic", "cornell_instances"]
 
 
 @pytest.fixture(scope="module")
@@ -275,8 +275,9 @@ def test_iteration_batching_is_bit_identical(gpu_lib, name):
 def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
     """RAYHIP_REFILL=1: the persistent ray-refill form of the closest-hit kernel (kernels.hip.h) performs the same node
     visits and triangle tests per ray, only interleaved differently between lanes -- hits and frames must be the same
-    bits, transparency rounds (cornell_principled) and all analytic lights (cornell_lights) included"""
-    for name in ("cornell_principled", "cornell_lights"):
+    bits, transparency rounds (cornell_principled), analytic lights (cornell_lights) and a TLAS with seven instances and
+    visibility masks (cornell_instances) included"""
+    for name in ("cornell_principled", "cornell_lights", "cornell_instances"):
         g = util.golden_ref(name)
         base = util.make_context(gpu_lib, name)
         monkeypatch.setenv("RAYHIP_REFILL", "1")

@@ -12,7 +12,7 @@ import oracle_lib as O
 import util
 from ray_amd import hip
 
-SCENES = ["cornell_basic", "cornell_principled", "cornell_lights", "cornell_env", "cornell_filmic"]
+SCENES = ["cornell_basic", "cornell_principled", "cornell_lights", "cornell_env", "cornell_filmic", "cornell_instances"]
 
 
 @pytest.fixture(scope="module")
