@@ -7,6 +7,8 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp RAY_AMD_CACHE=/tmp/ray_amd_cache
 cd $REPO
+echo "== parity report"; python tools/parity_report.py 2>&1 | grep -v Warning | tee $OUT/parity_report.txt
+echo "== shard emulation"; timeout 300 python tools/shard_emulation.py bistro 480 2>&1 | grep "^N=" | tee $OUT/shard_emulation.txt
 for wl in bistro sponza cornell principled; do
   echo "== bench $wl"
   timeout 400 python bench.py --workload $wl > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || tail -3 $OUT/bench_$wl.err
