@@ -69,7 +69,7 @@ InvalidHandle = _capi.INVALID_HANDLE
 class Settings:  # Ray::settings_t, RendererBase.h:52-63
     w: int = 0
     h: int = 0
-    use_tex_compression: bool = False  # the HIP backend takes uncompressed textures only
+    use_tex_compression: bool = False  # (the reference's default is True; the HIP backend decodes such textures at export)
     verbose: bool = False
 
 
@@ -145,7 +145,7 @@ class SceneBase:
 
     # -- textures / materials ----------------------------------------------------------------------------------
     def AddTexture(self, data: np.ndarray, fmt=eTextureFormat.RGBA8888, is_srgb=True, is_normalmap=False,
-                   generate_mipmaps=False, reconstruct_z=False) -> int:
+                   generate_mipmaps=False, reconstruct_z=False, force_no_compression=True) -> int:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         h, w = data.shape[0], data.shape[1]
         d = _capi.TexDesc()
@@ -154,7 +154,7 @@ class SceneBase:
         d.data_size = data.size
         d.w, d.h = w, h
         d.is_srgb, d.is_normalmap = int(is_srgb), int(is_normalmap)
-        d.force_no_compression = 1
+        d.force_no_compression = int(force_no_compression)  # False: settings_t::use_tex_compression decides
         d.generate_mipmaps, d.reconstruct_z = int(generate_mipmaps), int(reconstruct_z)
         return int(self._lib.ray_scene_add_texture(self._ptr, C.byref(d)))
 

@@ -41,7 +41,8 @@ class Scene final : public Cpu::Scene {
     std::atomic<uint64_t> version_{1};
 
   public:
-    explicit Scene(ILog *log) : Cpu::Scene(log, false /* use_wide_bvh */, false /* use_tex_compression */, false) {}
+    Scene(ILog *log, const bool use_tex_compression)
+        : Cpu::Scene(log, false /* use_wide_bvh */, use_tex_compression /* decoded at export, scene_export.h */, false) {}
 
     uint64_t version() const { return version_.load(); }
 
@@ -96,6 +97,7 @@ class Renderer final : public RendererBase {
     mutable rayhip_camera pending_cam_ = {};
     mutable int pending_rect_[4] = {};
     int lut_transform_ = 0; // view transform whose look-up table is on the device
+    bool use_tex_compression_ = false; // settings_t::use_tex_compression, handed to the scenes this renderer creates
     int max_batch_ = 64; // further limited by rayhip_max_batch() (frame size)
 
     void Flush() const {
@@ -153,7 +155,7 @@ class Renderer final : public RendererBase {
     }
 
   public:
-    Renderer(const settings_t &s, ILog *log) : log_(log) {
+    Renderer(const settings_t &s, ILog *log) : log_(log), use_tex_compression_(s.use_tex_compression) {
         if (rayhip_device_count() <= 0) {
             throw std::runtime_error("no HIP device found");
         }
@@ -229,7 +231,7 @@ class Renderer final : public RendererBase {
         }
     }
 
-    SceneBase *CreateScene() override { return new Scene(log_); }
+    SceneBase *CreateScene() override { return new Scene(log_, use_tex_compression_); }
 
     void RenderScene(const SceneBase &scene, RegionContext &region) override {
         const auto *s = dynamic_cast<const Scene *>(&scene);
@@ -328,7 +330,7 @@ class Renderer final : public RendererBase {
 
 RendererBase *CreateRenderer(const settings_t &s, ILog *log) { return new Renderer(s, log); }
 
-SceneBase *CreateScene(ILog *log) { return new Scene(log); }
+SceneBase *CreateScene(ILog *log) { return new Scene(log, false); }
 
 std::vector<uint8_t> ExportSceneBlob(const SceneBase &scene) {
     const auto *s = dynamic_cast<const Cpu::Scene *>(&scene);

@@ -130,14 +130,19 @@ class SceneAccess : public Cpu::Scene {
         export_storage<Cpu::TexStorageRG, 2>(s.tex_storage_rg_, out);
         d.tex_table[3] = uint32_t(out.textures.size());
         export_storage<Cpu::TexStorageR, 1>(s.tex_storage_r_, out);
-        for (int i = 4; i < 8; ++i) {
-            d.tex_table[i] = uint32_t(out.textures.size());
-        }
-        if (s.tex_storage_bc1_.img_count() || s.tex_storage_bc3_.img_count() || s.tex_storage_bc4_.img_count() ||
-            s.tex_storage_bc5_.img_count()) {
-            throw std::runtime_error(
-                "SceneHIP: BCn-compressed textures are not supported (settings_t::use_tex_compression must be false)");
-        }
+        // Block-compressed storages (settings_t::use_tex_compression, the reference's default; eTextureFormat::BC1..BC5
+        // inputs): the device keeps every texture as linear RGBA8, so these are DECODED here, texel by texel, with the
+        // reference's own TexStorageBCn::Get (TextureStorageCPU.h:384-544) -- the values a CPU fetch returns, hence the
+        // same images as the reference renders from the compressed data.  (Memory: 4-8x the compressed size; a
+        // Bistro-class texture set stays far below 288 GB.  Decoding on the device is SURVEY section 8f, N4.)
+        d.tex_table[4] = uint32_t(out.textures.size());
+        export_storage<Cpu::TexStorageBCn<3>, 3>(s.tex_storage_bc1_, out);
+        d.tex_table[5] = uint32_t(out.textures.size());
+        export_storage<Cpu::TexStorageBCn<4>, 4>(s.tex_storage_bc3_, out);
+        d.tex_table[6] = uint32_t(out.textures.size());
+        export_storage<Cpu::TexStorageBCn<1>, 1>(s.tex_storage_bc4_, out);
+        d.tex_table[7] = uint32_t(out.textures.size());
+        export_storage<Cpu::TexStorageBCn<2>, 2>(s.tex_storage_bc5_, out);
         d.textures = out.textures.data();
         d.textures_count = uint32_t(out.textures.size());
         d.texels = out.texels.data();

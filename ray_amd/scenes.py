@@ -15,7 +15,7 @@ from typing import Tuple
 
 import numpy as np
 
-from .api import PrincipledMat, ShadingNode, eShadingNode
+from .api import PrincipledMat, ShadingNode, eShadingNode, eTextureFormat
 
 # ---- Cornell box ----------------------------------------------------------------------------------------------
 # quad = (4 corners, normal, 4 uvs, index pattern).  Measurements are the classic Cornell data in metres with x
@@ -249,6 +249,37 @@ def cornell_env(scene, **cam_overrides):
     q = _CORNELL_QUADS
     attrs, idx = cornell_mesh_arrays([q[0], q[1], q[3], q[4]] + _block_quads("short") + _block_quads("tall"))
     groups = [(grey, None, 0, 12), (red, None, 12, 6), (green, None, 18, 6), (grey, None, 24, 30), (shiny, None, 54, 30)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
+def cornell_textures(scene, **cam_overrides):
+    """Cornell box whose floor / back wall / blocks carry an RGB888 base colour map, an R8 roughness map and a normal map,
+    all with mip chains and WITHOUT force_no_compression: under settings_t::use_tex_compression they land in the BC3
+    (YCoCg), BC4 and BC5 storages (SceneCPU.cpp:60-200), otherwise in RGB / R / RG."""
+    scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
+    res = 64
+    i, j = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
+    rgb = np.empty((res, res, 3), dtype=np.uint8)  # smooth gradients + a grid: lossy under BC3
+    rgb[..., 0] = (40 + 180 * (0.5 + 0.5 * np.sin(i * 0.31) * np.cos(j * 0.17))).astype(np.uint8)
+    rgb[..., 1] = (30 + 200 * (j / (res - 1.0))).astype(np.uint8)
+    rgb[..., 2] = np.where(((i // 8) + (j // 8)) % 2 == 0, 220, 60).astype(np.uint8)
+    rough = (20 + 200 * (0.5 + 0.5 * np.sin(i * 0.23 + j * 0.41))).astype(np.uint8)[..., None]
+    kw = dict(generate_mipmaps=True, force_no_compression=False)
+    t_rgb = scene.AddTexture(rgb, fmt=eTextureFormat.RGB888, is_srgb=True, **kw)
+    t_rough = scene.AddTexture(rough, fmt=eTextureFormat.R8, is_srgb=False, **kw)
+    t_nrm = scene.AddTexture(bump_normal_map(res), is_srgb=False, is_normalmap=True, **kw)
+    tex = scene.AddMaterial(PrincipledMat(base_texture=t_rgb, roughness=1.0, roughness_texture=t_rough, normal_map=t_nrm,
+                                          normal_map_intensity=1.0, specular=0.5))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.0, 0.0)))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.0, 0.5, 0.0)))
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=100.0, importance_sample=True))
+    attrs, idx = cornell_mesh_arrays()
+    groups = [(tex, None, 0, 6), (grey, None, 6, 6), (tex, None, 12, 6), (red, None, 19, 6), (green, None, 25, 6),
+              (emit, 0xFFFFFFFF, 31, 6), (tex, None, 37, 60)]
     mesh = scene.AddMesh(attrs, idx, groups)
     scene.AddMeshInstance(mesh)
     _cornell_camera(scene, **cam_overrides)

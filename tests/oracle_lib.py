@@ -48,8 +48,9 @@ def ref_lib():
     return _ref
 
 
-def create_renderer(w, h, renderer_type="REF", verbose=False):
-    return api.create_renderer_from(ref_lib(), api.Settings(w, h, use_tex_compression=False, verbose=verbose), renderer_type)
+def create_renderer(w, h, renderer_type="REF", verbose=False, use_tex_compression=False):
+    return api.create_renderer_from(ref_lib(), api.Settings(w, h, use_tex_compression=use_tex_compression, verbose=verbose),
+                                    renderer_type)
 
 
 def pmj_table() -> np.ndarray:
@@ -130,8 +131,8 @@ def hostsim_context(w, h, blob: bytes, pmj=None):
     return ctx
 
 
-def render_ref(scene_fn, w, h, spp, renderer_type="REF", **cam):
-    r = create_renderer(w, h, renderer_type)
+def render_ref(scene_fn, w, h, spp, renderer_type="REF", use_tex_compression=False, **cam):
+    r = create_renderer(w, h, renderer_type, use_tex_compression=use_tex_compression)
     s = r.CreateScene()
     scene_fn(s, **cam)
     region = api.RegionContext((0, 0, w, h))

@@ -341,6 +341,32 @@ def test_camera_features_match_the_host_build(gpu_lib, hostsim_lib, cam):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
 
 
+def test_compressed_textures_through_the_ray_api(gpu_lib, hostsim_lib):
+    """settings_t::use_tex_compression = true (the reference's default): SceneHIP keeps the BCn storages and the exporter
+    decodes them (host build == reference on this, tests/test_hostsim_parity.py); the GPU must agree with the host build"""
+    import os
+    from ray_amd import api, scenes
+    if not os.path.exists(api.HIP_HOST_LIB):
+        pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
+    w, h, spp = 64, 64, 4
+    blobs = []
+    for compress in (True, False):
+        r = api.CreateRenderer(api.Settings(w, h, use_tex_compression=compress), "HIP")
+        s = r.CreateScene()
+        scenes.cornell_textures(s)
+        blobs.append(api.export_scene_blob(s))
+    imgs = []
+    for lib, blob in ((hostsim_lib, blobs[0]), (gpu_lib, blobs[0]), (gpu_lib, blobs[1])):
+        ctx = hip.Context(0, lib)
+        ctx.upload_static(util.pmj())
+        ctx.resize(w, h)
+        ctx.upload_scene_blob(blob)
+        imgs.append(util.render_frames(ctx, spp))
+    m = util.frame_metrics(imgs[1], imgs[0])
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
+    assert not np.array_equal(imgs[1], imgs[2]), "compression did not change a texel: not exercised"
+
+
 @pytest.mark.parametrize("name", ["cornell_lights", "cornell_filmic"])
 def test_renderer_hip_through_the_ray_api(gpu_lib, name):
     """the drop-in itself: Ray::CreateRenderer(HIP) -> SceneHIP mutators -> RenderScene x N -> get_*_pixels_ref.  The live

@@ -125,6 +125,26 @@ def test_camera_features_against_live_reference(lib, cam):
     assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
 
 
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_compressed_textures_against_live_reference(lib):
+    """settings_t::use_tex_compression (the reference's default): RGBA/RGB/R inputs and normal maps land in the BC3
+    (YCoCg) / BC4 / BC5 storages; the exporter decodes them with the reference's own block decoder, so the frames must
+    equal the reference's rendered from the compressed data"""
+    from ray_amd import api, scenes
+
+    w, h, spp = 64, 64, 4
+    r, s = O.render_ref(scenes.cornell_textures, w, h, spp, use_tex_compression=True)
+    r0, s0 = O.render_ref(scenes.cornell_textures, w, h, spp)
+    ctx0 = O.hostsim_context(w, h, O.export_scene(s0))  # the same scene in the RGB / R / RG storages
+    assert np.array_equal(util.render_frames(ctx0, spp), r0.get_raw_pixels_ref())
+    assert not np.array_equal(r.get_raw_pixels_ref(), r0.get_raw_pixels_ref()), "compression did not change a texel: not exercised"
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    img = util.render_frames(ctx, spp)
+    assert np.array_equal(img, r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_layout_pass_is_exercised(lib, name):
     """librayhip re-orders nodes and triangles at upload (ray_amd/csrc/bvh_layout.h); the host build runs the same pass,

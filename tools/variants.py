@@ -110,9 +110,11 @@ def run1(name, workload="sponza", K=16):
             ctx.stage_times()
             t0 = time.perf_counter()
             ctx.render_batch(3 + K, K, flags=hip.FLAG_TIME_STAGES | rflags)
+            it_next = 3 + 2 * K
         else:
             for it in range(3, 3 + K):
                 ctx.render(it, flags=hip.FLAG_TIME_STAGES | rflags)
+            it_next = 3 + K
         ctx.sync()
         dt = time.perf_counter() - t0
         (k2, n2), (k3, n3) = ctx.trav_timing()
@@ -122,7 +124,9 @@ def run1(name, workload="sponza", K=16):
             ref_img = img
             np.save(ref_path, img)
         d = np.abs(img - ref_img)
-        ctx.render(3 + K, flags=hip.FLAG_COUNT_TRAVERSAL)
+        # (iterations must stay consecutive: a pixel whose required_samples is below the iteration counts as converged)
+        ctx.render(it_next, flags=hip.FLAG_COUNT_TRAVERSAL)
+        it_next += 1
         c2, c3 = ctx.trav_counters()
         print(f"{name:14s} {wl['w']}x{wl['h']} {wl['w'] * wl['h'] * K / dt / 1e6:7.1f} Msamples/s  step {dt / K * 1e3:6.2f} ms | K2 {k2 / K:6.2f} ms K3 {k3 / K:5.2f} ms "
               f"shade {(st['primary_shade'] + st['secondary_shade']) / K / 1e3:5.2f} ms gen {st['primary_ray_gen'] / K / 1e3:4.2f} sort {st['secondary_sort'] / K / 1e3:4.2f} | "
@@ -137,9 +141,9 @@ def run1(name, workload="sponza", K=16):
             if os.environ.get("RT_PROF_RAW"):
                 print("  raw (timed passes):", list(buf))
             if batch > 1:
-                ctx.render_batch(100, K)
+                ctx.render_batch(it_next, K)
             else:
-                for it in range(100, 100 + K):
+                for it in range(it_next, it_next + K):
                     ctx.render(it)
             f(ctx._ctx, ctypes.byref(buf), 1)
             if os.environ.get("RT_PROF_RAW"):
