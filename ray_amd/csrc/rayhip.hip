@@ -488,6 +488,12 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     if (d->env.qtree_levels < 0 || d->env.qtree_levels > 16) {
         return fail("bad env-map quadtree depth %d", d->env.qtree_levels);
     }
+    if (d->env.sky_map_spread_angle > 0.0f) {
+        // With PhysicalSkyTexture the reference evaluates narrow rays analytically (ShadeSky*, AtmosphereRef.cpp: SURVEY
+        // section 2, out of scope) and only wide ones through the baked map; rendering all of them from the map would be
+        // a silently different image.
+        return fail("the physical sky (environment_t::sky_map_spread_angle > 0) is not supported by the HIP backend");
+    }
     {
         size_t quads = 0;
         for (int lod = 0; lod < d->env.qtree_levels; ++lod) {

@@ -255,6 +255,31 @@ def cornell_env(scene, **cam_overrides):
     scene.Finalize()
 
 
+def cornell_portals(scene, **cam_overrides):
+    """cornell_env's open box under the RGBE sky, with the opening covered by sky portals -- a rectangular and a disk
+    light with sky_portal = true (SceneBase.h rect/disk_light_desc_t): SampleLightSource takes their colour from the
+    environment map, IntersectAreaLights / Evaluate_LightColor treat them as windows onto it."""
+    sky = scene.AddTexture(rgbe_sky(), is_srgb=False)
+    scene.SetEnvironment(env_col=(1.0, 1.0, 1.0), back_col=(1.0, 1.0, 1.0), env_map=sky, back_map=sky,
+                         env_map_rotation=0.3, back_map_rotation=0.3, importance_sample=False)
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.05, 0.05)))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.05, 0.5, 0.05)))
+    shiny = scene.AddMaterial(PrincipledMat(base_color=(0.8, 0.8, 0.85), metallic=1.0, roughness=0.15))
+    q = _CORNELL_QUADS
+    attrs, idx = cornell_mesh_arrays([q[0], q[1], q[3], q[4]] + _block_quads("short") + _block_quads("tall"))
+    groups = [(grey, None, 0, 12), (red, None, 12, 6), (green, None, 18, 6), (grey, None, 24, 30), (shiny, None, 54, 30)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    # facing down into the box (rect/disk lights emit along -y of their frame after the rotation about x)
+    scene.AddLight("rect", color=(1.0, 1.0, 1.0), width=0.30, height=0.50, sky_portal=True,
+                   xform=_translate(-0.41, 0.5488, -0.28))
+    scene.AddLight("disk", color=(1.0, 1.0, 1.0), width=0.24, height=0.24, sky_portal=True,
+                   xform=_translate(-0.13, 0.5488, -0.28))
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
 def cornell_textures(scene, **cam_overrides):
     """Cornell box whose floor / back wall / blocks carry an RGB888 base colour map, an R8 roughness map and a normal map,
     all with mip chains and WITHOUT force_no_compression: under settings_t::use_tex_compression they land in the BC3

@@ -341,6 +341,30 @@ def test_camera_features_match_the_host_build(gpu_lib, hostsim_lib, cam):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
 
 
+@pytest.mark.parametrize("scene", ["cornell_portals", "cornell_textures"])
+def test_live_only_scenes_match_the_host_build(gpu_lib, hostsim_lib, scene):
+    """scenes whose parity with the reference is established on the host build against the live reference
+    (tests/test_hostsim_parity.py: sky portals; RGB888 / R8 / normal-map textures with mip chains): GPU vs host build"""
+    import os
+    from ray_amd import api, scenes
+    if not os.path.exists(api.HIP_HOST_LIB):
+        pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
+    w, h, spp = 64, 64, 6
+    r = api.CreateRenderer(api.Settings(w, h), "HIP")
+    s = r.CreateScene()
+    getattr(scenes, scene)(s)
+    blob = api.export_scene_blob(s)
+    imgs = []
+    for lib in (hostsim_lib, gpu_lib):
+        ctx = hip.Context(0, lib)
+        ctx.upload_static(util.pmj())
+        ctx.resize(w, h)
+        ctx.upload_scene_blob(blob)
+        imgs.append(util.render_frames(ctx, spp))
+    m = util.frame_metrics(imgs[1], imgs[0])
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
+
+
 def test_compressed_textures_through_the_ray_api(gpu_lib, hostsim_lib):
     """settings_t::use_tex_compression = true (the reference's default): SceneHIP keeps the BCn storages and the exporter
     decodes them (host build == reference on this, tests/test_hostsim_parity.py); the GPU must agree with the host build"""

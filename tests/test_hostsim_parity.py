@@ -126,6 +126,20 @@ def test_camera_features_against_live_reference(lib, cam):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_sky_portals_against_live_reference(lib):
+    """rect / disk lights with sky_portal = true over an environment map"""
+    from ray_amd import api, scenes
+
+    w, h, spp = 64, 64, 6
+    r, s = O.render_ref(scenes.cornell_portals, w, h, spp)
+    r0, _ = O.render_ref(scenes.cornell_env, w, h, spp)
+    assert not np.array_equal(r.get_raw_pixels_ref(), r0.get_raw_pixels_ref())
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), r.get_pixels_ref())
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_compressed_textures_against_live_reference(lib):
     """settings_t::use_tex_compression (the reference's default): RGBA/RGB/R inputs and normal maps land in the BC3
     (YCoCg) / BC4 / BC5 storages; the exporter decodes them with the reference's own block decoder, so the frames must
