@@ -176,7 +176,7 @@ def _translate(x, y, z, rot_x_deg=0.0, rot_z_deg=0.0):
     return m.T.astype(np.float32).ravel()  # column-major
 
 
-def cornell_lights(scene, **cam_overrides):
+def cornell_lights(scene, light_flags=None, **cam_overrides):
     """Cornell box lit by every analytic light type (all visible to secondary rays -> IntersectAreaLights, MIS) with a
     zoo of shading nodes: Principled floor with textures, Oren-Nayar walls, normal-mapped glossy back wall, refractive
     short block, Mix(diffuse, transparent) tall block.  Not a reference sample; built to cover SURVEY 8 a11-a14."""
@@ -202,14 +202,17 @@ def cornell_lights(scene, **cam_overrides):
     mesh = scene.AddMesh(attrs, idx, groups)
     scene.AddMeshInstance(mesh)
 
-    scene.AddLight("sphere", color=(6.0, 5.0, 4.0), position=(-0.12, 0.42, -0.12), radius=0.025)
+    # `light_flags`: per-light overrides of the light_desc flags (tests: cast_shadow, *_visibility, multiple_importance)
+    lf = light_flags or {}
+    scene.AddLight("sphere", color=(6.0, 5.0, 4.0), position=(-0.12, 0.42, -0.12), radius=0.025, **lf.get("sphere", {}))
     scene.AddLight("spot", color=(20.0, 20.0, 26.0), position=(-0.47, 0.50, -0.10), direction=(0.45, -0.85, -0.3),
-                   radius=0.015, spot_size=55.0, spot_blend=0.2)
-    scene.AddLight("rect", color=(8.0, 8.0, 7.0), width=0.16, height=0.10, xform=_translate(-0.30, 0.52, -0.44))
+                   radius=0.015, spot_size=55.0, spot_blend=0.2, **lf.get("spot", {}))
+    scene.AddLight("rect", color=(8.0, 8.0, 7.0), width=0.16, height=0.10, xform=_translate(-0.30, 0.52, -0.44), **lf.get("rect", {}))
     scene.AddLight("disk", color=(2.0, 7.0, 2.5), width=0.09, height=0.12, doublesided=True,
-                   xform=_translate(-0.545, 0.30, -0.30, rot_z_deg=-90.0))
-    scene.AddLight("line", color=(7.0, 2.0, 2.0), radius=0.006, height=0.25, xform=_translate(-0.02, 0.35, -0.30, rot_x_deg=90.0))
-    scene.AddLight("directional", color=(1.2, 1.1, 1.0), direction=(0.25, -0.45, -1.0), angle=4.0)
+                   xform=_translate(-0.545, 0.30, -0.30, rot_z_deg=-90.0), **lf.get("disk", {}))
+    scene.AddLight("line", color=(7.0, 2.0, 2.0), radius=0.006, height=0.25, xform=_translate(-0.02, 0.35, -0.30, rot_x_deg=90.0),
+                   **lf.get("line", {}))
+    scene.AddLight("directional", color=(1.2, 1.1, 1.0), direction=(0.25, -0.45, -1.0), angle=4.0, **lf.get("directional", {}))
     _cornell_camera(scene, **cam_overrides)
     scene.Finalize()
 
@@ -251,6 +254,38 @@ def cornell_env(scene, **cam_overrides):
     groups = [(grey, None, 0, 12), (red, None, 12, 6), (green, None, 18, 6), (grey, None, 24, 30), (shiny, None, 54, 30)]
     mesh = scene.AddMesh(attrs, idx, groups)
     scene.AddMeshInstance(mesh)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
+def cornell_principled_zoo(scene, **cam_overrides):
+    """every quad group of the Cornell mesh gets its own corner of principled_mat_desc_t / shading_node_desc_t: metals
+    with anisotropy, rough and clear transmission, sheen + tints, clearcoat, emission inside a Principled material,
+    alpha (-> Mix with Transparent), Glossy / Refractive / Diffuse nodes with textures, a Mix with mix_add"""
+    scene.SetEnvironment(env_col=(0.05, 0.06, 0.08))
+    tex = scene.AddTexture(checkerboard(64, 8), generate_mipmaps=True)
+    alpha = scene.AddTexture(checkerboard(32, 4), is_srgb=False)
+    nmap = scene.AddTexture(bump_normal_map(64), is_srgb=False, is_normalmap=True)
+    P, N = PrincipledMat, ShadingNode
+    floor = scene.AddMaterial(P(base_texture=tex, metallic=1.0, roughness=0.3, anisotropic=0.8, anisotropic_rotation=0.25))
+    back = scene.AddMaterial(P(base_color=(0.7, 0.6, 0.9), roughness=0.5, sheen=1.0, sheen_tint=0.6, specular=0.8, specular_tint=0.7))
+    ceil = scene.AddMaterial(P(base_color=(0.8, 0.8, 0.8), roughness=0.7, emission_color=(1.0, 0.8, 0.6), emission_strength=0.5))
+    left = scene.AddMaterial(P(base_color=(0.6, 0.1, 0.1), clearcoat=1.0, clearcoat_roughness=0.05, roughness=0.6, normal_map=nmap,
+                               normal_map_intensity=0.5))
+    right = scene.AddMaterial(N(type=eShadingNode.Glossy, base_texture=tex, roughness=0.15, anisotropic=0.5))
+    emit = scene.AddMaterial(N(type=eShadingNode.Emissive, strength=60.0, importance_sample=True))
+    short = scene.AddMaterial(P(base_color=(0.9, 1.0, 0.9), transmission=1.0, roughness=0.05, ior=1.5, transmission_roughness=0.2))
+    tall_a = scene.AddMaterial(P(base_color=(0.2, 0.4, 0.9), roughness=0.4, alpha=0.6, alpha_texture=alpha))
+    d1 = scene.AddMaterial(N(type=eShadingNode.Diffuse, base_color=(0.8, 0.3, 0.1), roughness=0.9))
+    d2 = scene.AddMaterial(N(type=eShadingNode.Refractive, base_color=(1.0, 1.0, 1.0), roughness=0.3, ior=1.33))
+    tall_b = scene.AddMaterial(N(type=eShadingNode.Mix, mix_materials=(d1, d2), strength=0.35, mix_add=True))
+    attrs, idx = cornell_mesh_arrays()
+    # floor | ceiling | back | left | right | light | short block: 5 quads | tall block: 5 quads
+    groups = [(floor, None, 0, 6), (ceil, None, 6, 6), (back, None, 12, 6), (left, None, 19, 6), (right, None, 25, 6),
+              (emit, 0xFFFFFFFF, 31, 6), (short, short, 37, 30), (tall_a, tall_a, 67, 12), (tall_b, tall_b, 79, 18)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    scene.AddLight("sphere", color=(3.0, 3.0, 3.5), position=(-0.40, 0.45, -0.15), radius=0.02)
     _cornell_camera(scene, **cam_overrides)
     scene.Finalize()
 

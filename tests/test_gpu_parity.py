@@ -341,7 +341,7 @@ def test_camera_features_match_the_host_build(gpu_lib, hostsim_lib, cam):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
 
 
-@pytest.mark.parametrize("scene", ["cornell_portals", "cornell_textures"])
+@pytest.mark.parametrize("scene", ["cornell_portals", "cornell_textures", "cornell_principled_zoo"])
 def test_live_only_scenes_match_the_host_build(gpu_lib, hostsim_lib, scene):
     """scenes whose parity with the reference is established on the host build against the live reference
     (tests/test_hostsim_parity.py: sky portals; RGB888 / R8 / normal-map textures with mip chains): GPU vs host build"""

@@ -126,6 +126,38 @@ def test_camera_features_against_live_reference(lib, cam):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_light_flags_against_live_reference(lib):
+    """light_desc flags the fixtures leave at their defaults: cast_shadow, diffuse / specular / refraction visibility,
+    multiple_importance (SceneBase.h light descriptors -> light_t flag bits)"""
+    from functools import partial
+    from ray_amd import scenes
+
+    flags = {"sphere": dict(cast_shadow=False), "spot": dict(specular_visibility=False), "rect": dict(diffuse_visibility=False),
+             "disk": dict(refraction_visibility=False, multiple_importance=False), "line": dict(multiple_importance=False),
+             "directional": dict(cast_shadow=False, specular_visibility=False)}
+    w, h, spp = 64, 64, 6
+    r, s = O.render_ref(partial(scenes.cornell_lights, light_flags=flags), w, h, spp)
+    r0, _ = O.render_ref(scenes.cornell_lights, w, h, spp)
+    assert not np.array_equal(r.get_raw_pixels_ref(), r0.get_raw_pixels_ref())
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_material_zoo_against_live_reference(lib):
+    """principled_mat_desc_t / shading_node_desc_t corners the fixtures do not reach (anisotropy, transmission, sheen and
+    specular tints, emission inside Principled, alpha textures, mix_add, textured Glossy)"""
+    from ray_amd import api, scenes
+
+    w, h, spp = 72, 64, 6
+    r, s = O.render_ref(scenes.cornell_principled_zoo, w, h, spp)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_sky_portals_against_live_reference(lib):
     """rect / disk lights with sky_portal = true over an environment map"""
     from ray_amd import api, scenes
