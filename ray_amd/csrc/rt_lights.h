@@ -372,6 +372,29 @@ RT_HD void fill_light_children(const rayhip_light_cwbvh_node &n, float4 *out /* 
     }
 }
 
+// `light_tri_geom` table: what sampling a TRI light needs from the scene, resolved once per scene instead of once per
+// sample -- the reference walks light -> mesh instance (xform) -> vtx_indices -> three 44-byte vertices and transforms the
+// corners (CoreRef.cpp:3530-3545): three dependent round trips and ~25 scattered loads per shade point.  Four float4 per
+// light: (p1, uv1.x) (p2, uv1.y) (p3, uv2.x) (uv2.y, uv3.x, uv3.y, -), corners already in world space, computed by this
+// very function on the host (same IEEE operations as the device would perform, so the same bits).
+RT_HD void fill_light_tri_geom(const rayhip_light &l, const rayhip_mesh_instance *mesh_instances, const uint32_t *vtx_indices,
+                               const rayhip_vertex *vertices, float4 *out /* [4] */) {
+    out[0] = out[1] = out[2] = out[3] = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (light_type(l) != LIGHT_TYPE_TRI) {
+        return;
+    }
+    const uint32_t ltri_index = float_as_uint(l.params[0]);
+    const rayhip_mesh_instance &lmi = mesh_instances[float_as_uint(l.params[1])];
+    const rayhip_vertex &v1 = vertices[vtx_indices[ltri_index * 3 + 0]], &v2 = vertices[vtx_indices[ltri_index * 3 + 1]],
+                        &v3 = vertices[vtx_indices[ltri_index * 3 + 2]];
+    const f3 p1 = transform_point(mk3(v1.p), lmi.xform), p2 = transform_point(mk3(v2.p), lmi.xform),
+             p3 = transform_point(mk3(v3.p), lmi.xform);
+    out[0] = mkfloat4(p1.x, p1.y, p1.z, v1.t[0]);
+    out[1] = mkfloat4(p2.x, p2.y, p2.z, v1.t[1]);
+    out[2] = mkfloat4(p3.x, p3.y, p3.z, v2.t[0]);
+    out[3] = mkfloat4(v2.t[1], v3.t[0], v3.t[1], 0.0f);
+}
+
 // importance of the eight children of light-tree node `node_index` (through the table fill_light_children filled)
 RT_HD void calc_lnode_importance(const SceneView &sc, const uint32_t node_index, const f3 P, float importance[8]) {
     const float4 *t = sc.light_children + size_t(node_index) * LIGHT_CHILDREN_STRIDE;
@@ -788,16 +811,13 @@ RT_HD void sample_light_source(const SceneView &sc, const f3 P, const f3 T, cons
             ls.area = 0.0f;
         }
     } else if (ltype == LIGHT_TYPE_TRI) {
-        const uint32_t ltri_index = float_as_uint(l.params[0]);
-        const rayhip_mesh_instance &lmi = sc.mesh_instances[float_as_uint(l.params[1])];
         const uint32_t tex_index = float_as_uint(l.params[2]);
 
-        const rayhip_vertex &v1 = sc.vertices[sc.vtx_indices[ltri_index * 3 + 0]], &v2 = sc.vertices[sc.vtx_indices[ltri_index * 3 + 1]],
-                            &v3 = sc.vertices[sc.vtx_indices[ltri_index * 3 + 2]];
-
-        const f3 p1 = transform_point(mk3(v1.p), lmi.xform), p2 = transform_point(mk3(v2.p), lmi.xform),
-                 p3 = transform_point(mk3(v3.p), lmi.xform);
-        const f2 uv1 = mk2(v1.t[0], v1.t[1]), uv2 = mk2(v2.t[0], v2.t[1]), uv3 = mk2(v3.t[0], v3.t[1]);
+        // world-space corners and uvs from the per-light table (fill_light_tri_geom)
+        const float4 *tg = sc.light_tri_geom + size_t(light_index) * 4;
+        const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2], g3 = tg[3];
+        const f3 p1 = {g0.x, g0.y, g0.z}, p2 = {g1.x, g1.y, g1.z}, p3 = {g2.x, g2.y, g2.z};
+        const f2 uv1 = mk2(g0.w, g1.w), uv2 = mk2(g2.w, g3.x), uv3 = mk2(g3.y, g3.z);
 
         const f3 e1 = p2 - p1, e2 = p3 - p1;
         float light_fwd_len;

@@ -42,7 +42,7 @@ struct HostScene {
     std::vector<rayhip_light> lights;
     std::vector<uint32_t> li_indices;
     std::vector<rayhip_light_cwbvh_node> light_cwnodes;
-    std::vector<float4> light_children;
+    std::vector<float4> light_children, light_tri_geom;
     std::vector<float> env_qtree;
     std::vector<Bvh4Node> nodes4;
     std::vector<uint32_t> blas_root4;
@@ -129,6 +129,11 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     for (uint32_t n = 0; n < d->light_cwnodes_count; ++n) {
         fill_light_children(d->light_cwnodes[n], &s.light_children[size_t(n) * LIGHT_CHILDREN_STRIDE]);
     }
+    s.light_tri_geom.assign(size_t(d->lights_count) * 4, mkfloat4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (uint32_t k = 0; k < d->li_indices_count; ++k) { // (sparse pool: only the slots li_indices[] names hold lights)
+        const uint32_t i = d->li_indices[k];
+        fill_light_tri_geom(d->lights[i], d->mesh_instances, d->vtx_indices, d->vertices, &s.light_tri_geom[size_t(i) * 4]);
+    }
     CP(textures);
     CP(texels);
     CP(env_qtree);
@@ -172,6 +177,7 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     v.tri_materials = s.tri_materials.data(), v.materials = s.materials.data(), v.vertices = s.vertices.data();
     v.vtx_indices = s.vtx_indices.data(), v.mesh_instances = s.mesh_instances.data(), v.lights = s.lights.data();
     v.light_children = s.light_children.data();
+    v.light_tri_geom = s.light_tri_geom.data();
     v.env_qtree = reinterpret_cast<const float4 *>(s.env_qtree.data());
     for (int lod = 0, off = 0; lod < 16; ++lod) {
         v.env_qtree_offset[lod] = uint32_t(off);
