@@ -82,7 +82,7 @@ struct rayhip_ctx {
     DevBuf pmj, filter_table;
     // scene
     DevBuf nodes, tris, tri_indices, tri_materials, materials, vertices, vtx_indices, mesh_instances, lights, li_indices,
-        light_cwnodes, light_children, light_tri_geom, textures, texels, nodes4, blas_root4, env_qtree;
+        light_cwnodes, light_children, light_tri_geom, tri_verts, textures, texels, nodes4, blas_root4, env_qtree;
     SceneView sc = {};
     float bbox_min[3] = {}, bbox_max[3] = {};
     bool have_scene = false;
@@ -392,7 +392,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         (void)hipEventDestroy(e);
     }
     DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
-                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->light_tri_geom, &c->nodes4, &c->blas_root4, &c->env_qtree,
+                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->light_tri_geom, &c->tri_verts, &c->nodes4, &c->blas_root4, &c->env_qtree,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
                      &c->px_dn, &c->px_req, &c->px_aux_base, &c->px_aux_dn, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
                      &c->shadow_planes[2], &c->deferred_planes[0], &c->deferred_planes[1], &c->counters, &c->trav_counters, &c->stack_spill,
@@ -569,6 +569,17 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         if (upload(c, c->light_children, lc.data(), lc.size() * sizeof(float4))) {
             return 1;
         }
+        { // vertices gathered per triangle (rt_shade.h: fill_tri_verts)
+            const uint32_t n_tris = d->vtx_indices_count / 3;
+            std::vector<float4> tv(size_t(n_tris) * TRI_VERTS_STRIDE);
+            for (uint32_t t = 0; t < n_tris; ++t) {
+                fill_tri_verts(d->vertices, d->vertices_count, d->vtx_indices, t, &tv[size_t(t) * TRI_VERTS_STRIDE]);
+            }
+            if (upload(c, c->tri_verts, tv.data(), tv.size() * sizeof(float4))) {
+                return 1;
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream)); // `tv` goes out of scope
+        }
         // world-space corners of the TRI lights (rt_lights.h: fill_light_tri_geom)
         // (the light array is a sparse pool: only the slots li_indices[] names hold lights)
         std::vector<float4> tg(size_t(d->lights_count) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
@@ -604,6 +615,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     v.lights = c->lights.as<rayhip_light>(), v.li_indices = c->li_indices.as<uint32_t>();
     v.light_children = c->light_children.as<float4>();
     v.light_tri_geom = c->light_tri_geom.as<float4>();
+    v.tri_verts = c->tri_verts.as<float4>();
     v.env_qtree = c->env_qtree.as<float4>();
     for (int lod = 0, off = 0; lod < 16; ++lod) {
         v.env_qtree_offset[lod] = uint32_t(off);
