@@ -2,7 +2,9 @@
 //
 // Kernel map (reference GLSL kernel -> here; SURVEY.md section 2 kernel table):
 //   K1  primary_ray_gen.comp.glsl            -> k_raygen
-//   K2  intersect_scene.comp.glsl            -> k_trace_closest      (the roofline kernel)
+//   K2  intersect_scene.comp.glsl            -> k_trace_closest<COUNT, WIDE> (the roofline kernel; product form WIDE: the
+//                                               4-wide quantised BLAS of rt_bvh4.h, majority-scheduled; COUNT: the
+//                                               reference's BVH2 with visit counters), k_trace_closest_refill (opt-in)
 //   K3  intersect_scene_shadow.comp.glsl     -> k_trace_shadow
 //   K4  intersect_area_lights.comp.glsl      -> k_intersect_area_lights (+ k_shadow_blockers for the shadow-ray form)
 //   K5  shade.comp.glsl (PRIMARY/SECONDARY)  -> k_shade<PRIMARY>
@@ -16,8 +18,9 @@
 //   * one wavefront (64 lanes) per workgroup in the traversal kernels: the traversal stack is a per-wavefront
 //     LDS array laid out depth-major, stack[depth][lane] -> bank == lane for every lane at ANY mix of depths,
 //     i.e. conflict-free by construction (MI355X_MICROARCH.md LDS table: ds_read/write_b32 conflict only
-//     inside a 32-lane half).  48 entries x 64 lanes x 4 B = 12 KiB per wave, the same budget the reference's
-//     shader takes (shaders/intersect_scene.comp.glsl:87).
+//     inside a 32-lane half).  RT_LDS_STACK_DEPTH (24) entries x 64 lanes x 4 B = 6 KiB per wave live in LDS, deeper
+//     entries spill to a per-wave slab in HBM (the reference's shader keeps 48 in shared memory,
+//     shaders/intersect_scene.comp.glsl:87).
 //   * ray compaction between stages uses one atomic per wavefront: ballot + mbcnt prefix (wave_alloc) instead of
 //     the reference's per-thread atomicAdd (shaders/shade.comp.glsl:2432,2452), and the wavefronts are spread over
 //     64 counters (RayQueue below) because same-address atomics serialise at ~11 ns each on MI355X.
@@ -96,7 +99,7 @@ namespace rt {
 #define RT_TRACE_MIN_WAVES 6 // 80 VGPRs.  Sweep with the final kernels, 32-iteration passes: 4 waves 289, 5 waves 319, 6 waves 328 Msamples/s
 #endif
 #ifndef RT_SHADE_MIN_WAVES
-#define RT_SHADE_MIN_WAVES 3 // 168 VGPRs (80 B scratch): 2.98 ms/frame vs 3.17 at 201 VGPRs / 2 waves and at 128 / 4 waves
+#define RT_SHADE_MIN_WAVES 3 // 168 VGPRs: with the final kernels 2.10 ms/iteration vs 2.32 at 2 waves (215 VGPRs) and at 4 (128 VGPRs, 284 B scratch)
 #endif
 constexpr int WAVE = 64;
 constexpr int LDS_STACK_DEPTH = RT_LDS_STACK_DEPTH;

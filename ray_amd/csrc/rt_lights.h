@@ -253,7 +253,7 @@ RT_HD float sin_sub_clamped(float sin_a, float cos_a, float sin_b, float cos_b) 
 // calc_lnode_importance (CoreRef.cpp:1004-1066) is split in two:
 //   * decode_lnode_child: everything that depends on the node only (box un-quantisation, decode_oct_dir :935-947,
 //     decode_cosines :949-956, box centre / half-diagonal) -- about half of the arithmetic, 8 divisions and 3 square
-//     roots per child.  It is evaluated ONCE per scene into the `light_children` table (three float4 per child) when
+//     roots per child.  It is evaluated ONCE per scene into the `light_children` table (fill_light_children below) when
 //     the scene is uploaded, by this very function compiled for the host (same IEEE operations, so the same bits the
 //     device would produce), instead of 8 x depth times per shade point;
 //   * lnode_child_importance: the part that depends on the shade point P.
