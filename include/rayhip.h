@@ -348,6 +348,14 @@ RAYHIP_API int rayhip_reserve_batch(rayhip_ctx *ctx, int count);
  * caller owns the transform -> table mapping); scene blobs carry the table of their camera. */
 RAYHIP_API int rayhip_set_tonemap_lut(rayhip_ctx *ctx, int view_transform, const uint32_t *lut, int dims);
 
+/* RendererBase::DenoiseImage(const RegionContext &) (RendererBase.h:199; arithmetic RendererCPU.h:661-783 +
+ * DenoiseRef.cpp:9-93): separable 9-tap pre-filter of the per-pixel variance estimate the last accumulate left, joint
+ * non-local-means filter (7x7 window, 3x3 patches) of the reversibly tone-mapped running mean guided by the variance
+ * and by the base-colour / depth-normal images, then RAW <- filtered colour, FINAL <- Tonemap(RAW) on `rect`, and the
+ * adaptive-sampling flags of the rect's pixels.  `iteration` = RegionContext::iteration of the last RenderScene.
+ * SURVEY.md section 8f, N2; the UNet denoiser (DenoiseImage(pass, region)) is not implemented. */
+RAYHIP_API int rayhip_denoise_nlm(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int iteration);
+
 /* Multi-GPU tile sharding (new): this context renders only the pixels of the tile x tile
  * squares (row-major walk over the frame) whose ordinal % shard_count == shard_index; all other pixels of its
  * buffers stay zero, so that summing the RAW buffers of all ranks (one RCCL reduce) yields the full frame,

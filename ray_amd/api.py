@@ -327,6 +327,10 @@ class RendererBase:
     def RenderScene(self, scene: SceneBase, region: RegionContext):
         self._lib.ray_renderer_render(self._ptr, scene._ptr, region._bind(self._lib))
 
+    def DenoiseImage(self, region: RegionContext):
+        """RendererBase::DenoiseImage(const RegionContext &): the NLM denoiser"""
+        self._lib.ray_renderer_denoise(self._ptr, region._bind(self._lib))
+
     def _pixels(self, which: int) -> np.ndarray:
         w, h = self.size()
         out = np.empty((h, w, 4), dtype=np.float32)

@@ -78,6 +78,7 @@ __device__ __forceinline__ void prof_wait(float4 &a, float4 &b, float4 &c, float
 #define RT_PROF_WAIT(a, b, c, d) ::rt::prof_wait(const_cast<float4 &>(a), const_cast<float4 &>(b), const_cast<float4 &>(c), const_cast<float4 &>(d));
 #endif
 #include "rt_arealights.h"
+#include "rt_denoise.h"
 #include "rt_params.h"
 #include "rt_pixel.h"
 #include "rt_sort.h"
@@ -221,6 +222,8 @@ struct PixelBuffers {
     float4 *full, *half, *raw, *final_, *base_color, *depth_normals;
     uint16_t *required_samples;
     float4 *aux_base_layers, *aux_dn_layers; // [layers][h][w], batched passes only (rt_pixel.h)
+    float4 *variance; // [h][w]: the variance estimate of the last accumulate (the reference leaves it in its temp buffer,
+                      // RendererCPU.h:641-645; DenoiseImage reads it from there)
 };
 
 // per-layer part of AccumParams for a batched pass
@@ -923,7 +926,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const AccumParams p, const P
             continue; // another rank's pixel: stays zero here, filled in by the frame reduce
         }
         if (layers.count <= 1) {
-            accumulate_pixel(p, x, y, px.temp + (y * p.w + x), px.temp + (y * p.w + x), px.full, px.half, px.raw, px.final_, px.required_samples);
+            accumulate_pixel(p, x, y, px.temp + (y * p.w + x), px.variance + (y * p.w + x), px.full, px.half, px.raw, px.final_, px.required_samples);
             continue;
         }
         // batched pass: fold the layers into the running means in iteration order (what one call per iteration does)
@@ -940,7 +943,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const AccumParams p, const P
             if (!(px.required_samples[idx] < pl.iteration)) {
                 blend_aux_pixel(idx, px.aux_base_layers[vidx], px.aux_dn_layers[vidx], pl.mix_factor, px.base_color, px.depth_normals);
             }
-            accumulate_pixel(pl, x, y, px.temp + vidx, px.temp + vidx, px.full, px.half, px.raw, px.final_, px.required_samples);
+            accumulate_pixel(pl, x, y, px.temp + vidx, px.variance + idx, px.full, px.half, px.raw, px.final_, px.required_samples);
         }
     }
 }
@@ -953,6 +956,38 @@ __global__ void __launch_bounds__(256) k_retonemap(const AccumParams p, const Pi
         px.raw[i] = ff;
         const f4 c = tonemap(p, f4{ff.x, ff.y, ff.z, ff.w});
         px.final_[i] = mkfloat4(c.x, c.y, c.z, c.w);
+    }
+}
+
+// ---- DenoiseImage (NLM): rt_denoise.h ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_nlm_prepare_h(const DenoiseParams p, const PixelBuffers px, float4 *__restrict__ tm,
+                                                      float4 *__restrict__ var_h) {
+    const int n = p.ext_w * p.ext_h;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        nlm_prepare_h(p, i % p.ext_w, i / p.ext_w, px.full, px.variance, tm, var_h);
+    }
+}
+__global__ void __launch_bounds__(256) k_nlm_prepare_v(const DenoiseParams p, const float4 *__restrict__ var_h, float4 *__restrict__ var) {
+    const int iw = p.ext_w - 8, ih = p.ext_h - 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < iw * ih; i += gridDim.x * blockDim.x) {
+        nlm_prepare_v(p, 4 + i % iw, 4 + i / iw, var_h, var);
+    }
+}
+// one thread per pixel of the region; the 7x7 window x 3x3 patch taps come out of L1/L2 (neighbouring threads share them)
+__global__ void __launch_bounds__(256) k_nlm_filter(const DenoiseParams p, const AccumParams tone, const PixelBuffers px,
+                                                   const float4 *__restrict__ tm, const float4 *__restrict__ var) {
+    const int tiles_x = (p.rect[2] + 15) / 16, tiles_y = (p.rect[3] + 15) / 16;
+    for (int t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) { // 16x16 pixel tiles: a block's taps overlap
+        const int x = (t % tiles_x) * 16 + int(threadIdx.x % 16), y = (t / tiles_x) * 16 + int(threadIdx.x / 16);
+        if (x >= p.rect[2] || y >= p.rect[3]) {
+            continue;
+        }
+        const f4 nlm = nlm_filter_pixel(p, x, y, px.base_color, px.depth_normals, [&](const int ex, const int ey, const int which) {
+            return ld4((which ? var : tm)[ey * p.ext_w + ex]);
+        });
+        const int idx = (p.rect[1] + y) * p.w + (p.rect[0] + x);
+        nlm_finish_pixel(p, tone, idx, ld4(var[(NLM_EXT_RADIUS + y) * p.ext_w + (NLM_EXT_RADIUS + x)]), nlm, px.raw, px.final_,
+                         px.required_samples);
     }
 }
 

@@ -92,6 +92,7 @@ struct rayhip_ctx {
     int w = 0, h = 0;
     DevBuf px_temp, px_full, px_half, px_raw, px_final, px_base, px_dn, px_req, px_aux_base, px_aux_dn;
     size_t slots_cap = 0; // wavefront-state slots allocated
+    DevBuf px_variance, nlm_tm, nlm_var_h, nlm_var; // DenoiseImage: variance estimate [h][w]; [ext_h][ext_w] intermediates
     DevBuf tonemap_lut;   // table of view transform `lut_transform` (rayhip_set_tonemap_lut)
     int lut_transform = 0, lut_dims = 0;
     PixelBuffers px = {};
@@ -194,6 +195,10 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
     c->px.base_color = c->px_base.as<float4>(), c->px.depth_normals = c->px_dn.as<float4>();
     c->px.required_samples = c->px_req.as<uint16_t>();
     c->px.aux_base_layers = c->px_aux_base.as<float4>(), c->px.aux_dn_layers = c->px_aux_dn.as<float4>();
+    if (c->px_variance.alloc(npix * 16)) {
+        return 1;
+    }
+    c->px.variance = c->px_variance.as<float4>();
 
     // wavefront-state slots: one per pixel this context renders (its shard's share when the frame is tile-sharded, but
     // never less than one full frame: the kernel-level hooks and single-iteration passes of any shard fit) + the
@@ -446,7 +451,7 @@ int rayhip_resize(rayhip_ctx *c, int w, int h) {
     c->w = w, c->h = h;
     const size_t n = size_t(w) * size_t(h);
     // Resize zero-fills every buffer and arms required_samples (RendererCPU.h:266-295)
-    float4 *bufs[] = {c->px.temp, c->px.full, c->px.half, c->px.raw, c->px.final_, c->px.base_color, c->px.depth_normals};
+    float4 *bufs[] = {c->px.temp, c->px.full, c->px.half, c->px.raw, c->px.final_, c->px.base_color, c->px.depth_normals, c->px.variance};
     for (float4 *b : bufs) {
         HIP_TRY(hipMemsetAsync(b, 0, n * 16, c->stream));
     }
@@ -958,6 +963,46 @@ int rayhip_render(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], in
         return 1;
     }
     return render_pass(c, cam, rect, iteration, 1, flags, stats);
+}
+
+int rayhip_denoise_nlm(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->w) {
+        return fail("rayhip_denoise_nlm before rayhip_resize");
+    }
+    if (rect[0] < 0 || rect[1] < 0 || rect[2] <= 0 || rect[3] <= 0 || rect[0] + rect[2] > c->w || rect[1] + rect[3] > c->h) {
+        return fail("rect outside the frame");
+    }
+    if (iteration < 1) {
+        return fail("iteration is 1-based (the RegionContext::iteration of the last RenderScene)");
+    }
+    if (cam->view_transform != 0 && cam->view_transform != c->lut_transform) {
+        return fail("view transform %d needs its look-up table: rayhip_set_tonemap_lut", int(cam->view_transform));
+    }
+    DenoiseParams p;
+    p.w = c->w, p.h = c->h;
+    for (int i = 0; i < 4; ++i) {
+        p.rect[i] = rect[i];
+    }
+    p.ext_w = rect[2] + 2 * NLM_EXT_RADIUS, p.ext_h = rect[3] + 2 * NLM_EXT_RADIUS;
+    p.iteration = iteration;
+    AccumParams tone = make_accum_params(*cam, c->w, rect, iteration, c->shard);
+    tone.lut = c->tonemap_lut.as<uint32_t>(), tone.lut_dims = c->lut_dims;
+    p.variance_threshold = tone.variance_threshold; // what the last RenderScene left in variance_threshold_ (RendererCPU.h:583-604)
+    const size_t n_ext = size_t(p.ext_w) * size_t(p.ext_h);
+    if (c->nlm_tm.alloc(n_ext * 16) || c->nlm_var_h.alloc(n_ext * 16) || c->nlm_var.alloc(n_ext * 16)) {
+        return 1;
+    }
+    hipStream_t s = c->stream;
+    k_nlm_prepare_h<<<grid_for(c, n_ext, 256), 256, 0, s>>>(p, c->px, c->nlm_tm.as<float4>(), c->nlm_var_h.as<float4>());
+    k_nlm_prepare_v<<<grid_for(c, n_ext, 256), 256, 0, s>>>(p, c->nlm_var_h.as<float4>(), c->nlm_var.as<float4>());
+    const size_t tiles = size_t((rect[2] + 15) / 16) * size_t((rect[3] + 15) / 16);
+    k_nlm_filter<<<int(std::min<size_t>(tiles, size_t(c->props.multiProcessorCount) * 32u)), 256, 0, s>>>(
+        p, tone, c->px, c->nlm_tm.as<float4>(), c->nlm_var.as<float4>());
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int rayhip_set_shard(rayhip_ctx *c, int tile, int shard_count, int shard_index) {

@@ -73,7 +73,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 # every symbol include/rayhip.h declares (tests check that the built library exports all of them)
 ENTRY_POINTS = (
     "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
-    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "readback", "readback_device", "set_raw_device",
+    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand",
 )
@@ -110,6 +110,7 @@ class Library:
         f("max_batch").argtypes = [vp]
         f("reserve_batch").argtypes = [vp, C.c_int]
         f("set_tonemap_lut").argtypes = [vp, C.c_int, vp, C.c_int]
+        f("denoise_nlm").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int]
         f("readback").argtypes = [vp, C.c_int, vp, C.c_int]
         f("sync").argtypes = [vp]
         f("set_shard").argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -207,6 +208,13 @@ class Context:
         dims = round(lut.size ** (1.0 / 3.0))
         assert dims ** 3 == lut.size, "the table must be a cube"
         self.L.check(self.L.fn("set_tonemap_lut")(self._ctx, view_transform, lut.ctypes.data, dims))
+
+    def denoise_nlm(self, iteration: int, rect=None, cam: Camera = None):
+        """RendererBase::DenoiseImage(region): NLM filter of what `iteration` iterations accumulated -> RAW, FINAL"""
+        rect = (0, 0, self.w, self.h) if rect is None else rect
+        r = (C.c_int * 4)(*rect)
+        cam = cam or self.cam
+        self.L.check(self.L.fn("denoise_nlm")(self._ctx, C.byref(cam), C.byref(r), iteration))
 
     def reserve_batch(self, count: int):
         """allocate the buffers passes of `count` iterations need (under the current shard) ahead of time"""

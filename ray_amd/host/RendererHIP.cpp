@@ -96,6 +96,7 @@ class Renderer final : public RendererBase {
     mutable int pending_count_ = 0, pending_first_ = 0;
     mutable rayhip_camera pending_cam_ = {};
     mutable int pending_rect_[4] = {};
+    bool have_cam_ = false; // pending_cam_ holds the camera of the last RenderScene
     int lut_transform_ = 0; // view transform whose look-up table is on the device
     bool use_tex_compression_ = false; // settings_t::use_tex_compression, handed to the scenes this renderer creates
     int max_batch_ = 64; // further limited by rayhip_max_batch() (frame size)
@@ -286,6 +287,7 @@ class Renderer final : public RendererBase {
         // counterpart of the timestamp queries RendererVK reads back one frame later (RendererVK.cpp:452-487)
         const bool extends = pending_count_ > 0 && region.iteration == pending_first_ + pending_count_ &&
                              memcmp(&rc, &pending_cam_, sizeof(rc)) == 0 && memcmp(r, pending_rect_, sizeof(r)) == 0;
+        have_cam_ = true;
         if (!extends) {
             Flush();
             pending_cam_ = rc;
@@ -302,7 +304,21 @@ class Renderer final : public RendererBase {
     }
 
     // post-processing / caching stages are outside the hot path (OUT OF SCOPE)
-    void DenoiseImage(const RegionContext &) override { log_->Warning("RendererHIP: NLM denoiser is not implemented"); }
+    // NLM denoiser (RendererCPU.h:661-783): filters what the iterations so far accumulated, with the camera (tonemap, adaptive
+    // sampling threshold) of the last RenderScene, as the reference does through tonemap_params_ / variance_threshold_
+    void DenoiseImage(const RegionContext &region) override {
+        Flush();
+        if (!have_cam_) {
+            log_->Error("RendererHIP: DenoiseImage before the first RenderScene");
+            return;
+        }
+        const rect_t &r = region.rect();
+        const int rect[4] = {r.x, r.y, r.w, r.h};
+        check(rayhip_denoise_nlm(ctx_, &pending_cam_, rect, region.iteration), "rayhip_denoise_nlm");
+        for (bool &d : host_dirty_) {
+            d = true;
+        }
+    }
     void DenoiseImage(int, const RegionContext &) override { log_->Warning("RendererHIP: UNet denoiser is not implemented"); }
     void UpdateSpatialCache(const SceneBase &, RegionContext &) override {}
     void ResolveSpatialCache(const SceneBase &, const std::function<void(int, int, ParallelForFunction &&)> &) override {}

@@ -206,6 +206,7 @@ ray_scene *ray_renderer_create_scene(ray_renderer *r) {
     return out.release();
 }
 void ray_renderer_render(ray_renderer *r, ray_scene *s, ray_region *region) { r->r->RenderScene(*s->s, region->ctx); }
+void ray_renderer_denoise(ray_renderer *r, ray_region *region) { r->r->DenoiseImage(region->ctx); }
 int ray_renderer_get_pixels(ray_renderer *r, int which, float *dst) {
     Ray::color_data_rgba_t px = {};
     switch (which) {

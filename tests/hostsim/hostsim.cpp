@@ -21,6 +21,7 @@
 #include "../../ray_amd/csrc/bvh4_build.h"
 #include "../../ray_amd/csrc/bvh_layout.h"
 #include "../../ray_amd/csrc/rt_arealights.h"
+#include "../../ray_amd/csrc/rt_denoise.h"
 #include "../../ray_amd/csrc/rt_params.h"
 #include "../../ray_amd/csrc/rt_pixel.h"
 #include "../../ray_amd/csrc/scene_blob.h"
@@ -394,6 +395,48 @@ HS_API int hostsim_render_batch(hostsim_ctx *c, const rayhip_camera *cam, const 
 
 HS_API int hostsim_max_batch(hostsim_ctx *) { return 64; }
 HS_API int hostsim_reserve_batch(hostsim_ctx *, int) { return 0; }
+// RendererBase::DenoiseImage(region) with the host build of rt_denoise.h (the variance estimate lives in c->temp, as in
+// the reference)
+HS_API int hostsim_denoise_nlm(hostsim_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration) {
+    if (cam->view_transform != 0 && cam->view_transform != c->lut_transform) {
+        g_err = "view transform needs its look-up table";
+        return 1;
+    }
+    DenoiseParams p;
+    p.w = c->w, p.h = c->h;
+    for (int i = 0; i < 4; ++i) {
+        p.rect[i] = rect[i];
+    }
+    p.ext_w = rect[2] + 2 * NLM_EXT_RADIUS, p.ext_h = rect[3] + 2 * NLM_EXT_RADIUS;
+    p.iteration = iteration;
+    AccumParams tone = make_accum_params(*cam, c->w, rect, iteration, c->shard);
+    tone.lut = c->tonemap_lut.data(), tone.lut_dims = c->lut_dims;
+    p.variance_threshold = tone.variance_threshold;
+    const float4 z = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+    std::vector<float4> tm(size_t(p.ext_w) * p.ext_h, z), var_h(tm.size(), z), var(tm.size(), z);
+    for (int y = 0; y < p.ext_h; ++y) {
+        for (int x = 0; x < p.ext_w; ++x) {
+            nlm_prepare_h(p, x, y, c->full.data(), c->temp.data(), tm.data(), var_h.data());
+        }
+    }
+    for (int y = 4; y < p.ext_h - 4; ++y) {
+        for (int x = 4; x < p.ext_w - 4; ++x) {
+            nlm_prepare_v(p, x, y, var_h.data(), var.data());
+        }
+    }
+    for (int y = 0; y < rect[3]; ++y) {
+        for (int x = 0; x < rect[2]; ++x) {
+            const f4 nlm = nlm_filter_pixel(p, x, y, c->base_color.data(), c->depth_normals.data(), [&](const int ex, const int ey, const int which) {
+                return ld4((which ? var : tm)[size_t(ey) * p.ext_w + ex]);
+            });
+            const int idx = (rect[1] + y) * c->w + (rect[0] + x);
+            nlm_finish_pixel(p, tone, idx, ld4(var[size_t(NLM_EXT_RADIUS + y) * p.ext_w + (NLM_EXT_RADIUS + x)]), nlm, c->raw.data(),
+                             c->final_.data(), c->required_samples.data());
+        }
+    }
+    return 0;
+}
+
 HS_API int hostsim_set_shard(hostsim_ctx *c, int tile, int shard_count, int shard_index) {
     c->shard = Shard{tile, shard_count, shard_index};
     return 0;

@@ -341,6 +341,40 @@ def test_camera_features_match_the_host_build(gpu_lib, hostsim_lib, cam):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
 
 
+@pytest.mark.parametrize("name", ["cornell_lights", "cornell_filmic"])
+def test_nlm_denoise_matches_the_host_build(gpu_lib, hostsim_lib, name):
+    """RendererBase::DenoiseImage(region) (rt_denoise.h; host build == reference, tests/test_hostsim_parity.py): the GPU's
+    filtered RAW / FINAL images against the host build's, full frame and a sub-rect, batched render in front of it; and
+    through RendererHIP (DenoiseImage forces the pending iterations out first)"""
+    import os
+    from ray_amd import api, scenes
+    w, h, spp = 64, 64, 6
+    outs = []
+    for lib in (hostsim_lib, gpu_lib):
+        ctx = util.make_context(lib, name, w, h)
+        if lib is gpu_lib:
+            ctx.render_batch(1, spp)
+        else:
+            util.render_frames(ctx, spp)
+        ctx.denoise_nlm(spp)
+        full = (ctx.readback(hip.BUF_RAW), ctx.readback(hip.BUF_FINAL))
+        ctx.denoise_nlm(spp, rect=(8, 12, 40, 30))  # (filters the already filtered frame again inside the rect: fine for a comparison)
+        outs.append(full + (ctx.readback(hip.BUF_RAW),))
+    for a, b in zip(outs[1], outs[0]):
+        m = util.frame_metrics(a, b)
+        assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
+    if os.path.exists(api.HIP_HOST_LIB):
+        r = api.CreateRenderer(api.Settings(w, h), "HIP")
+        s = r.CreateScene()
+        scenes.SCENES[name](s)
+        region = api.RegionContext((0, 0, w, h))
+        for _ in range(spp):
+            r.RenderScene(s, region)
+        r.DenoiseImage(region)
+        assert np.array_equal(r.get_raw_pixels_ref(), outs[1][0])
+        assert np.array_equal(r.get_pixels_ref(), outs[1][1])
+
+
 @pytest.mark.parametrize("scene", ["cornell_portals", "cornell_textures", "cornell_principled_zoo"])
 def test_live_only_scenes_match_the_host_build(gpu_lib, hostsim_lib, scene):
     """scenes whose parity with the reference is established on the host build against the live reference

@@ -126,6 +126,38 @@ def test_camera_features_against_live_reference(lib, cam):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,cam", [("cornell_basic", {}), ("cornell_lights", {}), ("cornell_filmic", {}),
+                                      ("cornell_basic", dict(min_samples=2, variance_threshold=0.02))])
+def test_nlm_denoise_against_live_reference(lib, name, cam):
+    """RendererBase::DenoiseImage(region) (SURVEY 8f, N2): variance pre-filter + joint NLM + tonemap, on the full frame and
+    on a sub-rect (the extended region then reaches into rendered pixels instead of clamping), with adaptive sampling
+    (the filter re-arms required_samples) and with a look-up-table view transform"""
+    from ray_amd import api, scenes
+
+    w, h, spp = 72, 56, 6
+    r, s = O.render_ref(scenes.SCENES[name], w, h, spp, **cam)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    util.render_frames(ctx, spp)
+    noisy = ctx.readback(hip.BUF_RAW)
+    for rect in ((0, 0, w, h), (10, 6, 40, 30)):
+        region = api.RegionContext(rect)
+        region._bind(O.ref_lib())
+        region.iteration = spp  # what RenderScene calls on this region would have left
+        r.DenoiseImage(region)
+        ctx.denoise_nlm(spp, rect=rect)
+        assert np.array_equal(ctx.readback(hip.BUF_RAW), r.get_raw_pixels_ref()), rect
+        assert np.array_equal(ctx.readback(hip.BUF_FINAL), r.get_pixels_ref()), rect
+    assert not np.array_equal(noisy, ctx.readback(hip.BUF_RAW))
+    # the adaptive-sampling flags the filter left behind steer the next iteration: render one more on both sides
+    region = api.RegionContext((0, 0, w, h))
+    region._bind(O.ref_lib())
+    region.iteration = spp
+    r.RenderScene(s, region)
+    ctx.render(spp + 1)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), r.get_raw_pixels_ref())
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_light_flags_against_live_reference(lib):
     """light_desc flags the fixtures leave at their defaults: cast_shadow, diffuse / specular / refraction visibility,
     multiple_importance (SceneBase.h light descriptors -> light_t flag bits)"""
