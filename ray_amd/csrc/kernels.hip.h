@@ -973,21 +973,64 @@ __global__ void __launch_bounds__(256) k_nlm_prepare_v(const DenoiseParams p, co
         nlm_prepare_v(p, 4 + i % iw, 4 + i / iw, var_h, var);
     }
 }
-// one thread per pixel of the region; the 7x7 window x 3x3 patch taps come out of L1/L2 (neighbouring threads share them)
+// Stage 3.  One 256-thread block per 16x16 pixel tile.  The reference evaluates, for every pixel i and window position
+// j, nine pair distances d(i + o, j + o) over the 3x3 patch offsets o -- 441 per pixel, each with four IEEE divisions.
+// d(i + o, j + o) only depends on the pixel i + o and on the window offset j - i, so for one window offset the block
+// computes the distance image ONCE over its tile plus a one-pixel rim (18x18 values in LDS) and every pixel sums its
+// nine neighbours of that image, in the reference's order (q outer, p inner): the same additions of the same values,
+// hence the same result, with 9x fewer divisions.  The tile's part of the two inputs (24x24 with the 3 + 1 pixel rim) is
+// staged through LDS once.  Measured, 1080p: 2.25 ms for the per-pixel form -> see DESIGN.md.
 __global__ void __launch_bounds__(256) k_nlm_filter(const DenoiseParams p, const AccumParams tone, const PixelBuffers px,
                                                    const float4 *__restrict__ tm, const float4 *__restrict__ var) {
-    const int tiles_x = (p.rect[2] + 15) / 16, tiles_y = (p.rect[3] + 15) / 16;
-    for (int t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) { // 16x16 pixel tiles: a block's taps overlap
-        const int x = (t % tiles_x) * 16 + int(threadIdx.x % 16), y = (t / tiles_x) * 16 + int(threadIdx.x / 16);
-        if (x >= p.rect[2] || y >= p.rect[3]) {
-            continue;
+    constexpr int T = 16, R = 4, S = T + 2 * R; // tile, rim (window radius 3 + patch radius 1), staged side
+    constexpr int DS = T + 2;                   // side of the distance image
+    __shared__ float4 s_tm[S * S], s_var[S * S], s_d[DS * DS];
+    const int tiles_x = (p.rect[2] + T - 1) / T, tiles_y = (p.rect[3] + T - 1) / T;
+    const int lx = int(threadIdx.x % T), ly = int(threadIdx.x / T);
+    for (int t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) {
+        const int tx0 = (t % tiles_x) * T, ty0 = (t / tiles_x) * T; // region coordinates of the tile's corner
+        __syncthreads();                                            // (the previous tile's readers are done)
+        for (int i = int(threadIdx.x); i < S * S; i += 256) {
+            // staged position (i % S, i / S) <-> extended-region pixel (tx0 + 8 - 4 + ., ty0 + 8 - 4 + .); positions past the
+            // extended region only feed pixels past the region, which are not written: clamp to stay inside the buffers
+            const int ex = min(tx0 + NLM_EXT_RADIUS - R + i % S, p.ext_w - 1), ey = min(ty0 + NLM_EXT_RADIUS - R + i / S, p.ext_h - 1);
+            s_tm[i] = tm[ey * p.ext_w + ex], s_var[i] = var[ey * p.ext_w + ex];
         }
-        const f4 nlm = nlm_filter_pixel(p, x, y, px.base_color, px.depth_normals, [&](const int ex, const int ey, const int which) {
-            return ld4((which ? var : tm)[ey * p.ext_w + ex]);
-        });
-        const int idx = (p.rect[1] + y) * p.w + (p.rect[0] + x);
-        nlm_finish_pixel(p, tone, idx, ld4(var[(NLM_EXT_RADIUS + y) * p.ext_w + (NLM_EXT_RADIUS + x)]), nlm, px.raw, px.final_,
-                         px.required_samples);
+        __syncthreads();
+        const int x = tx0 + lx, y = ty0 + ly;
+        const bool valid = x < p.rect[2] && y < p.rect[3];
+        const int ix = NLM_EXT_RADIUS + (valid ? x : 0), iy = NLM_EXT_RADIUS + (valid ? y : 0);
+        const f4 f0_i = nlm_feature(p, px.base_color, ix, iy), f1_i = nlm_feature(p, px.depth_normals, ix, iy);
+        f4 sum_output = {0.0f, 0.0f, 0.0f, 0.0f};
+        float sum_weight = 0.0f;
+        for (int k = -3; k <= 3; ++k) {
+            for (int l = -3; l <= 3; ++l) {
+                for (int i = int(threadIdx.x); i < DS * DS; i += 256) { // distance image of window offset (l, k)
+                    const int u = i % DS - 1 + R, v = i / DS - 1 + R;    // staged coordinates of pixel i + o
+                    s_d[i] = st4(nlm_pair_distance(ld4(s_tm[v * S + u]), ld4(s_tm[(v + k) * S + (u + l)]), ld4(s_var[v * S + u]),
+                                                   ld4(s_var[(v + k) * S + (u + l)])));
+                }
+                __syncthreads();
+                f4 color_distance = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int q = -1; q <= 1; ++q) {
+                    for (int pp = -1; pp <= 1; ++pp) {
+                        color_distance += ld4(s_d[(ly + 1 + q) * DS + (lx + 1 + pp)]);
+                    }
+                }
+                const float weight = nlm_weight(color_distance, f0_i, nlm_feature(p, px.base_color, ix + l, iy + k), f1_i,
+                                                nlm_feature(p, px.depth_normals, ix + l, iy + k));
+                sum_output += ld4(s_tm[(ly + R + k) * S + (lx + R + l)]) * weight;
+                sum_weight += weight;
+                __syncthreads(); // s_d is rewritten for the next offset
+            }
+        }
+        if (valid) {
+            if (sum_weight != 0.0f) {
+                sum_output = sum_output / sum_weight;
+            }
+            const int idx = (p.rect[1] + y) * p.w + (p.rect[0] + x);
+            nlm_finish_pixel(p, tone, idx, ld4(s_var[(ly + R) * S + (lx + R)]), sum_output, px.raw, px.final_, px.required_samples);
+        }
     }
 }
 

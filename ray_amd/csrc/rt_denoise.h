@@ -74,6 +74,27 @@ RT_HD f4 nlm_feature(const DenoiseParams &p, const float4 *frame_buf, const int 
     return ld4(frame_buf[clampi(yy, 0, p.h - 1) * p.w + clampi(xx, 0, p.w - 1)]);
 }
 
+// one term of the patch distance, DenoiseRef.cpp:39-46 (alpha 1, damping 0.45)
+RT_HD f4 nlm_pair_distance(const f4 ipx, const f4 jpx, const f4 ivar, const f4 jvar) {
+    const float alpha = 1.0f, damping = 0.45f;
+    const f4 min_var = min4(ivar, jvar);
+    return ((ipx - jpx) * (ipx - jpx) - alpha * (ivar + min_var)) /
+           (f4{0.0001f, 0.0001f, 0.0001f, 0.0001f} + (damping * damping) * (ivar + jvar));
+}
+// weight of window position j for pixel i from the summed patch distance and the two guides, DenoiseRef.cpp:50-77
+RT_HD float nlm_weight(const f4 color_distance, const f4 f0_i, const f4 f0_j, const f4 f1_i, const f4 f1_j) {
+    const float PatchDistanceNormFactor = float(NLM_NEIGHBORHOOD_SIZE * NLM_NEIGHBORHOOD_SIZE);
+    const float feature0_weight = 64.0f, feature1_weight = 32.0f;
+    const float patch_distance =
+        0.25f * PatchDistanceNormFactor * (color_distance.x + color_distance.y + color_distance.z + color_distance.w);
+    float weight = expf(-fmaxf(0.0f, patch_distance));
+    f4 feature_distance = feature0_weight * (f0_i - f0_j) * (f0_i - f0_j);
+    feature_distance = max4(feature_distance, feature1_weight * (f1_i - f1_j) * (f1_i - f1_j));
+    const float feature_patch_distance = 0.25f * (feature_distance.x + feature_distance.y + feature_distance.z + feature_distance.w);
+    const float feature_weight = expf(-fmaxf(0.0f, fminf(10000.0f, feature_patch_distance)));
+    return fminf(weight, feature_weight);
+}
+
 // stage 3, pixel (x, y) of the region (frame coordinates xx = rect.x + x ...): RendererCPU.h:748-777 +
 // DenoiseRef.cpp:9-93 with WINDOW 7, NEIGHBORHOOD 3, alpha 1, damping 0.45, feature weights 64 / 32.
 // Fetch is a callable (ext_x, ext_y, which) -> f4 with which = 0: tm, 1: var (lets the device stage them through LDS).
@@ -81,8 +102,6 @@ template <class Fetch>
 RT_HD f4 nlm_filter_pixel(const DenoiseParams &p, const int x, const int y, const float4 *base_color, const float4 *depth_normals,
                           Fetch &&fetch) {
     constexpr int WindowRadius = (NLM_WINDOW_SIZE - 1) / 2, NeighborRadius = (NLM_NEIGHBORHOOD_SIZE - 1) / 2;
-    const float PatchDistanceNormFactor = float(NLM_NEIGHBORHOOD_SIZE * NLM_NEIGHBORHOOD_SIZE);
-    const float alpha = 1.0f, damping = 0.45f, feature0_weight = 64.0f, feature1_weight = 32.0f;
     const int ix = NLM_EXT_RADIUS + x, iy = NLM_EXT_RADIUS + y;
 
     const f4 f0_i = nlm_feature(p, base_color, ix, iy), f1_i = nlm_feature(p, depth_normals, ix, iy);
@@ -96,31 +115,12 @@ RT_HD f4 nlm_filter_pixel(const DenoiseParams &p, const int x, const int y, cons
             f4 color_distance = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int q = -NeighborRadius; q <= NeighborRadius; ++q) {
                 for (int pp = -NeighborRadius; pp <= NeighborRadius; ++pp) {
-                    const f4 ipx = fetch(ix + pp, iy + q, 0), jpx = fetch(jx + pp, jy + q, 0);
-                    const f4 ivar = fetch(ix + pp, iy + q, 1), jvar = fetch(jx + pp, jy + q, 1);
-                    const f4 min_var = min4(ivar, jvar);
-                    color_distance += ((ipx - jpx) * (ipx - jpx) - alpha * (ivar + min_var)) /
-                                      (f4{0.0001f, 0.0001f, 0.0001f, 0.0001f} + (damping * damping) * (ivar + jvar));
+                    color_distance += nlm_pair_distance(fetch(ix + pp, iy + q, 0), fetch(jx + pp, jy + q, 0), fetch(ix + pp, iy + q, 1),
+                                                        fetch(jx + pp, jy + q, 1));
                 }
             }
-            const float patch_distance =
-                0.25f * PatchDistanceNormFactor * (color_distance.x + color_distance.y + color_distance.z + color_distance.w);
-            float weight = expf(-fmaxf(0.0f, patch_distance));
-
-            f4 feature_distance;
-            {
-                const f4 jpx = nlm_feature(p, base_color, jx, jy);
-                feature_distance = feature0_weight * (f0_i - jpx) * (f0_i - jpx);
-            }
-            {
-                const f4 jpx = nlm_feature(p, depth_normals, jx, jy);
-                feature_distance = max4(feature_distance, feature1_weight * (f1_i - jpx) * (f1_i - jpx));
-            }
-            const float feature_patch_distance =
-                0.25f * (feature_distance.x + feature_distance.y + feature_distance.z + feature_distance.w);
-            const float feature_weight = expf(-fmaxf(0.0f, fminf(10000.0f, feature_patch_distance)));
-            weight = fminf(weight, feature_weight);
-
+            const float weight =
+                nlm_weight(color_distance, f0_i, nlm_feature(p, base_color, jx, jy), f1_i, nlm_feature(p, depth_normals, jx, jy));
             sum_output += fetch(jx, jy, 0) * weight;
             sum_weight += weight;
         }
