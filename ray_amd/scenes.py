@@ -290,6 +290,23 @@ def cornell_principled_zoo(scene, **cam_overrides):
     scene.Finalize()
 
 
+def empty_scene(scene, **cam_overrides):
+    """no geometry at all (no TLAS): every ray leaves into the background"""
+    scene.SetEnvironment(env_col=(0.3, 0.4, 0.5), back_col=(0.1, 0.2, 0.3))
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
+def lights_only_scene(scene, **cam_overrides):
+    """analytic lights and a background, but no geometry (primary rays never see analytic lights: IntersectAreaLights runs
+    on secondary rays only)"""
+    scene.SetEnvironment(env_col=(0.02, 0.02, 0.03), back_col=(0.05, 0.05, 0.08))
+    scene.AddLight("sphere", color=(6.0, 5.0, 4.0), position=(-0.28, 0.27, -0.3), radius=0.08)
+    scene.AddLight("directional", color=(1.0, 1.0, 1.0), direction=(0.0, -1.0, -0.2), angle=2.0)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
 def cornell_portals(scene, **cam_overrides):
     """cornell_env's open box under the RGBE sky, with the opening covered by sky portals -- a rectangular and a disk
     light with sky_portal = true (SceneBase.h rect/disk_light_desc_t): SampleLightSource takes their colour from the

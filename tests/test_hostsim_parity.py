@@ -158,6 +158,19 @@ def test_nlm_denoise_against_live_reference(lib, name, cam):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("scene", ["empty_scene", "lights_only_scene"])
+def test_degenerate_scenes_against_live_reference(lib, scene):
+    """no geometry (no TLAS, empty BVH / triangle / vertex arrays), with and without lights"""
+    from ray_amd import scenes
+
+    w, h, spp = 48, 32, 3
+    r, s = O.render_ref(getattr(scenes, scene), w, h, spp)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    assert float(np.abs(r.get_raw_pixels_ref()).max()) > 0.0
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_light_flags_against_live_reference(lib):
     """light_desc flags the fixtures leave at their defaults: cast_shadow, diffuse / specular / refraction visibility,
     multiple_importance (SceneBase.h light descriptors -> light_t flag bits)"""
