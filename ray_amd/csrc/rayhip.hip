@@ -77,6 +77,7 @@ struct rayhip_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t props = {};
     int grid_waves = 0; // resident-ish grid for the wave-per-block kernels
+    bool small_scene = false; // BLAS nodes + triangles fit one XCD's L2: traversal kernels with the smaller register footprint
     int refill_waves = 0; // exactly-resident grid of the persistent closest-hit kernel; 0 = kernel switched off
 
     DevBuf pmj, filter_table;
@@ -555,6 +556,10 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
                 }
                 HIP_TRY(hipStreamSynchronize(c->stream)); // b4 goes out of scope
                 have_wide = true;
+                // "small": the BLAS working set (nodes + triangle records) fits one XCD's 4 MB L2 with room to spare
+                const size_t n_tris = lay.applied ? lay.tris.size() : size_t(d->tris_count);
+                c->small_scene = getenv("RAYHIP_NO_SMALL") == nullptr &&
+                                 b4.nodes.size() * sizeof(Bvh4Node) + n_tris * sizeof(rayhip_tri_accel) <= (size_t(2) << 20);
             }
         }
     }
@@ -782,6 +787,8 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else if (c->sc.nodes4 && c->refill_waves) {
             k_trace_closest_refill<<<std::min(gtrace, c->refill_waves), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
+        } else if (c->sc.nodes4 && c->small_scene) {
+            k_trace_closest<false, true, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else if (c->sc.nodes4) {
             k_trace_closest<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else {
@@ -863,6 +870,9 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         if (count) {
             k_trace_shadow<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
                                                                 vw, c->px.temp, nullptr, spill, tc + 5, layers);
+        } else if (c->sc.nodes4 && c->small_scene) {
+            k_trace_shadow<false, true, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes),
+                                                                                      limit, vw, c->px.temp, nullptr, spill, tc + 5, layers);
         } else if (c->sc.nodes4) {
             k_trace_shadow<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
                                                                 vw, c->px.temp, nullptr, spill, tc + 5, layers);
