@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -481,13 +482,16 @@ int rayhip_clear(rayhip_ctx *c, const float rgba[4]) {
 
 #define UPLOAD_TRACE(msg)                                                                                              \
     if (getenv("RAYHIP_TRACE_UPLOAD")) {                                                                               \
-        fprintf(stderr, "rayhip_scene_upload: %s\n", msg);                                                             \
+        fprintf(stderr, "rayhip_scene_upload: %8.1f ms  %s\n",                                                         \
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - upload_t0).count(), msg);  \
     }
 
 int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     if (use_device(c)) {
         return 1;
     }
+    const auto upload_t0 = std::chrono::steady_clock::now();
+    (void)upload_t0;
     UPLOAD_TRACE("begin")
     const rayhip_layout::AlignedDesc aligned(*d_in); // see bvh_layout.h
     const rayhip_scene_desc *d = &aligned.d;
@@ -564,6 +568,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         }
     }
     UPLOAD_TRACE(have_wide ? "bvh4 built" : "no bvh4")
+    UPLOAD_TRACE("bvh uploaded")
     UP(tri_materials)
     UP(materials)
     UP(vertices)
@@ -579,6 +584,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         if (upload(c, c->light_children, lc.data(), lc.size() * sizeof(float4))) {
             return 1;
         }
+        UPLOAD_TRACE("light_children done")
         { // vertices gathered per triangle (rt_shade.h: fill_tri_verts)
             const uint32_t n_tris = d->vtx_indices_count / 3;
             std::vector<float4> tv(size_t(n_tris) * TRI_VERTS_STRIDE);
@@ -590,6 +596,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             }
             HIP_TRY(hipStreamSynchronize(c->stream)); // `tv` goes out of scope
         }
+        UPLOAD_TRACE("tri_verts done")
         // world-space corners of the TRI lights (rt_lights.h: fill_light_tri_geom)
         // (the light array is a sparse pool: only the slots li_indices[] names hold lights)
         std::vector<float4> tg(size_t(d->lights_count) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
