@@ -136,6 +136,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner with the C library's printf (block-buffered
+    # when piped, so it would land after anything Python printed): point file descriptor 1 at stderr for the duration of
+    # the run and restore it on rank 0 for the JSON line only.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,7 +156,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # RAY_AMD_FORCE_DIST=1: run the N > 1 code path (process group, frame reduce over RCCL, re-tonemap) with one rank
+    force_dist = world == 1 and os.environ.get("RAY_AMD_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -170,7 +182,7 @@ def main():
     cam = ctx.upload_scene_blob(blob)
     del blob
     ctx.set_shard(TILE, world, rank)
-    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") if world > 1 else None
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") if dist is not None else None
 
     batch = int(os.environ.get("RAY_AMD_BATCH", "0")) or multigpu.batch_size(W * H // world, ctx.max_batch(), K)
     ctx.reserve_batch(batch)  # (the shard is set: a rank's buffers are sized for its share of the frame)
@@ -181,7 +193,7 @@ def main():
             n = min(batch, Wm - done)
             ctx.render_batch(it + 1, n)
             it, done = it + n, done + n
-    if world > 1:  # warm the communicator too
+    if dist is not None:  # warm the communicator too
         ctx.readback_device(hip.BUF_RAW, frame.data_ptr())
         dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
     ctx.sync()
@@ -199,7 +211,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -218,7 +230,7 @@ def main():
     k2_bytes = ((72 + 20 + 4) * c2["rays"] + 64 * c2["nodes"] + 48 * c2["tris"] + 144 * c2["instances"]) * scale
     k3_bytes = ((48 + 32) * c3["rays"] + 64 * c3["nodes"] + 48 * c3["tris"] + 144 * c3["instances"]) * scale
 
-    if world > 1:  # whole-job traversal figures: sum over ranks
+    if dist is not None:  # whole-job traversal figures: sum over ranks
         v = torch.tensor([k2_bytes, k2_ms, k2_launches, k3_bytes, k3_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
         vmax = v.clone()
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
@@ -272,10 +284,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # everything the libraries wrote to "stdout" went to stderr (see main's prologue); the real stdout gets the one line
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

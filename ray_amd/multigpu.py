@@ -50,8 +50,8 @@ def render_sharded(ctx: hip.Context, iterations: Iterable[int], rank: int, world
         n = min(batch, len(its) - done)
         ctx.render_batch(its[done], n, flags=flags)
         done += n
-    if world <= 1 or dist is None:
-        return None
+    if dist is None or (world <= 1 and frame is None):
+        return None  # (world == 1 with a frame: the exchange step is still run -- a one-rank reduce -- for testing)
     if frame.is_cuda:
         ctx.readback_device(hip.BUF_RAW, frame.data_ptr())
     else:
