@@ -46,3 +46,18 @@ def test_no_device_no_render(lib):
     assert b"" != lib.lib.rayhip_last_error()
     with pytest.raises(Exception):
         hip.Context(0, lib)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py is the product path: no device -> a loud exit, nothing on stdout (the contract's one JSON line is only
+    ever printed after a measured run)"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "needs a GPU" in r.stderr
