@@ -199,6 +199,33 @@ def test_sharded_batches_walk_owned_tiles_only(gpu_lib, w, h, tile, n):
     assert np.array_equal(acc, full)
 
 
+@pytest.mark.parametrize("name", ["cornell_lights", "cornell_instances"])
+def test_ray_sort_is_bit_identical(gpu_lib, name):
+    """SURVEY a10 (SortRays: key = direction octant | Morton code of the origin cell, radix sort, gather): opt-in through
+    RAYHIP_FLAG_SORT_RAYS; ray order must not change a pixel -- full frame, a rect, and on a rank of a sharded frame"""
+    w, h = 96, 72
+    plain = util.make_context(gpu_lib, name, w, h)
+    sorted_ = util.make_context(gpu_lib, name, w, h)
+    for it in range(1, 5):
+        plain.render(it)
+        sorted_.render(it, flags=hip.FLAG_SORT_RAYS)
+    plain.render(5, rect=(8, 8, 64, 40))
+    sorted_.render(5, rect=(8, 8, 64, 40), flags=hip.FLAG_SORT_RAYS)
+    for buf in (hip.BUF_RAW, hip.BUF_FINAL, hip.BUF_BASE_COLOR, hip.BUF_DEPTH_NORMALS):
+        assert np.array_equal(plain.readback(buf), sorted_.readback(buf)), buf
+    a = util.make_context(gpu_lib, name, w, h)
+    b = util.make_context(gpu_lib, name, w, h)
+    a.set_shard(32, 3, 1), b.set_shard(32, 3, 1)
+    for it in range(1, 4):
+        a.render(it)
+        b.render(it, flags=hip.FLAG_SORT_RAYS)
+    assert np.array_equal(a.readback(hip.BUF_RAW), b.readback(hip.BUF_RAW))
+    b.render_batch(4, 3, flags=hip.FLAG_SORT_RAYS)  # (a batch with the sort flag falls back to one pass per iteration)
+    for it in range(4, 7):
+        a.render(it)
+    assert np.array_equal(a.readback(hip.BUF_RAW), b.readback(hip.BUF_RAW))
+
+
 def test_rect_render(gpu_lib):
     """RegionContext rect: rendering two half-frame rects == rendering the full frame"""
     name = "cornell_basic"
