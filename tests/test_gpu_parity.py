@@ -452,6 +452,51 @@ def test_compressed_textures_through_the_ray_api(gpu_lib, hostsim_lib):
     assert not np.array_equal(imgs[1], imgs[2]), "compression did not change a texel: not exercised"
 
 
+def test_renderer_hip_clear_resize_stats(gpu_lib, hostsim_lib):
+    """RendererHIP::Clear / Resize / GetStats / ResetStats behind the Ray API (with iterations pending in the batch queue
+    when they are called): pixels against the host build (which equals the reference on this sequence,
+    tests/test_hostsim_parity.py::test_clear_and_resize_against_live_reference)"""
+    import os
+    from ray_amd import api, scenes
+    if not os.path.exists(api.HIP_HOST_LIB):
+        pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
+    name, w, h = "cornell_basic", 56, 40
+    r = api.CreateRenderer(api.Settings(w, h), "HIP")
+    s = r.CreateScene()
+    scenes.SCENES[name](s)
+    ctx = hip.Context(0, hostsim_lib)
+    ctx.upload_static(util.pmj())
+    ctx.resize(w, h)
+    ctx.upload_scene_blob(api.export_scene_blob(s))
+    region = api.RegionContext((0, 0, w, h))
+    for it in (1, 2, 3):
+        r.RenderScene(s, region)  # (left pending)
+        ctx.render(it)
+    r.Clear((0.25, 0.5, 0.75, 1.0))
+    ctx.clear((0.25, 0.5, 0.75, 1.0))
+    region = api.RegionContext((0, 0, w, h))
+    for it in (1, 2):
+        r.RenderScene(s, region)
+        ctx.render(it)
+    m = util.frame_metrics(r.get_raw_pixels_ref(), ctx.readback(hip.BUF_RAW))
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
+    st = r.GetStats()
+    assert st["primary_trace"] > 0 and st["secondary_shade"] > 0, st
+    r.ResetStats()
+    assert sum(r.GetStats().values()) == 0
+    w2, h2 = 72, 48
+    r.Resize(w2, h2)
+    ctx.resize(w2, h2)
+    assert r.size() == (w2, h2)
+    region = api.RegionContext((0, 0, w2, h2))
+    for it in (1, 2, 3):
+        r.RenderScene(s, region)
+        ctx.render(it)
+    m = util.frame_metrics(r.get_raw_pixels_ref(), ctx.readback(hip.BUF_RAW))
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
+    assert r.get_pixels_ref().shape == (h2, w2, 4)
+
+
 @pytest.mark.parametrize("name", ["cornell_lights", "cornell_filmic"])
 def test_renderer_hip_through_the_ray_api(gpu_lib, name):
     """the drop-in itself: Ray::CreateRenderer(HIP) -> SceneHIP mutators -> RenderScene x N -> get_*_pixels_ref.  The live

@@ -158,6 +158,36 @@ def test_nlm_denoise_against_live_reference(lib, name, cam):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_clear_and_resize_against_live_reference(lib):
+    """RendererBase::Clear (full / half <- colour, required_samples re-armed; RendererCPU.h:297-301) and Resize followed by
+    more iterations"""
+    from ray_amd import api, scenes
+
+    w, h = 56, 40
+    r, s = O.render_ref(scenes.cornell_basic, w, h, 3)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    util.render_frames(ctx, 3)
+    r.Clear((0.25, 0.5, 0.75, 1.0))
+    ctx.clear((0.25, 0.5, 0.75, 1.0))
+    region = api.RegionContext((0, 0, w, h))  # a cleared region: iterations restart at 1
+    for it in (1, 2):
+        r.RenderScene(s, region)
+        ctx.render(it)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), r.get_pixels_ref())
+    w2, h2 = 72, 48
+    r.Resize(w2, h2)
+    ctx.resize(w2, h2)
+    assert r.size() == (w2, h2)
+    region = api.RegionContext((0, 0, w2, h2))
+    for it in (1, 2, 3):
+        r.RenderScene(s, region)
+        ctx.render(it)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("scene", ["empty_scene", "lights_only_scene"])
 def test_degenerate_scenes_against_live_reference(lib, scene):
     """no geometry (no TLAS, empty BVH / triangle / vertex arrays), with and without lights"""
