@@ -232,6 +232,9 @@ def declare(lib):
         "ray_scene_add_mesh": (ray_handle, [vp, C.POINTER(MeshDesc)]),
         "ray_scene_add_mesh_instance": (ray_handle, [vp, ray_handle, C.POINTER(C.c_float * 16)]),
         "ray_scene_add_mesh_instance_vis": (ray_handle, [vp, ray_handle, C.POINTER(C.c_float * 16), C.c_uint]),
+        "ray_scene_set_mesh_instance_transform": (None, [vp, ray_handle, C.POINTER(C.c_float * 16)]),
+        "ray_scene_remove_mesh_instance": (None, [vp, ray_handle]),
+        "ray_scene_remove_light": (None, [vp, ray_handle]),
         "ray_scene_add_light": (ray_handle, [vp, C.POINTER(LightDesc)]),
         "ray_scene_add_camera": (ray_handle, [vp, C.POINTER(CameraDesc)]),
         "ray_scene_set_current_cam": (None, [vp, ray_handle]),

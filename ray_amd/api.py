@@ -204,6 +204,16 @@ class SceneBase:
             return int(self._lib.ray_scene_add_mesh_instance(self._ptr, mesh, C.byref(m)))
         return int(self._lib.ray_scene_add_mesh_instance_vis(self._ptr, mesh, C.byref(m), vis))
 
+    def SetMeshInstanceTransform(self, mi: int, xform):
+        m = (C.c_float * 16)(*np.asarray(xform, np.float32).ravel())
+        self._lib.ray_scene_set_mesh_instance_transform(self._ptr, mi, C.byref(m))
+
+    def RemoveMeshInstance(self, mi: int):
+        self._lib.ray_scene_remove_mesh_instance(self._ptr, mi)
+
+    def RemoveLight(self, light: int):
+        self._lib.ray_scene_remove_light(self._ptr, light)
+
     def AddLight(self, kind: str, **kw) -> int:
         """kind: 'directional' | 'sphere' | 'spot' | 'rect' | 'disk' | 'line' (the six AddLight overloads)."""
         kinds = {"directional": 0, "sphere": 1, "spot": 2, "rect": 3, "disk": 4, "line": 5}

@@ -385,6 +385,12 @@ ray_handle ray_scene_add_mesh_instance_vis(ray_scene *s, ray_handle mesh, const 
     return from_handle(s->s->AddMeshInstance(mi));
 }
 
+void ray_scene_set_mesh_instance_transform(ray_scene *s, ray_handle mi, const float xform[16]) {
+    s->s->SetMeshInstanceTransform(to_handle<Ray::MeshInstanceHandle>(mi), xform);
+}
+void ray_scene_remove_mesh_instance(ray_scene *s, ray_handle mi) { s->s->RemoveMeshInstance(to_handle<Ray::MeshInstanceHandle>(mi)); }
+void ray_scene_remove_light(ray_scene *s, ray_handle light) { s->s->RemoveLight(to_handle<Ray::LightHandle>(light)); }
+
 ray_handle ray_scene_add_light(ray_scene *s, const ray_light_desc *d) {
 #define COMMON(l)                                                                                                      \
     memcpy(l.color, d->color, 12);                                                                                     \

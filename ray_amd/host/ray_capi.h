@@ -192,6 +192,9 @@ ray_handle ray_scene_add_mesh_instance(ray_scene *s, ray_handle mesh, const floa
 /* mesh_instance_desc_t with its visibility flags (SceneBase.h:135-143); bits: 1 camera, 2 diffuse, 4 specular,
  * 8 refraction, 16 shadow */
 ray_handle ray_scene_add_mesh_instance_vis(ray_scene *s, ray_handle mesh, const float xform[16], unsigned visibility);
+void ray_scene_set_mesh_instance_transform(ray_scene *s, ray_handle mi, const float xform[16]); /* SceneBase.h:464 */
+void ray_scene_remove_mesh_instance(ray_scene *s, ray_handle mi);                             /* :472 */
+void ray_scene_remove_light(ray_scene *s, ray_handle light);                                  /* :440 */
 ray_handle ray_scene_add_light(ray_scene *s, const ray_light_desc *d);                /* the six AddLight overloads */
 ray_handle ray_scene_add_camera(ray_scene *s, const ray_camera_desc *d);              /* SceneBase::AddCamera */
 void ray_scene_set_current_cam(ray_scene *s, ray_handle cam);

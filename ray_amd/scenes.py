@@ -290,6 +290,42 @@ def cornell_principled_zoo(scene, **cam_overrides):
     scene.Finalize()
 
 
+def mutate_instances_scene(scene):
+    """a cornell_instances scene after it was rendered: drop an instance and a light, move another instance, add a light,
+    change the environment, Finalize again.  The scene's arrays are sparse pools -- freed slots keep stale contents --
+    and the TLAS / light tree are rebuilt: what a backend must re-upload (RendererHIP: version counter)."""
+    h = scene._test_handles
+    scene.RemoveMeshInstance(h["hidden"])
+    scene.SetMeshInstanceTransform(h["scaled"], _xform(translate=(-0.33, 0.05, 0.05), rot_y_deg=-15.0, scale=(0.5, 1.5, 0.7)))
+    scene.RemoveLight(h["light_a"])
+    scene.AddLight("sphere", color=(2.0, 6.0, 3.0), position=(-0.45, 0.35, -0.35), radius=0.03)
+    scene.SetEnvironment(env_col=(0.10, 0.04, 0.02))
+    scene.Finalize()
+
+
+def cornell_instances_mutable(scene, **cam_overrides):
+    """cornell_instances plus two analytic lights, with the handles the mutation above needs kept on the scene object"""
+    scene.SetEnvironment(env_col=(0.02, 0.03, 0.05))
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.0, 0.0)))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.0, 0.5, 0.0)))
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=100.0, importance_sample=True))
+    attrs, idx = cornell_mesh_arrays(_CORNELL_QUADS)
+    room = scene.AddMesh(attrs, idx, [(grey, None, 0, 18), (red, None, 18, 6), (green, None, 24, 6), (emit, 0xFFFFFFFF, 30, 6)])
+    attrs, idx = cornell_mesh_arrays(_block_quads("short"))
+    block = scene.AddMesh(attrs, idx, [(grey, None, 0, 30)])
+    scene.AddMeshInstance(room)
+    scene.AddMeshInstance(block)
+    scaled = scene.AddMeshInstance(block, _xform(translate=(-0.30, 0.0, 0.10), rot_y_deg=35.0, scale=(0.6, 1.8, 0.6)))
+    hidden = scene.AddMeshInstance(block, _xform(translate=(0.12, 0.30, -0.10), rot_y_deg=-20.0, rot_z_deg=25.0, scale=(0.5, 0.5, 0.5)))
+    scene.AddMeshInstance(block, _xform(translate=(-0.02, 0.0, 0.22), rot_y_deg=10.0, scale=(0.7, 1.2, 0.3)))
+    light_a = scene.AddLight("sphere", color=(6.0, 5.0, 4.0), position=(-0.12, 0.42, -0.12), radius=0.025)
+    scene.AddLight("rect", color=(8.0, 8.0, 7.0), width=0.16, height=0.10, xform=_translate(-0.30, 0.52, -0.44))
+    scene._test_handles = dict(scaled=scaled, hidden=hidden, light_a=light_a)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
 def empty_scene(scene, **cam_overrides):
     """no geometry at all (no TLAS): every ray leaves into the background"""
     scene.SetEnvironment(env_col=(0.3, 0.4, 0.5), back_col=(0.1, 0.2, 0.3))

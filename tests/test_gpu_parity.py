@@ -452,6 +452,33 @@ def test_compressed_textures_through_the_ray_api(gpu_lib, hostsim_lib):
     assert not np.array_equal(imgs[1], imgs[2]), "compression did not change a texel: not exercised"
 
 
+def test_renderer_hip_reuploads_a_mutated_scene(gpu_lib, hostsim_lib):
+    """scene mutators between RenderScene calls (with iterations still pending): RendererHIP must flush, notice the new
+    scene version and upload the mutated arrays -- sparse pools with freed slots, rebuilt TLAS / light tree"""
+    import os
+    from ray_amd import api, scenes
+    if not os.path.exists(api.HIP_HOST_LIB):
+        pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
+    w, h = 64, 48
+    r = api.CreateRenderer(api.Settings(w, h), "HIP")
+    s = r.CreateScene()
+    scenes.cornell_instances_mutable(s)
+    region = api.RegionContext((0, 0, w, h))
+    for _ in range(2):
+        r.RenderScene(s, region)  # (pending)
+    scenes.mutate_instances_scene(s)
+    r.Clear()
+    region = api.RegionContext((0, 0, w, h))
+    for _ in range(3):
+        r.RenderScene(s, region)
+    ctx = hip.Context(0, hostsim_lib)
+    ctx.upload_static(util.pmj())
+    ctx.resize(w, h)
+    ctx.upload_scene_blob(api.export_scene_blob(s))
+    m = util.frame_metrics(r.get_raw_pixels_ref(), util.render_frames(ctx, 3))
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
+
+
 def test_renderer_hip_clear_resize_stats(gpu_lib, hostsim_lib):
     """RendererHIP::Clear / Resize / GetStats / ResetStats behind the Ray API (with iterations pending in the batch queue
     when they are called): pixels against the host build (which equals the reference on this sequence,

@@ -158,6 +158,26 @@ def test_nlm_denoise_against_live_reference(lib, name, cam):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_scene_mutation_against_live_reference(lib):
+    """render, then RemoveMeshInstance / SetMeshInstanceTransform / RemoveLight / AddLight / SetEnvironment / Finalize, render
+    again: the export of the mutated scene (sparse pools with freed slots, rebuilt TLAS and light tree) must reproduce the
+    reference"""
+    from ray_amd import api, scenes
+
+    w, h = 64, 48
+    r, s = O.render_ref(scenes.cornell_instances_mutable, w, h, 2)
+    before = r.get_raw_pixels_ref().copy()
+    scenes.mutate_instances_scene(s)
+    region = api.RegionContext((0, 0, w, h))
+    r.Clear()
+    for _ in range(3):
+        r.RenderScene(s, region)
+    assert not np.array_equal(before, r.get_raw_pixels_ref())
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, 3), r.get_raw_pixels_ref())
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_clear_and_resize_against_live_reference(lib):
     """RendererBase::Clear (full / half <- colour, required_samples re-armed; RendererCPU.h:297-301) and Resize followed by
     more iterations"""
