@@ -479,6 +479,41 @@ def test_renderer_hip_reuploads_a_mutated_scene(gpu_lib, hostsim_lib):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
 
 
+def test_renderer_hip_camera_switch(gpu_lib, hostsim_lib):
+    """two cameras in one scene, switched between RenderScene calls on the SAME region (iterations pending): the pending
+    batch must be rendered with the camera it was queued with, the next iterations with the new one"""
+    import os
+    from ray_amd import api, scenes
+    if not os.path.exists(api.HIP_HOST_LIB):
+        pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
+    w, h = 64, 48
+    r = api.CreateRenderer(api.Settings(w, h), "HIP")
+    s = r.CreateScene()
+    scenes.cornell_basic(s)
+    cam_b = s.AddCamera(type=0, origin=(-0.10, 0.40, 0.75), fwd=(-0.25, -0.2, -1.0), fov=50.0, gamma=2.2)
+    region = api.RegionContext((0, 0, w, h))
+    blobs = [api.export_scene_blob(s)]
+    for _ in range(3):
+        r.RenderScene(s, region)
+    s.set_current_cam(cam_b)
+    blobs.append(api.export_scene_blob(s))
+    for _ in range(2):
+        r.RenderScene(s, region)  # iterations 4, 5 of the same region, through the other camera
+    ctx = hip.Context(0, hostsim_lib)
+    ctx.upload_static(util.pmj())
+    ctx.resize(w, h)
+    ctx.upload_scene_blob(blobs[0])
+    for it in (1, 2, 3):
+        ctx.render(it)
+    ctx.upload_scene_blob(blobs[1])  # (same scene, the blob's camera is the current one)
+    for it in (4, 5):
+        ctx.render(it)
+    m = util.frame_metrics(r.get_raw_pixels_ref(), ctx.readback(hip.BUF_RAW))
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
+    m = util.frame_metrics(r.get_pixels_ref(), ctx.readback(hip.BUF_FINAL))
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
+
+
 def test_renderer_hip_clear_resize_stats(gpu_lib, hostsim_lib):
     """RendererHIP::Clear / Resize / GetStats / ResetStats behind the Ray API (with iterations pending in the batch queue
     when they are called): pixels against the host build (which equals the reference on this sequence,
