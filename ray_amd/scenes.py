@@ -326,6 +326,40 @@ def cornell_instances_mutable(scene, **cam_overrides):
     scene.Finalize()
 
 
+def cornell_delta_lights(scene, **cam_overrides):
+    """corner cases of the light and texture code: delta lights (sphere / spot of radius 0, directional of angle 0 -- never hit
+    by rays, pdf-less sampling), an emitter that is NOT importance-sampled, a textured emitter, a two-sided group with
+    different front / back materials, non-power-of-two textures with mip chains, a 1x1 texture"""
+    scene.SetEnvironment(env_col=(0.01, 0.01, 0.015))
+    i, j = np.meshgrid(np.arange(20), np.arange(48), indexing="ij")
+    npot = np.empty((20, 48, 4), dtype=np.uint8)
+    npot[..., 0] = (40 + 4 * j) % 256
+    npot[..., 1] = (30 + 11 * i) % 256
+    npot[..., 2] = np.where((i // 3 + j // 5) % 2 == 0, 230, 40)
+    npot[..., 3] = 255
+    t_npot = scene.AddTexture(npot, generate_mipmaps=True)
+    t_one = scene.AddTexture(np.array([[[200, 120, 60, 255]]], dtype=np.uint8))
+    floor = scene.AddMaterial(PrincipledMat(base_texture=t_npot, roughness=0.5, specular=0.4))
+    back = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_texture=t_one, roughness=0.2))
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.0, 0.0)))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=(0.1, 0.6, 0.1), roughness=0.35))
+    emit_plain = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=12.0, importance_sample=False))
+    emit_tex = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, base_texture=t_npot, strength=6.0, importance_sample=True))
+    attrs, idx = cornell_mesh_arrays()
+    # floor | ceiling | back | left | right | light | short block | tall block (front: textured emitter, back: grey)
+    groups = [(floor, None, 0, 6), (grey, None, 6, 6), (back, None, 12, 6), (red, green, 19, 6), (green, red, 25, 6),
+              (emit_plain, 0xFFFFFFFF, 31, 6), (grey, None, 37, 30), (emit_tex, grey, 67, 30)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    scene.AddLight("sphere", color=(0.8, 0.7, 0.6), position=(-0.12, 0.42, -0.12), radius=0.0)
+    scene.AddLight("spot", color=(2.0, 2.0, 2.6), position=(-0.47, 0.50, -0.10), direction=(0.45, -0.85, -0.3), radius=0.0,
+                   spot_size=40.0, spot_blend=0.5)
+    scene.AddLight("directional", color=(0.6, 0.55, 0.5), direction=(0.25, -0.45, -1.0), angle=0.0)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
 def empty_scene(scene, **cam_overrides):
     """no geometry at all (no TLAS): every ray leaves into the background"""
     scene.SetEnvironment(env_col=(0.3, 0.4, 0.5), back_col=(0.1, 0.2, 0.3))

@@ -253,6 +253,19 @@ def test_material_zoo_against_live_reference(lib):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_delta_lights_and_texture_corners_against_live_reference(lib):
+    """delta lights, emitters without importance sampling / with a texture, different front and back materials,
+    non-power-of-two and 1x1 textures with mip chains"""
+    from ray_amd import api, scenes
+
+    w, h, spp = 72, 64, 6
+    r, s = O.render_ref(scenes.cornell_delta_lights, w, h, spp)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_sky_portals_against_live_reference(lib):
     """rect / disk lights with sky_portal = true over an environment map"""
     from ray_amd import api, scenes
