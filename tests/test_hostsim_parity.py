@@ -266,6 +266,22 @@ def test_delta_lights_and_texture_corners_against_live_reference(lib):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_atrium_against_live_reference(lib, wide, monkeypatch):
+    """the procedural atrium bench.py renders (Sponza- / Bistro-class at full detail), at a detail the CPU reference
+    finishes in seconds: deep SAH BVH, thousands of emissive triangles in the light tree, textures; BVH2 and 4-wide walks"""
+    from functools import partial
+    from ray_amd import scenes
+
+    monkeypatch.setenv("HOSTSIM_BVH4", wide)
+    w, h, spp = 96, 54, 3
+    r, s = O.render_ref(partial(scenes.atrium, detail=0.02), w, h, spp)
+    assert s.triangle_count() > 5000
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_sky_portals_against_live_reference(lib):
     """rect / disk lights with sky_portal = true over an environment map"""
     from ray_amd import api, scenes
