@@ -641,6 +641,11 @@ def _unit(v):
     return tuple(float(x) for x in v / np.linalg.norm(v))
 
 
+def atrium_small(scene, **cam_overrides):
+    """the bench atrium at 1/20 of the Sponza-class detail (tests)"""
+    atrium(scene, 0.05, cam_overrides or None)
+
+
 SCENES = {
     "cornell_basic": cornell_basic,
     "cornell_principled": cornell_principled,

@@ -403,7 +403,7 @@ def test_nlm_denoise_matches_the_host_build(gpu_lib, hostsim_lib, name):
 
 
 @pytest.mark.parametrize("scene", ["cornell_portals", "cornell_textures", "cornell_principled_zoo", "cornell_delta_lights", "empty_scene",
-                                   "lights_only_scene"])
+                                   "lights_only_scene", "atrium_small"])
 def test_live_only_scenes_match_the_host_build(gpu_lib, hostsim_lib, scene):
     """scenes whose parity with the reference is established on the host build against the live reference
     (tests/test_hostsim_parity.py: sky portals; RGB888 / R8 / normal-map textures with mip chains): GPU vs host build"""
