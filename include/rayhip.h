@@ -332,7 +332,8 @@ RAYHIP_API int rayhip_render_batch(rayhip_ctx *ctx, const rayhip_camera *cam, co
                                    int count, uint32_t flags, rayhip_stats *stats);
 /* Largest number of iterations one wavefront pass of the current frame can carry:
  * min(512, (65535 / width) * (65535 / height)) -- the layers of a pass are stacked side by side and on top of each other
- * in one virtual frame whose coordinates must fit the two 16-bit halves of ray_data_t::xy (internal/Core.h).
+ * in one virtual frame whose coordinates must fit the two 16-bit halves of ray_data_t::xy (internal/Core.h) -- and fewer
+ * for frames so large that the virtual frame would pass 2^31 pixels.
  * rayhip_render_batch splits longer runs itself; callers that choose the run length (RendererHIP's deferred RenderScene
  * calls, bench.py) use this to cut a render into passes of equal size.  Memory: about 0.3 KB of wavefront state per ray
  * in flight plus 48 B per pixel and layer.  0 before rayhip_resize. */

@@ -169,7 +169,12 @@ int max_layers_for(int w, int h) {
     if (w <= 0 || h <= 0) {
         return 0;
     }
-    return int(std::max<size_t>(1, std::min<size_t>(size_t(MAX_LAYERS), size_t(65535 / w) * size_t(65535 / h))));
+    // (the pixel helpers index the virtual frame with 32-bit ints: cols * rows * w * h must stay below 2^31; make_layering
+    // rounds the layer count up to whole columns, hence the margin of one column)
+    const size_t npix = size_t(w) * size_t(h), max_rows = size_t(65535 / h);
+    const size_t by_index = ((size_t(1) << 31) - 1) / npix;
+    const size_t by_index_cols = by_index > max_rows ? (by_index / max_rows) * max_rows : by_index;
+    return int(std::max<size_t>(1, std::min<size_t>({size_t(MAX_LAYERS), size_t(65535 / w) * max_rows, by_index_cols})));
 }
 // the virtual frame of a pass of `layers` iterations: as few columns as the row limit allows
 Layering make_layering(int w, int h, int layers) {
@@ -442,6 +447,9 @@ int rayhip_resize(rayhip_ctx *c, int w, int h) {
     }
     if (w <= 0 || h <= 0 || w > 65535 || h > 65535) {
         return fail("bad frame size %dx%d (pixel coordinates are 16-bit)", w, h);
+    }
+    if (size_t(w) * size_t(h) > (size_t(1) << 30)) {
+        return fail("frame of %dx%d pixels is too large (pixel indices are 32-bit)", w, h);
     }
     if (c->w == w && c->h == h) {
         return 0;
