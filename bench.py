@@ -130,8 +130,8 @@ def cpu_baseline(wl, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=480)  # 8 passes of 60 iterations on one GPU, 1 pass of 480 on each of 8
-    ap.add_argument("--warmup", type=int, default=60)  # one full pass of 60 iterations (1080p), the shape of the timed passes
+    ap.add_argument("--steps", type=int, default=480)  # 4 passes of 120 iterations on one GPU, 1 pass of 480 on each of 8
+    ap.add_argument("--warmup", type=int, default=120)  # one full pass of 120 iterations (1080p), the shape of the timed passes
     ap.add_argument("--workload", default=os.environ.get("RAY_AMD_WORKLOAD", "bistro"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

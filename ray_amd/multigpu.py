@@ -19,12 +19,13 @@ from . import hip
 TILE = 64
 
 
-def batch_size(owned_pixels: int, limit: int, steps: int = 0, target_rays: int = 128 << 20) -> int:
+def batch_size(owned_pixels: int, limit: int, steps: int = 0, target_rays: int = 256 << 20) -> int:
     """iterations per wavefront pass (rayhip_render_batch).  Measured on one MI355X, Bistro-class 1080p: 228 Msamples/s at 1
-    iteration per pass, 274 at 8, 299 at 16, 317 at 32 (then, with later kernels, 382 at 32, 392 at 48, 394 at 60) -- the
-    fixed cost of a launch (its longest rays) and the thinly populated late bounces are shared by all layers.
+    iteration per pass, 274 at 8, 299 at 16, 317 at 32 (then, with later kernels, 382 at 32, 392 at 48, 394 at 60; with the
+    final ones 406 at 60, 416 at 120, 422 at 240) -- the fixed cost of a launch (its longest rays) and the thinly
+    populated late bounces are shared by all layers.
     `limit` = Context.max_batch() (the stacked frame's coordinates are 16-bit); the target keeps the wavefront state
-    (~0.3 KB per ray) near 40 GB of the 288 GB; with `steps` given the run is cut into passes of equal size.  A rank of a
+    (~0.25 KB per ray, plus 48 B per pixel and layer) near 75 GB of the 288 GB; with `steps` given the run is cut into passes of equal size.  A rank of a
     tile-sharded render owns 1/N of the pixels and therefore stacks N times more iterations into a pass: its launches stay
     as full as a single GPU's."""
     b = max(1, min(limit, -(-target_rays // max(owned_pixels, 1))))
