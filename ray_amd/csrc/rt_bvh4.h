@@ -14,7 +14,12 @@
 // whenever the reference's test accepts a child with its exact box, this test accepts it with the wider box: every
 // triangle the reference tests with a chance to hit is tested here, IntersectTri is unchanged, and the closest hit
 // (t, u, v, triangle) is the same -- only exact-t ties between different triangles could resolve differently, as they
-// already do between the reference's own BVH2 and wide-BVH back-ends.  The instrumented kernels
+// already do between the reference's own BVH2 and wide-BVH back-ends.  Any-hit (shadow) rays have one more order
+// dependence, also the reference's own: IntersectScene(shadow_ray_t) stops a ray whose throughput fell below FLT_EPS after
+// a transparent surface and returns that (~1e-8) throughput, while a walk that happens to reach a solid occluder first
+// returns 0 -- which of the two a ray gets depends on the leaf order, i.e. on the tree.  Found by the scene fuzzer
+// (tests/test_hostsim_parity.py: random_cornell seed 215 in wide mode: 8 pixels differ by <= 4e-7); the committed wide-BVH
+// parity scenes are bit-exact.  The instrumented kernels
 // (RAYHIP_FLAG_COUNT_TRAVERSAL) keep walking the BVH2, so the algorithmic-bytes counters stay those of the reference
 // algorithm.  The TLAS stays BVH2 (a handful of nodes).
 //

@@ -641,6 +641,88 @@ def _unit(v):
     return tuple(float(x) for x in v / np.linalg.norm(v))
 
 
+def random_cornell(scene, seed: int = 0, **cam_overrides):
+    """Cornell box with pseudo-random materials, lights and camera drawn from `seed` (tests: a fuzzer over the corners of
+    shading_node_desc_t / principled_mat_desc_t / the light descriptors / camera_desc_t)"""
+    rs = np.random.RandomState(seed)
+    u = lambda lo=0.0, hi=1.0: float(rs.uniform(lo, hi))  # noqa: E731
+    col = lambda lo=0.05, hi=0.95: (u(lo, hi), u(lo, hi), u(lo, hi))  # noqa: E731
+    scene.SetEnvironment(env_col=col(0.0, 0.08), back_col=col(0.0, 0.05))
+    tex = scene.AddTexture(checkerboard(64, int(rs.choice([4, 8, 16]))), generate_mipmaps=bool(rs.randint(2)))
+    nmap = scene.AddTexture(bump_normal_map(32), is_srgb=False, is_normalmap=True)
+
+    def leaf_material():
+        kind = rs.randint(4)
+        if kind == 0:
+            return scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=col(), roughness=u(),
+                                                 base_texture=tex if rs.randint(3) == 0 else None))
+        if kind == 1:
+            return scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=col(), roughness=u(0.02, 0.9), anisotropic=u(0.0, 0.9),
+                                                 anisotropic_rotation=u(), normal_map=nmap if rs.randint(2) else None,
+                                                 normal_map_intensity=u(0.2, 1.0)))
+        if kind == 2:
+            return scene.AddMaterial(ShadingNode(type=eShadingNode.Refractive, base_color=col(0.6, 1.0), roughness=u(0.0, 0.5), ior=u(1.05, 2.0)))
+        return scene.AddMaterial(PrincipledMat(
+            base_color=col(), base_texture=tex if rs.randint(3) == 0 else None, metallic=float(rs.choice([0.0, u(), 1.0])), specular=u(),
+            specular_tint=u(), roughness=u(0.02, 1.0), anisotropic=u(0.0, 0.9), anisotropic_rotation=u(), sheen=u(0.0, 1.0) * rs.randint(2),
+            sheen_tint=u(), clearcoat=u() * rs.randint(2), clearcoat_roughness=u(0.0, 0.5), ior=u(1.1, 1.9),
+            transmission=float(rs.choice([0.0, 0.0, u(), 1.0])), transmission_roughness=u(0.0, 0.6),
+            emission_color=col(), emission_strength=u(0.0, 0.8) * rs.randint(2), alpha=float(rs.choice([1.0, 1.0, u(0.3, 1.0)])),
+            normal_map=nmap if rs.randint(3) == 0 else None, normal_map_intensity=u(0.2, 1.0)))
+
+    def material():
+        if rs.randint(5) == 0:
+            a, b = leaf_material(), leaf_material()
+            if rs.randint(2):
+                b = scene.AddMaterial(ShadingNode(type=eShadingNode.Transparent, base_color=col(0.5, 1.0)))
+            return scene.AddMaterial(ShadingNode(type=eShadingNode.Mix, mix_materials=(a, b), strength=u(0.1, 0.9), mix_add=bool(rs.randint(2)),
+                                                 base_texture=tex if rs.randint(3) == 0 else None))
+        return leaf_material()
+
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=u(20.0, 100.0), base_color=col(0.6, 1.0),
+                                         importance_sample=bool(rs.randint(4))))
+    attrs, idx = cornell_mesh_arrays()
+    mats = [material() for _ in range(7)]
+    groups = [(mats[0], None, 0, 6), (mats[1], None, 6, 6), (mats[2], None, 12, 6), (mats[3], None, 19, 6), (mats[4], None, 25, 6),
+              (emit, 0xFFFFFFFF, 31, 6), (mats[5], mats[5], 37, 30), (mats[6], mats[6], 67, 30)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    flags = lambda: dict(multiple_importance=bool(rs.randint(2)), cast_shadow=bool(rs.randint(4)),  # noqa: E731
+                         diffuse_visibility=bool(rs.randint(4)), specular_visibility=bool(rs.randint(4)),
+                         refraction_visibility=bool(rs.randint(4)))
+    for _ in range(rs.randint(1, 5)):
+        kind = rs.choice(["sphere", "spot", "rect", "disk", "line", "directional"])
+        pos = (u(-0.5, -0.05), u(0.15, 0.5), u(-0.5, -0.05))
+        if kind == "sphere":
+            scene.AddLight("sphere", color=col(0.5, 8.0), position=pos, radius=float(rs.choice([0.0, u(0.005, 0.05)])), **flags())
+        elif kind == "spot":
+            scene.AddLight("spot", color=col(2.0, 20.0), position=pos, direction=(u(-0.5, 0.5), -1.0, u(-0.5, 0.5)),
+                           radius=float(rs.choice([0.0, u(0.005, 0.03)])), spot_size=u(20.0, 90.0), spot_blend=u(0.0, 1.0), **flags())
+        elif kind == "rect":
+            scene.AddLight("rect", color=col(1.0, 10.0), width=u(0.05, 0.2), height=u(0.05, 0.2), doublesided=bool(rs.randint(2)),
+                           xform=_translate(*pos, rot_x_deg=u(-40.0, 40.0), rot_z_deg=u(-40.0, 40.0)), **flags())
+        elif kind == "disk":
+            scene.AddLight("disk", color=col(1.0, 10.0), width=u(0.05, 0.2), height=u(0.05, 0.2), doublesided=bool(rs.randint(2)),
+                           xform=_translate(*pos, rot_x_deg=u(-40.0, 40.0), rot_z_deg=u(-40.0, 40.0)), **flags())
+        elif kind == "line":
+            scene.AddLight("line", color=col(1.0, 10.0), radius=u(0.002, 0.01), height=u(0.1, 0.3),
+                           xform=_translate(*pos, rot_x_deg=u(0.0, 180.0), rot_z_deg=u(0.0, 180.0)), **flags())
+        else:
+            scene.AddLight("directional", color=col(0.2, 2.0), direction=(u(-0.5, 0.5), -1.0, u(-1.0, 0.0)),
+                           angle=float(rs.choice([0.0, u(0.5, 8.0)])), **flags())
+    kw = dict(fov=u(30.0, 60.0), filter=int(rs.randint(3)), filter_width=u(1.0, 2.5), exposure=u(-1.0, 1.0), gamma=float(rs.choice([1.0, 2.2])),
+              max_diff_depth=int(rs.randint(1, 5)), max_spec_depth=int(rs.randint(1, 7)), max_refr_depth=int(rs.randint(1, 7)),
+              max_transp_depth=int(rs.randint(1, 7)), max_total_depth=int(rs.randint(2, 8)), min_total_depth=int(rs.randint(1, 4)),
+              min_transp_depth=int(rs.randint(1, 4)), clamp_direct=float(rs.choice([0.0, u(1.0, 10.0)])),
+              clamp_indirect=float(rs.choice([0.0, u(1.0, 10.0)])), regularize_alpha=float(rs.choice([0.0, u(0.01, 0.1)])))
+    if rs.randint(3) == 0:
+        kw.update(fstop=u(1.0, 8.0), focus_distance=u(0.4, 1.0), focal_length=u(0.02, 0.08), lens_blades=int(rs.choice([0, 5, 7])),
+                  lens_rotation=u(0.0, 1.0), lens_ratio=u(0.7, 1.5))
+    kw.update(cam_overrides)
+    _cornell_camera(scene, **kw)
+    scene.Finalize()
+
+
 def atrium_small(scene, **cam_overrides):
     """the bench atrium at 1/20 of the Sponza-class detail (tests)"""
     atrium(scene, 0.05, cam_overrides or None)

@@ -282,6 +282,23 @@ def test_atrium_against_live_reference(lib, wide, monkeypatch):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_random_scenes_against_live_reference(lib, seed):
+    """a small fuzzer: materials (all node types, Mix trees, every Principled parameter), lights (all types, delta and
+    area, all flags) and camera / pass settings drawn from a seed; host build vs the reference, bit for bit"""
+    from functools import partial
+    from ray_amd import api, scenes
+
+    w, h, spp = 56, 48, 3
+    r, s = O.render_ref(partial(scenes.random_cornell, seed=seed), w, h, spp)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), r.get_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_sky_portals_against_live_reference(lib):
     """rect / disk lights with sky_portal = true over an environment map"""
     from ray_amd import api, scenes
