@@ -15,7 +15,7 @@ from typing import Tuple
 
 import numpy as np
 
-from .api import PrincipledMat, ShadingNode, eShadingNode, eTextureFormat
+from .api import InvalidHandle, PrincipledMat, ShadingNode, eShadingNode, eTextureFormat
 
 # ---- Cornell box ----------------------------------------------------------------------------------------------
 # quad = (4 corners, normal, 4 uvs, index pattern).  Measurements are the classic Cornell data in metres with x
@@ -718,6 +718,70 @@ def random_cornell(scene, seed: int = 0, **cam_overrides):
     if rs.randint(3) == 0:
         kw.update(fstop=u(1.0, 8.0), focus_distance=u(0.4, 1.0), focal_length=u(0.02, 0.08), lens_blades=int(rs.choice([0, 5, 7])),
                   lens_rotation=u(0.0, 1.0), lens_ratio=u(0.7, 1.5))
+    kw.update(cam_overrides)
+    _cornell_camera(scene, **kw)
+    scene.Finalize()
+
+
+def random_instances(scene, seed: int = 0, **cam_overrides):
+    """fuzzer over the two-level hierarchy and the environment: an open or closed room, 2-9 instances of two block meshes
+    with random rotations / non-uniform scales / translations / ray-type visibility, random leaf materials, an HDR
+    environment (importance-sampled or not, rotated) or a constant one, optional sky portals"""
+    rs = np.random.RandomState(10000 + seed)
+    u = lambda lo=0.0, hi=1.0: float(rs.uniform(lo, hi))  # noqa: E731
+    col = lambda lo=0.05, hi=0.95: (u(lo, hi), u(lo, hi), u(lo, hi))  # noqa: E731
+    open_top = bool(rs.randint(2))
+    if rs.randint(3):
+        sky = scene.AddTexture(rgbe_sky(), is_srgb=False)
+        rot = u(0.0, 6.0)
+        scene.SetEnvironment(env_col=col(0.3, 1.5), back_col=col(0.3, 1.5), env_map=sky, back_map=sky if rs.randint(2) else InvalidHandle,
+                             env_map_rotation=rot, back_map_rotation=rot, importance_sample=bool(rs.randint(2)))
+    else:
+        scene.SetEnvironment(env_col=col(0.0, 0.6), back_col=col(0.0, 0.3))
+    tex = scene.AddTexture(checkerboard(32, 4), generate_mipmaps=True)
+
+    def material():
+        kind = rs.randint(5)
+        if kind == 0:
+            return scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=col(), roughness=u(), base_texture=tex if rs.randint(3) == 0 else None))
+        if kind == 1:
+            return scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=col(), roughness=u(0.02, 0.8)))
+        if kind == 2:
+            return scene.AddMaterial(ShadingNode(type=eShadingNode.Refractive, base_color=col(0.7, 1.0), roughness=u(0.0, 0.3), ior=u(1.1, 1.8)))
+        if kind == 3:
+            a = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=col()))
+            b = scene.AddMaterial(ShadingNode(type=eShadingNode.Transparent, base_color=col(0.5, 1.0)))
+            return scene.AddMaterial(ShadingNode(type=eShadingNode.Mix, mix_materials=(a, b), strength=u(0.2, 0.8)))
+        return scene.AddMaterial(PrincipledMat(base_color=col(), metallic=float(rs.randint(2)), roughness=u(0.05, 0.9), specular=u(),
+                                               transmission=float(rs.choice([0.0, 0.0, 1.0])), ior=u(1.1, 1.8), clearcoat=u() * rs.randint(2)))
+
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=u(20.0, 80.0), importance_sample=True))
+    q = _CORNELL_QUADS
+    if open_top:
+        attrs, idx = cornell_mesh_arrays([q[0], q[2], q[3], q[4]])  # floor, back, left, right
+        room = scene.AddMesh(attrs, idx, [(material(), None, 0, 6), (grey, None, 6, 6), (material(), None, 12, 12)])
+    else:
+        attrs, idx = cornell_mesh_arrays(q)
+        room = scene.AddMesh(attrs, idx, [(material(), None, 0, 6), (grey, None, 6, 12), (material(), None, 18, 12), (emit, 0xFFFFFFFF, 30, 6)])
+    scene.AddMeshInstance(room)
+    meshes = []
+    for kind in ("short", "tall"):
+        attrs, idx = cornell_mesh_arrays(_block_quads(kind))
+        for _ in range(2):
+            m = material()
+            meshes.append(scene.AddMesh(attrs, idx, [(m, m, 0, 30)]))
+    for _ in range(rs.randint(2, 10)):
+        xf = _xform(translate=(u(-0.25, 0.2), u(0.0, 0.3), u(-0.15, 0.25)), rot_y_deg=u(0.0, 360.0), rot_z_deg=u(-30.0, 30.0) * rs.randint(2),
+                    scale=(u(0.3, 1.0), u(0.3, 1.4), u(0.3, 1.0)))
+        vis = dict(camera=bool(rs.randint(5)), diffuse=bool(rs.randint(5)), specular=bool(rs.randint(5)), refraction=bool(rs.randint(5)),
+                   shadow=bool(rs.randint(5)))
+        scene.AddMeshInstance(int(rs.choice(meshes)), xf, **vis)
+    if open_top and rs.randint(2):
+        scene.AddLight("rect", color=(1.0, 1.0, 1.0), width=0.5, height=0.5, sky_portal=True, xform=_translate(-0.28, 0.5488, -0.28))
+    if rs.randint(2):
+        scene.AddLight("sphere", color=col(1.0, 6.0), position=(u(-0.5, -0.05), u(0.3, 0.5), u(-0.5, -0.05)), radius=u(0.0, 0.04))
+    kw = dict(fov=u(35.0, 55.0), max_total_depth=int(rs.randint(2, 8)), max_transp_depth=int(rs.randint(1, 8)))
     kw.update(cam_overrides)
     _cornell_camera(scene, **kw)
     scene.Finalize()

@@ -299,6 +299,27 @@ def test_random_scenes_against_live_reference(lib, seed):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", list(range(1, 9)))
+def test_random_instanced_scenes_against_live_reference(lib, seed):
+    """the second fuzzer: 2-9 instances of shared meshes with random transforms and ray-type visibility, HDR environment
+    with / without importance sampling, sky portals; frames and the NLM-denoised frames, bit for bit"""
+    from functools import partial
+    from ray_amd import api, scenes
+
+    w, h, spp = 56, 48, 3
+    r, s = O.render_ref(partial(scenes.random_instances, seed=seed), w, h, spp)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    region = api.RegionContext((0, 0, w, h))
+    region._bind(O.ref_lib())
+    region.iteration = spp
+    r.DenoiseImage(region)
+    ctx.denoise_nlm(spp)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), r.get_pixels_ref())
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_sky_portals_against_live_reference(lib):
     """rect / disk lights with sky_portal = true over an environment map"""
     from ray_amd import api, scenes
