@@ -1,0 +1,54 @@
+"""Random scenes (ray_amd.scenes.random_cornell / random_instances) on the GPU against the host build of the same kernel
+sources (which equals the reference on these, tests/test_hostsim_parity.py).  Runs on a GPU box:
+    python tools/gpu_fuzz.py [first_seed] [count]"""
+import os
+import sys
+from functools import partial
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401,E402
+
+import oracle_lib as O  # noqa: E402
+import util  # noqa: E402
+from ray_amd import api, hip, scenes  # noqa: E402
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+    gpu, host = hip.Library(), hip.Library(O.HOSTSIM_LIB, prefix="hostsim_")
+    w, h, spp = 64, 48, 4
+    worst = (1.0, 1e9, None)
+    for seed in range(first, first + count):
+        for fn in (scenes.random_cornell, scenes.random_instances):
+            r = api.CreateRenderer(api.Settings(w, h), "HIP")
+            s = r.CreateScene()
+            fn(s, seed=seed)
+            blob = api.export_scene_blob(s)
+            imgs = []
+            for lib in (host, gpu):
+                ctx = hip.Context(0, lib)
+                ctx.upload_static(util.pmj())
+                ctx.resize(w, h)
+                ctx.upload_scene_blob(blob)
+                if lib is gpu:
+                    ctx.render_batch(1, spp)
+                else:
+                    util.render_frames(ctx, spp)
+                ctx.denoise_nlm(spp)
+                imgs.append(ctx.readback(hip.BUF_RAW))
+            m = util.frame_metrics(imgs[1], imgs[0])
+            if (m["frac_within"], m["psnr"]) < (worst[0], worst[1]):
+                worst = (m["frac_within"], m["psnr"], (fn.__name__, seed))
+            if m["frac_within"] < util.MIN_FRACTION or m["psnr"] < util.MIN_PSNR_8SPP:
+                print("FAIL", fn.__name__, seed, m)
+    print(f"{2 * count} random scenes, GPU vs host build after render + NLM: worst fraction within tolerance {worst[0]:.5f}, "
+          f"worst PSNR {worst[1]:.1f} dB at {worst[2]}")
+
+
+if __name__ == "__main__":
+    main()
