@@ -427,6 +427,38 @@ def test_live_only_scenes_match_the_host_build(gpu_lib, hostsim_lib, scene):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
 
 
+@pytest.mark.parametrize("fn,seed", [("random_cornell", 3), ("random_cornell", 7), ("random_cornell", 215), ("random_instances", 2),
+                                     ("random_instances", 1013)])
+def test_random_scenes_match_the_host_build(gpu_lib, hostsim_lib, fn, seed):
+    """the scene fuzzers of tests/test_hostsim_parity.py on the device (batched render, then the NLM filter): GPU vs the host
+    build of the same kernel sources, which equals the reference on these scenes (tools/gpu_fuzz.py runs more of them)"""
+    import os
+    from ray_amd import api, scenes
+    if not os.path.exists(api.HIP_HOST_LIB):
+        pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
+    w, h, spp = 64, 48, 4
+    r = api.CreateRenderer(api.Settings(w, h), "HIP")
+    s = r.CreateScene()
+    getattr(scenes, fn)(s, seed=seed)
+    blob = api.export_scene_blob(s)
+    imgs = []
+    for lib in (hostsim_lib, gpu_lib):
+        ctx = hip.Context(0, lib)
+        ctx.upload_static(util.pmj())
+        ctx.resize(w, h)
+        ctx.upload_scene_blob(blob)
+        if lib is gpu_lib:
+            ctx.render_batch(1, spp)
+        else:
+            util.render_frames(ctx, spp)
+        raw = ctx.readback(hip.BUF_RAW)
+        ctx.denoise_nlm(spp)
+        imgs.append((raw, ctx.readback(hip.BUF_RAW)))
+    for a, b in zip(imgs[1], imgs[0]):
+        m = util.frame_metrics(a, b)
+        assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
+
+
 def test_compressed_textures_through_the_ray_api(gpu_lib, hostsim_lib):
     """settings_t::use_tex_compression = true (the reference's default): SceneHIP keeps the BCn storages and the exporter
     decodes them (host build == reference on this, tests/test_hostsim_parity.py); the GPU must agree with the host build"""
