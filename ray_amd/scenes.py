@@ -787,6 +787,61 @@ def random_instances(scene, seed: int = 0, **cam_overrides):
     scene.Finalize()
 
 
+def random_textures(scene, seed: int = 0, **cam_overrides):
+    """fuzzer over the texture code: base-colour / roughness / metallic / specular / emission / alpha / normal maps of random
+    sizes (incl. non-power-of-two and 1 pixel wide), channel formats, sRGB flags and mip chains, none of them with
+    force_no_compression -- so under settings_t::use_tex_compression they take the block-compressed storages"""
+    rs = np.random.RandomState(20000 + seed)
+    u = lambda lo=0.0, hi=1.0: float(rs.uniform(lo, hi))  # noqa: E731
+    scene.SetEnvironment(env_col=(0.03, 0.03, 0.04))
+
+    def image(channels):
+        h_, w_ = int(rs.choice([1, 3, 8, 20, 32, 48, 64])), int(rs.choice([1, 5, 8, 24, 32, 64]))
+        i, j = np.meshgrid(np.arange(h_), np.arange(w_), indexing="ij")
+        planes = [(rs.randint(20, 120) + rs.randint(40, 130) * (0.5 + 0.5 * np.sin(i * u(0.1, 0.9) + j * u(0.1, 0.9) + u(0, 6)))) for _ in range(channels)]
+        img = np.stack(planes, axis=-1)
+        if rs.randint(2):
+            img += 40.0 * (((i // max(1, h_ // 4)) + (j // max(1, w_ // 4))) % 2)[..., None]
+        img = np.clip(img, 0, 255).astype(np.uint8)
+        if channels == 4:
+            img[..., 3] = 255
+        return img
+
+    def texture(kind):
+        mips = bool(rs.randint(2))
+        if kind == "rgb":
+            if rs.randint(2):
+                return scene.AddTexture(image(3), fmt=eTextureFormat.RGB888, is_srgb=bool(rs.randint(2)), generate_mipmaps=mips, force_no_compression=False)
+            return scene.AddTexture(image(4), fmt=eTextureFormat.RGBA8888, is_srgb=bool(rs.randint(2)), generate_mipmaps=mips, force_no_compression=False)
+        if kind == "r":
+            return scene.AddTexture(image(1), fmt=eTextureFormat.R8, is_srgb=bool(rs.randint(2)), generate_mipmaps=mips, force_no_compression=False)
+        res = int(rs.choice([16, 32, 64]))
+        return scene.AddTexture(bump_normal_map(res), is_srgb=False, is_normalmap=True, generate_mipmaps=mips, force_no_compression=False)
+
+    def material():
+        if rs.randint(4) == 0:
+            return scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_texture=texture("rgb"), roughness=u(),
+                                                 normal_map=texture("n") if rs.randint(2) else None, normal_map_intensity=u(0.3, 1.0)))
+        return scene.AddMaterial(PrincipledMat(
+            base_texture=texture("rgb") if rs.randint(4) else None, base_color=(u(0.2, 0.9), u(0.2, 0.9), u(0.2, 0.9)), roughness=u(0.1, 1.0),
+            roughness_texture=texture("r") if rs.randint(2) else None, metallic=u(), metallic_texture=texture("r") if rs.randint(3) == 0 else None,
+            specular=u(), specular_texture=texture("r") if rs.randint(3) == 0 else None,
+            emission_color=(1.0, 0.9, 0.8), emission_strength=u(0.0, 0.6) * rs.randint(2), emission_texture=texture("rgb") if rs.randint(3) == 0 else None,
+            alpha=float(rs.choice([1.0, 1.0, u(0.4, 1.0)])), alpha_texture=texture("r") if rs.randint(4) == 0 else None,
+            normal_map=texture("n") if rs.randint(3) == 0 else None, normal_map_intensity=u(0.3, 1.0)))
+
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=60.0, base_texture=texture("rgb") if rs.randint(2) else None,
+                                         importance_sample=True))
+    attrs, idx = cornell_mesh_arrays()
+    mats = [material() for _ in range(7)]
+    groups = [(mats[0], None, 0, 6), (mats[1], None, 6, 6), (mats[2], None, 12, 6), (mats[3], None, 19, 6), (mats[4], None, 25, 6),
+              (emit, 0xFFFFFFFF, 31, 6), (mats[5], mats[5], 37, 30), (mats[6], mats[6], 67, 30)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
 def atrium_small(scene, **cam_overrides):
     """the bench atrium at 1/20 of the Sponza-class detail (tests)"""
     atrium(scene, 0.05, cam_overrides or None)

@@ -320,6 +320,21 @@ def test_random_instanced_scenes_against_live_reference(lib, seed):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed,compress", [(1, False), (2, True), (3, False), (4, True), (5, True), (6, False)])
+def test_random_textures_against_live_reference(lib, seed, compress):
+    """the third fuzzer: texture slots of Principled / Diffuse / Emissive materials with random sizes (1-pixel and
+    non-power-of-two included), channel formats, sRGB flags and mip chains, with and without settings_t::use_tex_compression"""
+    from functools import partial
+    from ray_amd import api, scenes
+
+    w, h, spp = 56, 48, 3
+    r, s = O.render_ref(partial(scenes.random_textures, seed=seed), w, h, spp, use_tex_compression=compress)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_sky_portals_against_live_reference(lib):
     """rect / disk lights with sky_portal = true over an environment map"""
     from ray_amd import api, scenes
