@@ -226,6 +226,36 @@ def test_ray_sort_is_bit_identical(gpu_lib, name):
     assert np.array_equal(a.readback(hip.BUF_RAW), b.readback(hip.BUF_RAW))
 
 
+def test_error_paths_are_loud(gpu_lib):
+    """misuse and unsupported content return an error (rayhip_last_error) instead of rendering something else"""
+    import copy
+    ctx = hip.Context(0, gpu_lib)
+    with pytest.raises(RuntimeError, match="resize"):
+        ctx.render_batch(1, 2, rect=(0, 0, 8, 8), cam=hip.Camera())  # nothing set up
+    ctx = util.make_context(gpu_lib, "cornell_basic")
+    with pytest.raises(RuntimeError, match="rect"):
+        ctx.render(1, rect=(32, 32, 64, 64))
+    with pytest.raises(RuntimeError, match="1-based"):
+        ctx.render(0)
+    cam = copy.copy(ctx.cam)
+    cam.view_transform = 8  # Filmic_HighContrast without its table
+    with pytest.raises(RuntimeError, match="look-up table"):
+        ctx.render(1, cam=cam)
+    with pytest.raises(RuntimeError, match="look-up table"):
+        ctx.denoise_nlm(1, cam=cam)
+    cam = copy.copy(ctx.cam)
+    cam.type = 1  # eCamType::Ortho
+    with pytest.raises(RuntimeError, match="perspective"):
+        ctx.render(1, cam=cam)
+    with pytest.raises(RuntimeError, match="bad frame size"):
+        ctx.resize(0, 10)
+    with pytest.raises(RuntimeError, match="bad shard"):
+        ctx.set_shard(64, 2, 2)
+    ctx.resize(64, 64)
+    ctx.render(1)  # still usable after the errors
+    assert float(ctx.readback(hip.BUF_RAW)[..., :3].max()) > 0.0
+
+
 def test_rect_render(gpu_lib):
     """RegionContext rect: rendering two half-frame rects == rendering the full frame"""
     name = "cornell_basic"
