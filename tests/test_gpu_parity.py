@@ -457,9 +457,10 @@ def test_live_only_scenes_match_the_host_build(gpu_lib, hostsim_lib, scene):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
 
 
-@pytest.mark.parametrize("fn,seed", [("random_cornell", 3), ("random_cornell", 7), ("random_cornell", 215), ("random_instances", 2),
-                                     ("random_instances", 1013)])
-def test_random_scenes_match_the_host_build(gpu_lib, hostsim_lib, fn, seed):
+@pytest.mark.parametrize("fn,seed,compress", [("random_cornell", 3, False), ("random_cornell", 7, False), ("random_cornell", 215, False),
+                                              ("random_instances", 2, False), ("random_instances", 1013, False),
+                                              ("random_textures", 2, True), ("random_textures", 3, False), ("random_textures", 5, True)])
+def test_random_scenes_match_the_host_build(gpu_lib, hostsim_lib, fn, seed, compress):
     """the scene fuzzers of tests/test_hostsim_parity.py on the device (batched render, then the NLM filter): GPU vs the host
     build of the same kernel sources, which equals the reference on these scenes (tools/gpu_fuzz.py runs more of them)"""
     import os
@@ -467,7 +468,7 @@ def test_random_scenes_match_the_host_build(gpu_lib, hostsim_lib, fn, seed):
     if not os.path.exists(api.HIP_HOST_LIB):
         pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
     w, h, spp = 64, 48, 4
-    r = api.CreateRenderer(api.Settings(w, h), "HIP")
+    r = api.CreateRenderer(api.Settings(w, h, use_tex_compression=compress), "HIP")
     s = r.CreateScene()
     getattr(scenes, fn)(s, seed=seed)
     blob = api.export_scene_blob(s)

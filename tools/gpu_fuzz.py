@@ -1,4 +1,4 @@
-"""Random scenes (ray_amd.scenes.random_cornell / random_instances) on the GPU against the host build of the same kernel
+"""Random scenes (ray_amd.scenes.random_cornell / random_instances / random_textures) on the GPU against the host build of the same kernel
 sources (which equals the reference on these, tests/test_hostsim_parity.py).  Runs on a GPU box:
     python tools/gpu_fuzz.py [first_seed] [count]"""
 import os
@@ -24,8 +24,8 @@ def main():
     w, h, spp = 64, 48, 4
     worst = (1.0, 1e9, None)
     for seed in range(first, first + count):
-        for fn in (scenes.random_cornell, scenes.random_instances):
-            r = api.CreateRenderer(api.Settings(w, h), "HIP")
+        for fn in (scenes.random_cornell, scenes.random_instances, scenes.random_textures):
+            r = api.CreateRenderer(api.Settings(w, h, use_tex_compression=bool(seed & 1)), "HIP")
             s = r.CreateScene()
             fn(s, seed=seed)
             blob = api.export_scene_blob(s)
@@ -46,7 +46,7 @@ def main():
                 worst = (m["frac_within"], m["psnr"], (fn.__name__, seed))
             if m["frac_within"] < util.MIN_FRACTION or m["psnr"] < util.MIN_PSNR_8SPP:
                 print("FAIL", fn.__name__, seed, m)
-    print(f"{2 * count} random scenes, GPU vs host build after render + NLM: worst fraction within tolerance {worst[0]:.5f}, "
+    print(f"{3 * count} random scenes, GPU vs host build after render + NLM: worst fraction within tolerance {worst[0]:.5f}, "
           f"worst PSNR {worst[1]:.1f} dB at {worst[2]}")
 
 
