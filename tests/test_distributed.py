@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, w, h, spp, out_dir):
+def _worker(rank, world, port, w, h, spp, out_dir, batch=1):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -40,7 +40,7 @@ def _worker(rank, world, port, w, h, spp, out_dir):
     lib = hip.Library(O2.HOSTSIM_LIB, prefix="hostsim_")
     ctx = U.make_context(lib, "cornell_basic", w, h)
     frame = torch.zeros((h, w, 4), dtype=torch.float32)
-    multigpu.render_sharded(ctx, range(1, spp + 1), rank, world, dist=dist, frame=frame, tile=32)
+    multigpu.render_sharded(ctx, range(1, spp + 1), rank, world, dist=dist, frame=frame, tile=32, batch=batch)
     part = ctx.readback(hip.BUF_RAW)
     mask = multigpu.owned_pixel_mask(w, h, rank, world, tile=32)
     assert not part[~mask].any(), "a rank wrote pixels it does not own"
@@ -57,6 +57,22 @@ def test_two_ranks_gloo_bit_identical(tmp_path):
 
     w, h, spp, world = 96, 80, 2, 2
     mp.spawn(_worker, args=(world, _free_port(), w, h, spp, str(tmp_path)), nprocs=world, join=True)
+    from ray_amd import hip
+
+    lib = hip.Library(O.HOSTSIM_LIB, prefix="hostsim_")
+    full = util.render_frames(util.make_context(lib, "cornell_basic", w, h), spp)
+    got = np.load(os.path.join(str(tmp_path), "frame.npy"))
+    assert np.array_equal(got, full)
+
+
+@pytest.mark.skipif(not O.have_hostsim(), reason="tests/hostsim not built")
+def test_three_ranks_batched_gloo_bit_identical(tmp_path):
+    """a world size that does not divide the tile count, a frame that is not a whole number of tiles, and every rank
+    stacking its iterations into one wavefront pass (what bench.py does): still the single-process frame, bit for bit"""
+    import torch.multiprocessing as mp
+
+    w, h, spp, world = 100, 72, 3, 3
+    mp.spawn(_worker, args=(world, _free_port(), w, h, spp, str(tmp_path), spp), nprocs=world, join=True)
     from ray_amd import hip
 
     lib = hip.Library(O.HOSTSIM_LIB, prefix="hostsim_")
