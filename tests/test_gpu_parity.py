@@ -226,6 +226,18 @@ def test_ray_sort_is_bit_identical(gpu_lib, name):
     assert np.array_equal(a.readback(hip.BUF_RAW), b.readback(hip.BUF_RAW))
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (65, 1), (13, 9)])
+def test_tiny_and_ragged_frames(gpu_lib, hostsim_lib, w, h):
+    """frames smaller than one 8x8 ray-generation tile / one wave, and ragged ones, stacked into one pass: GPU vs the host
+    build (which equals the reference on these sizes, tests/test_hostsim_parity.py::test_live_reference_other_sizes)"""
+    spp = 5
+    host = util.render_frames(util.make_context(hostsim_lib, "cornell_basic", w, h), spp)
+    ctx = util.make_context(gpu_lib, "cornell_basic", w, h)
+    ctx.render_batch(1, spp)
+    m = util.frame_metrics(ctx.readback(hip.BUF_RAW), host)
+    assert m["frac_within"] == 1.0 and m["alpha_equal"], m
+
+
 def test_error_paths_are_loud(gpu_lib):
     """misuse and unsupported content return an error (rayhip_last_error) instead of rendering something else"""
     import copy

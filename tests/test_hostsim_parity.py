@@ -76,9 +76,12 @@ def test_tile_sharding_and_rects(lib):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("name,w,h,spp", [("cornell_basic", 160, 96, 5), ("cornell_principled", 96, 160, 5)])
+@pytest.mark.parametrize("name,w,h,spp", [("cornell_basic", 160, 96, 5), ("cornell_principled", 96, 160, 5),
+                                              ("cornell_basic", 1, 1, 4), ("cornell_basic", 7, 3, 4), ("cornell_lights", 13, 9, 3),
+                                              ("cornell_basic", 65, 1, 3)])
 def test_live_reference_other_sizes(lib, name, w, h, spp):
-    """non-square frames, against the reference run live (not the fixtures)"""
+    """non-square frames, single-pixel and ragged ones (not whole 8x8 ray-generation tiles), against the reference run
+    live (not the fixtures)"""
     from ray_amd import api, scenes
 
     r, s = O.render_ref(scenes.SCENES[name], w, h, spp)
