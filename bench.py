@@ -20,13 +20,21 @@ inside the timed region.  Total work is fixed -> "scaling": "strong".
 Timed region: barrier + stream sync | K iterations (+ the reduce at N>1) | stream sync + barrier; max over ranks.
 Inputs (scene, PMJ table) are resident in HBM before the region starts; nothing is copied to the host inside it.
 
-roofline: for the dominant kernel k_trace_closest (BVH2 closest-hit traversal).  Its launches are bracketed by
-HIP events on the context stream during the timed region (RAYHIP_FLAG_TIME_STAGES, no synchronisation); the
-ALGORITHMIC bytes are the SURVEY.md section 8(d) formula  72+20+4 + 64*nodes + 48*tris + 144*instances  per ray,
-with the visit counts taken from the instrumented kernel variant on iterations of the same workload right after
-the timed region (counts per iteration are averaged over up to 4 iterations and scaled to K).
-cpu_baseline: the reference's own AVX2 backend (oracle/_ref, kind "reference") on all host cores with the
-documented tile/thread pattern, on a bounded number of spp of the same scene and resolution (rank 0, N=1 only).
+roofline (dominant kernel: k_trace_closest<false,true>, the closest-hit traversal K2).  Its launches are bracketed by HIP
+events on the context stream during the timed region (RAYHIP_FLAG_TIME_STAGES, no synchronisation).  Three byte counts,
+all per launch:
+  traffic      HBM bytes that actually moved: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE of this kernel, from a profiled run of
+               THIS command line (profiles/r02/k2_traffic.json, keyed by workload / steps / iterations per pass; written by
+               tools/k2_traffic.py from the rocprofv3 output); null when this configuration was not profiled
+  achieved     = traffic / launch time when traffic is known (the north star's figure: "achieved HBM GB/s from rocprof
+               against the chip's memory roofline"), else the kernel's own algorithmic rate; frac = achieved / 8 TB/s
+  algorithmic  the kernel's OWN algorithmic bytes: 72+20+4 per ray + 64 per TLAS node + 64 per 4-wide node + 48 per
+               triangle + 144 per instance, counted by the instrumented product kernel (RAYHIP_FLAG_COUNT_WIDE) on iterations
+               of the same workload right after the timed region; next to it the same for the reference's BVH2 walk
+               (SURVEY 8d's formula, RAYHIP_FLAG_COUNT_TRAVERSAL) -- what a cache-less machine would have to move
+cpu_baseline: the reference's own AVX2 backend (oracle/_ref, kind "reference"), one persistent pool of worker threads (as
+many as this process may run on: affinity mask and cgroup quota) pulling 32x32 tiles, ALL samples of a tile in one go, on a
+bounded number of spp of the same scene and resolution (rank 0, N=1 only); per-stage split from RendererBase::GetStats.
 """
 import argparse
 import json
@@ -83,28 +91,53 @@ def get_scene_blob(name, wl, rank, world, barrier):
     return blob, info
 
 
-def measured_traffic(workload, batch):
-    """HBM bytes per K2 launch from the committed rocprofv3 PMC passes (profiles/r01/k2_traffic.json: FETCH_SIZE + WRITE_SIZE,
-    collected in separate runs of this command under the profiler; scaled by the ray count if this run puts a different
-    number of iterations into a pass than the profiled one); None for workloads that were not profiled"""
+def measured_traffic(workload, steps, batch):
+    """HBM bytes per K2 launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 PMC passes of this very command line
+    (profiles/r02/k2_traffic.json, written by tools/k2_traffic.py); None when this configuration was not profiled"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "k2_traffic.json")) as f:
-            t = json.load(f).get(workload)
-        if t is None:
-            return None
-        return float(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) * batch / float(t.get("iterations_per_pass", batch))
+        with open(os.path.join(ROOT, "profiles", "r02", "k2_traffic.json")) as f:
+            table = json.load(f)
+        for e in table.get("runs", []):
+            if e["workload"] == workload and e["steps"] == steps and e["iterations_per_pass"] == batch:
+                return {"bytes_per_launch": float(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]),
+                        "fetch_bytes_per_launch": float(e["fetch_bytes_per_launch"]),
+                        "write_bytes_per_launch": float(e["write_bytes_per_launch"]),
+                        "profiled_avg_launch_ms": e.get("avg_launch_ms"), "source": e.get("source")}
     except (OSError, ValueError, KeyError):
-        return None
+        pass
+    return None
 
 
-def cpu_baseline(wl, budget_s=12.0):
+def usable_cpus():
+    """hardware threads this process may actually run on: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota|max> <period>"
+            q, period = f.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, period = float(f1.read()), float(f2.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+def cpu_baseline(wl, budget_s=15.0):
     """reference AVX2 backend on the host cores, bounded sample of the same workload"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     try:
         import oracle_lib as O
         if not O.have_ref():
             return None
-        threads = os.cpu_count() or 1
+        threads, quota = usable_cpus()
         kind = "AVX2"
         try:
             r = O.create_renderer(wl["w"], wl["h"], kind)
@@ -113,18 +146,50 @@ def cpu_baseline(wl, budget_s=12.0):
             r = O.create_renderer(wl["w"], wl["h"], kind)
         s = r.CreateScene()
         build_scene(s, wl)
-        spp_done, t_total = 0, 0.0
-        step = 1
-        while t_total < budget_s and spp_done < 64:
-            t_total += r.render_tiled_mt(s, 32, step, threads)
-            spp_done += step
-            step = min(step * 2, 8)
-        return {"value": wl["w"] * wl["h"] * spp_done / t_total / 1e6, "unit": "Msamples/s", "cores": threads,
+        # calibration: one sample per pixel (also pages the scene in and sizes the per-thread buffers) ...
+        t1 = r.render_tiled_mt(s, 32, 1, threads)
+        # ... then ONE call for all remaining samples: the pool lives for the whole call, every tile gets all its samples
+        spp = int(max(1, min(63, budget_s / max(t1, 1e-3))))
+        r.ResetStats()
+        t = r.render_tiled_mt(s, 32, spp, threads)
+        st = r.GetStats()
+        tot = float(sum(st.values())) or 1.0
+        return {"value": wl["w"] * wl["h"] * spp / t / 1e6, "unit": "Msamples/s", "cores": threads,
                 "kind": "reference",
-                "sample": f"{kind} backend of the reference (oracle/_ref), {wl['w']}x{wl['h']}, {spp_done} spp, "
-                          f"{threads} threads x 32x32 tiles, {t_total:.1f} s"}
+                "sample": f"{kind} backend of the reference (oracle/_ref), {wl['w']}x{wl['h']}, {spp} spp in one call after a "
+                          f"1-spp warm-up ({t1:.2f} s), {threads} threads x 32x32 tiles, {t:.1f} s",
+                "host": {"cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota},
+                "first_spp_value": wl["w"] * wl["h"] / t1 / 1e6,
+                "stage_share": {k: round(v / tot, 4) for k, v in st.items() if v}}
     except Exception as e:  # the baseline is informational: never fail the bench because of it
         return {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+
+
+def parity_check(ctx, wl):
+    """the benchmarked workload against the oracle, outside the timed region: iteration 1 of the full frame rendered by
+    RendererRef (scalar reference backend, all usable cores, tiles) and by the HIP path, compared in the stated tolerance
+    (tests/util.py: >= 99.5 % of pixels within 1e-3 * max(1, |ref|), PSNR >= 55 dB at 1 spp)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import oracle_lib as O
+        import util
+        from ray_amd import hip
+        if not O.have_ref():
+            return None
+        threads, _ = usable_cpus()
+        r = O.create_renderer(wl["w"], wl["h"], "REF")
+        s = r.CreateScene()
+        build_scene(s, wl)
+        t = r.render_tiled_mt(s, 32, 1, threads)
+        ref = r.get_raw_pixels_ref()
+        ctx.clear()
+        ctx.render(1)
+        m = util.frame_metrics(ctx.readback(hip.BUF_RAW), ref)
+        m.update({"against": "RendererRef (oracle/_ref), iteration 1, full frame", "ref_render_s": t,
+                  "pass": bool(m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_1SPP)})
+        return m
+    except Exception as e:
+        return {"pass": False, "error": str(e)}
 
 
 def main():
@@ -194,7 +259,7 @@ def main():
             ctx.render_batch(it + 1, n)
             it, done = it + n, done + n
     if dist is not None:  # warm the communicator too
-        ctx.readback_device(hip.BUF_RAW, frame.data_ptr())
+        ctx.export_shard_device(hip.BUF_RAW, frame.data_ptr())
         dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
     ctx.sync()
     ctx.trav_timing(reset=True)
@@ -207,6 +272,8 @@ def main():
     multigpu.render_sharded(ctx, range(it + 1, it + 1 + K), rank, world, dist=dist, frame=frame,
                             flags=hip.FLAG_TIME_STAGES, tile=TILE, batch=batch)
     it += K
+    if dist is None:  # what the reduce is at N > 1: the finished frame leaves the GPU once per image
+        host_frame = ctx.readback(hip.BUF_RAW)
     ctx.sync()
     torch.cuda.synchronize()
     barrier()
@@ -219,29 +286,35 @@ def main():
     (k2_ms, k2_launches), (k3_ms, k3_launches) = ctx.trav_timing(reset=True)
     stages = ctx.stage_times(reset=True)
 
-    # algorithmic bytes of the traversal kernels: instrumented variant on the next iterations of the same workload
-    n_count = max(1, min(K, 4))
-    ctx.trav_counters(reset=True)
-    for _ in range(n_count):
-        it += 1
-        ctx.render(it, flags=hip.FLAG_COUNT_TRAVERSAL)
-    c2, c3 = ctx.trav_counters(reset=True)
+    # algorithmic bytes of the traversal kernels: instrumented variants on the next iterations of the same workload --
+    # first the product kernels with counters (their own bytes), then the reference's BVH2 walk on the same rays
+    n_count = max(1, min(K, 2))
     scale = K / n_count
-    k2_bytes = ((72 + 20 + 4) * c2["rays"] + 64 * c2["nodes"] + 48 * c2["tris"] + 144 * c2["instances"]) * scale
-    k3_bytes = ((48 + 32) * c3["rays"] + 64 * c3["nodes"] + 48 * c3["tris"] + 144 * c3["instances"]) * scale
 
-    if dist is not None:  # whole-job traversal figures: sum over ranks
-        v = torch.tensor([k2_bytes, k2_ms, k2_launches, k3_bytes, k3_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
-        vmax = v.clone()
-        dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
-        k2_bytes_all, k2_ms_max = float(v[0]), float(vmax[1])
-    else:
-        k2_bytes_all, k2_ms_max = k2_bytes, k2_ms
+    def count_pass(flag):
+        nonlocal it
+        ctx.trav_counters(reset=True)
+        for _ in range(n_count):
+            it += 1
+            ctx.render(it, flags=flag)
+        return ctx.trav_counters(reset=True)
+
+    def alg_bytes(c, per_ray):
+        return (per_ray * c["rays"] + 64 * (c["nodes"] + c.get("nodes4", 0)) + 48 * c["tris"] + 144 * c["instances"]) * scale
+
+    w2, w3 = count_pass(hip.FLAG_COUNT_WIDE)
+    c2, c3 = count_pass(hip.FLAG_COUNT_TRAVERSAL)
+    k2_bytes, k3_bytes = alg_bytes(w2, 72 + 20 + 4), alg_bytes(w3, 48 + 32)          # the kernels' own
+    k2_bytes_ref, k3_bytes_ref = alg_bytes(c2, 72 + 20 + 4), alg_bytes(c3, 48 + 32)  # the reference algorithm's
 
     if rank == 0:
         samples = W * H * K
-        achieved = (k2_bytes / 1e9) / (k2_ms / 1e3) if k2_ms > 0 else 0.0  # this rank's GPU: GB/s inside K2
+        launches = max(k2_launches, 1)
+        k2_s = k2_ms / 1e3
+        alg_gbs = (k2_bytes / 1e9) / k2_s if k2_s > 0 else 0.0          # the kernel's own algorithmic bytes per second
+        traffic = measured_traffic(args.workload, K, batch) if world == 1 else None
+        hbm_gbs = (traffic["bytes_per_launch"] * launches / 1e9) / k2_s if (traffic and k2_s > 0) else None
+        achieved = hbm_gbs if hbm_gbs is not None else alg_gbs
         out = {
             "metric": "Msamples/sec (W*H*spp/time)",
             "value": samples / dt / 1e6,
@@ -261,19 +334,26 @@ def main():
                        "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 RCCL reduce/frame)",
                        "iterations_per_pass": batch},
             "roofline": {
-                "bound": "hbm", "kernel": "k_trace_closest<false,true> (closest-hit traversal, K2); algorithmic bytes = "
-                                          "reference BVH2 visit counts on the same rays (SURVEY 8d)",
+                "bound": "hbm", "kernel": "k_trace_closest<false,true> (closest-hit traversal, K2)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "frac_note": "algorithmic bytes are those of the reference's BVH2 walk (64 B/node visit, 48 B/triangle test); the "
-                             "kernel walks a 4-wide quantised tree out of L1/L2, so frac > 1 means it finishes the reference's "
-                             "traversal faster than HBM could stream it -- see traffic for what actually left L2",
-                "traffic": measured_traffic(args.workload, batch),
-                "alg_bytes_per_launch": k2_bytes / max(k2_launches, 1), "avg_launch_ms": k2_ms / max(k2_launches, 1),
-                "launches": k2_launches,
-                "alg_bytes_per_ray": k2_bytes / scale / max(c2["rays"], 1),
-                "nodes_per_ray": c2["nodes"] / max(c2["rays"], 1), "tris_per_ray": c2["tris"] / max(c2["rays"], 1),
+                "achieved_is": ("HBM traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE of a profiled run of this command) / launch time"
+                                if hbm_gbs is not None else
+                                "the kernel's own algorithmic bytes / launch time (no PMC profile of this configuration is committed)"),
+                "traffic": traffic["bytes_per_launch"] if traffic else None,
+                "traffic_detail": traffic,
+                "avg_launch_ms": k2_ms / launches, "launches": k2_launches,
+                "algorithmic": {
+                    "bytes_per_launch": k2_bytes / launches, "GBps": alg_gbs, "frac_of_peak": alg_gbs / HBM_PEAK_GBS,
+                    "bytes_per_ray": k2_bytes / scale / max(w2["rays"], 1),
+                    "tlas_nodes_per_ray": w2["nodes"] / max(w2["rays"], 1), "nodes4_per_ray": w2["nodes4"] / max(w2["rays"], 1),
+                    "tris_per_ray": w2["tris"] / max(w2["rays"], 1),
+                    "reference_bvh2": {"bytes_per_launch": k2_bytes_ref / launches,
+                                       "bytes_per_ray": k2_bytes_ref / scale / max(c2["rays"], 1),
+                                       "nodes_per_ray": c2["nodes"] / max(c2["rays"], 1), "tris_per_ray": c2["tris"] / max(c2["rays"], 1),
+                                       "note": "what the reference's BVH2 walk would move for the same rays; not a rate of this kernel"},
+                },
                 "rays_per_sample": c2["rays"] / (n_count * W * H / world),
-                "shadow_kernel": {"achieved": (k3_bytes / 1e9) / (k3_ms / 1e3) if k3_ms > 0 else 0.0,
+                "shadow_kernel": {"algorithmic_GBps": (k3_bytes / 1e9) / (k3_ms / 1e3) if k3_ms > 0 else 0.0,
                                   "avg_launch_ms": k3_ms / max(k3_launches, 1),
                                   "rays_per_sample": c3["rays"] / (n_count * W * H / world)},
             },
@@ -282,6 +362,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
+            out["parity"] = parity_check(ctx, wl)
         else:
             out["cpu_baseline"] = None
         line = json.dumps(out)

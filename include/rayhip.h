@@ -264,6 +264,7 @@ typedef struct rayhip_trav_counters {
     unsigned long long tris;      /* triangles tested (48 B each) */
     unsigned long long instances; /* mesh instances entered (144 B each) */
     unsigned long long max_stack; /* deepest traversal-stack use seen (entries per ray; not a sum) */
+    unsigned long long nodes4;    /* 4-wide quantised BLAS nodes fetched (64 B each): RAYHIP_FLAG_COUNT_WIDE only */
 } rayhip_trav_counters;
 
 typedef struct rayhip_ctx rayhip_ctx;
@@ -272,14 +273,20 @@ enum {
     RAYHIP_BUF_FINAL = 0,        /* tonemapped, RendererBase::get_pixels_ref (RendererBase.h:152) */
     RAYHIP_BUF_RAW = 1,          /* linear running mean, get_raw_pixels_ref (RendererBase.h:157) */
     RAYHIP_BUF_BASE_COLOR = 2,   /* get_aux_pixels_ref(eAUXBuffer::BaseColor) */
-    RAYHIP_BUF_DEPTH_NORMALS = 3 /* get_aux_pixels_ref(eAUXBuffer::DepthNormals) */
+    RAYHIP_BUF_DEPTH_NORMALS = 3, /* get_aux_pixels_ref(eAUXBuffer::DepthNormals) */
+    RAYHIP_BUF_VARIANCE = 4       /* per-pixel variance estimate of the last accumulate (what the reference leaves in its temp
+                                     buffer for DenoiseImage, RendererCPU.h:641-645) */
 };
 
 enum {
     RAYHIP_FLAG_SORT_RAYS = 1u << 0,     /* ray sort between bounces (RendererVK.cpp:641-652) */
     RAYHIP_FLAG_COUNT_TRAVERSAL = 1u << 1, /* run the instrumented traversal kernels (slower) */
-    RAYHIP_FLAG_TIME_STAGES = 1u << 2      /* record HIP events around every stage WITHOUT synchronising; read the
+    RAYHIP_FLAG_TIME_STAGES = 1u << 2,     /* record HIP events around every stage WITHOUT synchronising; read the
                                               result later with rayhip_get_stage_times / rayhip_get_trav_timing */
+    RAYHIP_FLAG_COUNT_WIDE = 1u << 3       /* run the PRODUCT traversal kernels (4-wide quantised BLAS) with visit counters:
+                                              nodes = TLAS BVH2 nodes, nodes4 = 4-wide nodes, tris, instances -- the
+                                              kernel's own algorithmic bytes (COUNT_TRAVERSAL counts the reference's BVH2
+                                              walk on the same rays instead).  Wins over COUNT_TRAVERSAL. */
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -373,6 +380,38 @@ RAYHIP_API int rayhip_readback_device(rayhip_ctx *ctx, int which, void *dst_devi
 RAYHIP_API int rayhip_set_raw_device(rayhip_ctx *ctx, const void *src_device_rgba, int pitch_px,
                                      const rayhip_camera *cam);
 
+/* ---- multi-GPU: the frame exchange behind the C ABI (new, the reference has no multi-GPU mode) ----
+ * N contexts (one per GPU) render the tiles rayhip_set_shard deals them; ONE ncclReduce(sum, fp32) over RCCL/xGMI then
+ * assembles the frame on `root`.  Every rank contributes only the pixels it owns (zero elsewhere), so the result equals a
+ * single-GPU render bit for bit and the call can be repeated after more iterations (progressive refinement).
+ *   rayhip_comm_create            one process drives all `ndev` GPUs (ncclCommInitAll): what a C++ host using RendererHIP does
+ *   rayhip_comm_unique_id +       one process per GPU: rank 0 makes the id, hands its RAYHIP_COMM_ID_BYTES bytes to the other
+ *   rayhip_comm_create_rank       processes by its own means, every process creates its rank (ncclCommInitRank) -- collective
+ *   rayhip_comm_bind              attach the context of `rank` (a GPU of `devices[rank]`); also sets its shard to (tile, N, rank)
+ *   rayhip_comm_reduce_framebuffers   `what`: RAYHIP_REDUCE_* mask, 0 = all four images.  On return the root context holds the
+ *                                 combined running mean (RAW, and FINAL re-tonemapped with `cam`), aux images and variance
+ *                                 estimate, i.e. everything DenoiseImage reads.  Blocking (synchronises the local streams).
+ * RCCL is loaded on first use (dlopen librccl.so.1; RAYHIP_RCCL_LIB overrides); librayhip itself does not link it. */
+typedef struct rayhip_comm rayhip_comm;
+#define RAYHIP_COMM_ID_BYTES 128
+enum {
+    RAYHIP_REDUCE_RADIANCE = 1u << 0,
+    RAYHIP_REDUCE_BASE_COLOR = 1u << 1,
+    RAYHIP_REDUCE_DEPTH_NORMALS = 1u << 2,
+    RAYHIP_REDUCE_VARIANCE = 1u << 3,
+    RAYHIP_REDUCE_ALL = 15u
+};
+RAYHIP_API int rayhip_comm_create(int ndev, const int *devices, rayhip_comm **out_comm);
+RAYHIP_API int rayhip_comm_unique_id(void *out_id, size_t size);
+RAYHIP_API int rayhip_comm_create_rank(const void *unique_id, int nranks, int rank, rayhip_ctx *ctx, rayhip_comm **out_comm);
+RAYHIP_API int rayhip_comm_bind(rayhip_comm *comm, int rank, rayhip_ctx *ctx);
+RAYHIP_API int rayhip_comm_reduce_framebuffers(rayhip_comm *comm, int root, uint32_t what, const rayhip_camera *cam);
+RAYHIP_API void rayhip_comm_destroy(rayhip_comm *comm);
+/* The pack step alone for hosts that bring their own collective: this rank's OWNED pixels of image `which`
+ * (RAYHIP_BUF_RAW = the running mean, BASE_COLOR, DEPTH_NORMALS, VARIANCE), zero elsewhere, tightly packed [h][w][4] into
+ * DEVICE memory.  Sum over ranks = the frame; hand it to the root with rayhip_set_raw_device. */
+RAYHIP_API int rayhip_export_shard_device(rayhip_ctx *ctx, int which, void *dst_device_rgba);
+
 RAYHIP_API int rayhip_sync(rayhip_ctx *ctx);
 
 /* traversal counters accumulated by RAYHIP_FLAG_COUNT_TRAVERSAL renders since the last reset:
@@ -400,6 +439,15 @@ RAYHIP_API int rayhip_k_intersect_closest(rayhip_ctx *ctx, const rayhip_camera *
 RAYHIP_API int rayhip_k_intersect_shadow(rayhip_ctx *ctx, const rayhip_camera *cam,
                                          const rayhip_shadow_ray *rays, int count, int iteration,
                                          float *out_rc, rayhip_trav_counters *out_counters /* may be NULL */);
+/* Ref::ShadePrimary (bounce 0) / Ref::ShadeSecondary (bounce >= 1) (ShadeRef.cpp:1654-1738, i.e. ShadeSurface
+ * :1174-1652 per ray) on `count` host (ray, hit) pairs -- the oracle's twin is oracle/ref_shim.cpp: refk_shade.
+ * inout_color: the per-iteration radiance image [h][w][4] (bounce 0 assigns the pixels of the rays, later bounces add).
+ * out_secondary / out_shadow: room for `count` rays each; the emitted rays come back in no particular order (every
+ * pixel emits at most one of each: compare after sorting by xy).  Runs the kernels rayhip_render launches; bounce 0
+ * also blends the aux images of the context like a first-bounce shade does. */
+RAYHIP_API int rayhip_k_shade(rayhip_ctx *ctx, const rayhip_camera *cam, int bounce, int iteration, const rayhip_ray *rays,
+                              const rayhip_hit *hits, int count, float *inout_color, rayhip_ray *out_secondary,
+                              int *out_secondary_count, rayhip_shadow_ray *out_shadow, int *out_shadow_count);
 /* Ref::get_scrambled_2d_rand (CoreRef.cpp:1418-1427) for `count` (dim,seed,sample) triples */
 RAYHIP_API int rayhip_k_scrambled_rand(rayhip_ctx *ctx, const uint32_t *dims, const uint32_t *seeds,
                                        const int32_t *samples, int count, float *out_xy);

@@ -220,6 +220,7 @@ def declare(lib):
         "ray_renderer_get_stats": (None, [vp, C.POINTER(Stats)]),
         "ray_renderer_reset_stats": (None, [vp]),
         "ray_renderer_render_tiled_mt": (C.c_double, [vp, vp, C.c_int, C.c_int, C.c_int]),
+        "ray_renderer_render_tiled_from": (C.c_double, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "ray_region_create": (vp, [C.c_int, C.c_int, C.c_int, C.c_int]),
         "ray_region_destroy": (None, [vp]),
         "ray_region_iteration": (C.c_int, [vp]),

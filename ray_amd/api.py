@@ -365,9 +365,10 @@ class RendererBase:
     def ResetStats(self):
         self._lib.ray_renderer_reset_stats(self._ptr)
 
-    def render_tiled_mt(self, scene: SceneBase, tile: int, spp: int, threads: int) -> float:
-        """README.md:336-356 multithreading pattern; returns wall seconds (CPU backends only)."""
-        return float(self._lib.ray_renderer_render_tiled_mt(self._ptr, scene._ptr, tile, spp, threads))
+    def render_tiled_mt(self, scene: SceneBase, tile: int, spp: int, threads: int, iterations_done: int = 0) -> float:
+        """README.md:336-356 multithreading pattern: `threads` workers pull tile x tile regions from a queue and run `spp`
+        iterations on each, continuing after `iterations_done`; returns wall seconds (CPU backends only)."""
+        return float(self._lib.ray_renderer_render_tiled_from(self._ptr, scene._ptr, tile, iterations_done, spp, threads))
 
 
 _LIBS = {}

@@ -321,9 +321,21 @@ __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint
     }
 }
 
+// instrumented builds: fold one ray's visit counts into the per-kernel totals (TRAV_COUNTER_WORDS u64 per kernel)
+constexpr int TRAV_COUNTER_WORDS = 6;
+__device__ __forceinline__ void flush_trav_count(unsigned long long *__restrict__ counters, const TravCount &tc) {
+    atomicAdd(&counters[0], 1ull);
+    atomicAdd(&counters[1], (unsigned long long)tc.nodes);
+    atomicAdd(&counters[2], (unsigned long long)tc.tris);
+    atomicAdd(&counters[3], (unsigned long long)tc.instances);
+    atomicMax(&counters[4], (unsigned long long)tc.max_stack);
+    atomicAdd(&counters[5], (unsigned long long)tc.nodes4);
+}
+
 // ---- K2 ---------------------------------------------------------------------------------------------------
 // One ray per lane; grid-stride over the device-resident ray count.
-// COUNT: instrumented walk of the reference's BVH2 (visit counters = algorithmic bytes); WIDE: 4-wide BLAS (rt_bvh4.h)
+// COUNT: with visit counters; WIDE: 4-wide BLAS (rt_bvh4.h).  <true, false> = instrumented walk of the reference's BVH2
+// (counters = the reference algorithm's bytes), <true, true> = the product walk with counters (its OWN algorithmic bytes)
 // MINW: occupancy hint.  The default (6 waves/SIMD, 80 VGPRs, some spills outside the hot loop) is best when node and
 // triangle fetches miss the caches; a scene that fits L2 (RT_TRACE_SMALL_WAVES = 5: 96 VGPRs, fewer spills) has little
 // latency to hide and runs 15 % faster in K2 with the smaller footprint (Cornell: 0.42 -> 0.35 ms per iteration).
@@ -372,7 +384,7 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
         st.lane_base = &lds_stack[lane];
         st.spill_base = stack_spill + size_t(blockIdx.x) * size_t(STACK_SPILL_DEPTH * WAVE) + lane;
         st.size = 0;
-        TravCount tc = {0, 0, 0, 0};
+        TravCount tc = {0, 0, 0, 0, 0};
         RT_PROF_T(25)
         const uint32_t xy_virtual = r.xy, layer = xy_layer(xy_virtual, layers);
         if (layer == 0) {
@@ -396,11 +408,7 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
             rays.xy_depth[i] = xd;
         }
         if (COUNT) {
-            atomicAdd(&counters[0], 1ull);
-            atomicAdd(&counters[1], (unsigned long long)tc.nodes);
-            atomicAdd(&counters[2], (unsigned long long)tc.tris);
-            atomicAdd(&counters[3], (unsigned long long)tc.instances);
-            atomicMax(&counters[4], (unsigned long long)tc.max_stack);
+            flush_trav_count(counters, tc);
         }
     }
 #ifdef RT_PROFILE_TRACE
@@ -700,7 +708,7 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_shadow(const SceneView sc,
         st.lane_base = &lds_stack[lane];
         st.spill_base = stack_spill + size_t(blockIdx.x) * size_t(STACK_SPILL_DEPTH * WAVE) + lane;
         st.size = 0;
-        TravCount tc = {0, 0, 0, 0};
+        TravCount tc = {0, 0, 0, 0, 0};
         f3 rc;
         const uint32_t layer = xy_layer(r.xy, layers);
         if (layer == 0) {
@@ -719,11 +727,7 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_shadow(const SceneView sc,
             add_shadow_pixel(rc, limit, r.xy, img_w, temp_buf);
         }
         if (COUNT) {
-            atomicAdd(&counters[0], 1ull);
-            atomicAdd(&counters[1], (unsigned long long)tc.nodes);
-            atomicAdd(&counters[2], (unsigned long long)tc.tris);
-            atomicAdd(&counters[3], (unsigned long long)tc.instances);
-            atomicMax(&counters[4], (unsigned long long)tc.max_stack);
+            flush_trav_count(counters, tc);
         }
     }
 }
@@ -962,6 +966,22 @@ __global__ void __launch_bounds__(256) k_retonemap(const AccumParams p, const Pi
         px.raw[i] = ff;
         const f4 c = tonemap(p, f4{ff.x, ff.y, ff.z, ff.w});
         px.final_[i] = mkfloat4(c.x, c.y, c.z, c.w);
+    }
+}
+
+// ---- multi-GPU frame exchange (rayhip_comm_reduce_framebuffers, rayhip_export_shard_device) -----------------------------
+// pack: this rank's OWNED pixels of one image, zero elsewhere -- whatever a buffer holds on pixels of other ranks (the
+// clear colour, the combined frame of an earlier reduce) never enters the sum
+__global__ void __launch_bounds__(256) k_pack_owned(const float4 *__restrict__ src, float4 *__restrict__ dst, const int w, const int h,
+                                                   const Shard shard) {
+    const int n = w * h;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        dst[i] = pixel_owned(shard, w, i % w, i / w) ? src[i] : mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+__global__ void __launch_bounds__(256) k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, const size_t n) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        dst[i] = src[i];
     }
 }
 

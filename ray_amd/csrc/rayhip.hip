@@ -20,6 +20,7 @@
 #include "bvh4_build.h"
 #include "bvh_layout.h"
 #include "scene_blob.h"
+#include "scene_validate.h"
 #include "sort.h"
 
 using namespace rt;
@@ -96,6 +97,10 @@ struct rayhip_ctx {
     size_t slots_cap = 0; // wavefront-state slots allocated
     DevBuf px_variance, nlm_tm, nlm_var_h, nlm_var; // DenoiseImage: variance estimate [h][w]; [ext_h][ext_w] intermediates
     DevBuf tonemap_lut;   // table of view transform `lut_transform` (rayhip_set_tonemap_lut)
+    DevBuf shard_stage;   // [4][h][w] float4: this rank's owned pixels of full / base colour / depth-normals / variance, zero elsewhere
+                          // (what the multi-GPU frame reduce sums; rayhip_comm_reduce_framebuffers, rayhip_export_shard_device)
+    bool adaptive_dirty = false; // a pass ran with variance_threshold != 0 since the last Clear / Resize: required_samples may
+                                 // lie below the next iteration, so passes are not batched (rayhip_render_batch)
     int lut_transform = 0, lut_dims = 0;
     PixelBuffers px = {};
 
@@ -106,7 +111,7 @@ struct rayhip_ctx {
     ShadowSoA shadow = {};
     DeferredSoA deferred = {};
     DevBuf counters;      // uint32 [MAX_BOUNCE_SLOTS][2: rays, shadow rays][QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE]
-    DevBuf trav_counters; // u64 [2][5]
+    DevBuf trav_counters; // u64 [2][TRAV_COUNTER_WORDS]
     DevBuf stack_spill;   // per-wave overflow slabs of the traversal stack
     DevBuf sort_keys[2], sort_idx[2], sort_temp;
     SortGrid sort_grid = {};
@@ -211,7 +216,9 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
     // never less than one full frame: the kernel-level hooks and single-iteration passes of any shard fit) + the
     // rounding of the striped queues (each stripe holds whole chunks)
     const size_t n = std::max(tile_slots(w, h), pass_slots(c, w, h, w, h, layers)) + size_t(WAVE) * QUEUE_MAX_STRIPES;
-    c->slots_cap = std::max(c->slots_cap, n); // (DevBuf never shrinks)
+    // (slots_cap is raised only after every plane below exists: a failed hipMalloc must not make pass_fits() lie)
+    const size_t old_cap = c->slots_cap;
+    c->slots_cap = 0;
     for (int k = 0; k < 2; ++k) {
         for (int pl = 0; pl < 5; ++pl) {
             if (c->ray_planes[k][pl].alloc(n * (pl == 4 ? 8 : 16))) {
@@ -247,6 +254,7 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
         c->sort_idx[1].alloc(n_sort * 4) || c->sort_temp.alloc(temp_bytes)) {
         return 1;
     }
+    c->slots_cap = std::max(old_cap, n); // (DevBuf never shrinks)
     return 0;
 }
 
@@ -385,11 +393,11 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         delete c;
         return 1;
     }
-    if (c->counters.alloc(sizeof(uint32_t) * 3 * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 10)) {
+    if (c->counters.alloc(sizeof(uint32_t) * 3 * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS)) {
         delete c;
         return 1;
     }
-    (void)hipMemsetAsync(c->trav_counters.p, 0, 80, c->stream);
+    (void)hipMemsetAsync(c->trav_counters.p, 0, sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS, c->stream);
     *out_ctx = c;
     return 0;
 }
@@ -406,9 +414,10 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
     DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
                      &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->light_tri_geom, &c->tri_verts, &c->nodes4, &c->blas_root4, &c->env_qtree,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
-                     &c->px_dn, &c->px_req, &c->px_aux_base, &c->px_aux_dn, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
+                     &c->px_dn, &c->px_req, &c->px_aux_base, &c->px_aux_dn, &c->px_variance, &c->nlm_tm, &c->nlm_var_h, &c->nlm_var,
+                     &c->tonemap_lut, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
                      &c->shadow_planes[2], &c->deferred_planes[0], &c->deferred_planes[1], &c->counters, &c->trav_counters, &c->stack_spill,
-                     &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->sort_temp};
+                     &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->sort_temp, &c->shard_stage};
     for (DevBuf *b : all) {
         b->release();
     }
@@ -468,6 +477,7 @@ int rayhip_resize(rayhip_ctx *c, int w, int h) {
     k_fill_u16<<<grid_for(c, n, 256), 256, 0, c->stream>>>(c->px.required_samples, uint16_t(0xffff), n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->adaptive_dirty = false;
     return 0;
 }
 
@@ -485,6 +495,7 @@ int rayhip_clear(rayhip_ctx *c, const float rgba[4]) {
     k_fill_f4<<<grid_for(c, n, 256), 256, 0, c->stream>>>(c->px.half, v, n);
     k_fill_u16<<<grid_for(c, n, 256), 256, 0, c->stream>>>(c->px.required_samples, uint16_t(0xffff), n);
     HIP_TRY(hipGetLastError());
+    c->adaptive_dirty = false;
     return 0;
 }
 
@@ -521,6 +532,13 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             return fail("env_qtree holds %u floats, %d levels need %zu", d->env_qtree_count, d->env.qtree_levels, quads * 4);
         }
     }
+    { // every index a kernel would follow without a bound of its own (scene_validate.h)
+        std::string why;
+        if (!rayhip_validate::validate(*d, why)) {
+            return fail("%s", why.c_str());
+        }
+    }
+    UPLOAD_TRACE("validated")
     HIP_TRY(hipStreamSynchronize(c->stream));
 #define UP(field)                                                                                                      \
     if (upload(c, c->field, d->field, size_t(d->field##_count) * sizeof(*d->field))) {                                 \
@@ -740,7 +758,13 @@ static bool pass_fits(const rayhip_ctx *c, const int rect[4], int n) {
            pass_slots(c, c->w, c->h, rect[2], rect[3], n) + size_t(WAVE) * QUEUE_MAX_STRIPES <= c->slots_cap;
 }
 // grow the per-iteration pixel buffers / the wavefront state if a pass of `n` iterations over `rect` needs more
+static bool rect_inside(const rayhip_ctx *c, const int rect[4]) {
+    return rect[0] >= 0 && rect[1] >= 0 && rect[2] > 0 && rect[3] > 0 && rect[0] <= c->w - rect[2] && rect[1] <= c->h - rect[3];
+}
 static int ensure_pass(rayhip_ctx *c, const int rect[4], int n) {
+    if (!rect_inside(c, rect)) { // before anything is (re)allocated for it
+        return fail("rect outside the frame");
+    }
     if (!pass_fits(c, rect, n)) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (alloc_frame(c, c->w, c->h, n)) {
@@ -748,6 +772,29 @@ static int ensure_pass(rayhip_ctx *c, const int rect[4], int n) {
         }
     }
     return 0;
+}
+
+// K5 of one bounce: shade the rays of queue `bounce` in ray buffer `cur` -> secondary rays into queue bounce + 1 of the
+// other ray buffer, shadow rays into shadow queue `bounce`, radiance into the per-iteration pixel buffer.  One place for
+// rayhip_render and the kernel-level hook rayhip_k_shade.
+static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration, int bounce, int cur, size_t nslots, uint32_t stripes,
+                         int gtrace, int vw, float mix_factor, const Layering &layers) {
+    hipStream_t s = c->stream;
+    const ShadeParams sp = make_shade_params(cam, iteration, bounce);
+    if (bounce == 0) {
+        k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
+                                              c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
+                                              c->shadow_queue(bounce, nslots, stripes), c->deferred,
+                                              c->deferred_queue(bounce, nslots, stripes), c->px, vw, mix_factor, layers);
+    } else {
+        k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
+                                               c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
+                                               c->shadow_queue(bounce, nslots, stripes), c->deferred,
+                                               c->deferred_queue(bounce, nslots, stripes), c->px, vw, mix_factor, layers);
+        // emitter hits whose MIS weight was deferred (kernels.hip.h); an empty queue costs a few microseconds
+        k_shade_emissive<<<std::min(gtrace, 2048), WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred,
+                                                                 c->deferred_queue(bounce, nslots, stripes), c->px, vw);
+    }
 }
 
 // One wavefront pass over `count` consecutive iterations of the rect (count == 1: the plain case; > 1: layered, see
@@ -769,15 +816,19 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     if (cam->view_transform != 0 /* eViewTransform::Standard */ && cam->view_transform != c->lut_transform) {
         return fail("view transform %d needs its look-up table: rayhip_set_tonemap_lut", int(cam->view_transform));
     }
-    if (rect[0] < 0 || rect[1] < 0 || rect[2] <= 0 || rect[3] <= 0 || rect[0] + rect[2] > c->w || rect[1] + rect[3] > c->h) {
+    if (!rect_inside(c, rect)) {
         return fail("rect outside the frame");
     }
     const int max_depth = cam->pass_settings.max_total_depth;
     if (max_depth + 2 > MAX_BOUNCE_SLOTS) {
         return fail("max_total_depth too large");
     }
-    const bool count = (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) != 0;
+    const bool count_wide = (flags & RAYHIP_FLAG_COUNT_WIDE) != 0;
+    const bool count = !count_wide && (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) != 0;
     const bool sort_rays = (flags & RAYHIP_FLAG_SORT_RAYS) != 0;
+    if (cam->pass_settings.variance_threshold != 0.0f) {
+        c->adaptive_dirty = true;
+    }
     hipStream_t s = c->stream;
     const size_t npix = size_t(rect[2]) * size_t(rect[3]);
     const Layering layers = make_layering(c->w, c->h, count_iterations);
@@ -798,7 +849,9 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     const uint32_t stripes = sort_rays ? 1u : QUEUE_MAX_STRIPES;
     // K2 launcher (instrumented variant on request)
     auto launch_closest = [&](const RaySoA &r, const RayQueue &q, int init_hits) {
-        if (count) {
+        if (count_wide && c->sc.nodes4) {
+            k_trace_closest<true, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
+        } else if (count) {
             k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else if (c->sc.nodes4 && c->refill_waves) {
             k_trace_closest_refill<<<std::min(gtrace, c->refill_waves), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
@@ -860,21 +913,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         if (tm.mark(bounce == 0 ? ST_PSHADE : ST_SSHADE, -1)) {
             return 1;
         }
-        const ShadeParams sp = make_shade_params(*cam, iteration, bounce);
-        if (bounce == 0) {
-            k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
-                                                  c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
-                                                  c->shadow_queue(bounce, nslots, stripes), c->deferred,
-                                                  c->deferred_queue(bounce, nslots, stripes), c->px, vw, mix_factor, layers);
-        } else {
-            k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
-                                                   c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
-                                                   c->shadow_queue(bounce, nslots, stripes), c->deferred,
-                                                   c->deferred_queue(bounce, nslots, stripes), c->px, vw, mix_factor, layers);
-            // emitter hits whose MIS weight was deferred (kernels.hip.h); an empty queue costs a few microseconds
-            k_shade_emissive<<<std::min(gtrace, 2048), WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred,
-                                                     c->deferred_queue(bounce, nslots, stripes), c->px, vw);
-        }
+        launch_shade(c, *cam, iteration, bounce, cur, nslots, stripes, gtrace, vw, mix_factor, layers);
         if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
             return 1;
         }
@@ -882,18 +921,21 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         if (c->sc.blocker_lights_count != 0) {
             k_shadow_blockers<<<gtrace, WAVE, 0, s>>>(c->sc, c->shadow, c->shadow_queue(bounce, nslots, stripes));
         }
-        if (count) {
+        if (count_wide && c->sc.nodes4) {
+            k_trace_shadow<true, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
+                                                               vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
+        } else if (count) {
             k_trace_shadow<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                vw, c->px.temp, nullptr, spill, tc + 5, layers);
+                                                                vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
         } else if (c->sc.nodes4 && c->small_scene) {
             k_trace_shadow<false, true, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes),
-                                                                                      limit, vw, c->px.temp, nullptr, spill, tc + 5, layers);
+                                                                                      limit, vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
         } else if (c->sc.nodes4) {
             k_trace_shadow<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                vw, c->px.temp, nullptr, spill, tc + 5, layers);
+                                                                vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
         } else {
             k_trace_shadow<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                 vw, c->px.temp, nullptr, spill, tc + 5, layers);
+                                                                 vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
         }
         cur ^= 1;
     }
@@ -961,8 +1003,11 @@ int rayhip_render_batch(rayhip_ctx *c, const rayhip_camera *cam, const int rect[
     }
     // A batch is exact only while adaptive sampling is inert (the reference re-queues every pixel every iteration when
     // variance_threshold == 0); the ray sort works on one dense ray array; pixel rows are 16-bit.
+    // ... and only while no pixel can have required_samples < first_iteration: once an adaptive pass has run, pixels may be
+    // parked; a one-by-one run would wake them up again after the first iteration with threshold 0, a batch would not
+    // (k_raygen decides liveness once per pass).  adaptive_dirty is cleared by Clear / Resize.
     int max_layers = rayhip_max_batch(c);
-    if (cam->pass_settings.variance_threshold != 0.0f || (flags & RAYHIP_FLAG_SORT_RAYS) != 0) {
+    if (cam->pass_settings.variance_threshold != 0.0f || c->adaptive_dirty || (flags & RAYHIP_FLAG_SORT_RAYS) != 0) {
         max_layers = 1;
     }
     int done = 0;
@@ -1048,6 +1093,8 @@ static float4 *pick_buffer(rayhip_ctx *c, int which) {
         return c->px.base_color;
     case RAYHIP_BUF_DEPTH_NORMALS:
         return c->px.depth_normals;
+    case RAYHIP_BUF_VARIANCE:
+        return c->px.variance;
     default:
         return nullptr;
     }
@@ -1111,12 +1158,12 @@ int rayhip_get_trav_counters(rayhip_ctx *c, rayhip_trav_counters out[2], int res
     if (use_device(c)) {
         return 1;
     }
-    unsigned long long h[10];
+    unsigned long long h[2 * TRAV_COUNTER_WORDS];
     HIP_TRY(hipMemcpyAsync(h, c->trav_counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 2; ++k) {
-        out[k].rays = h[5 * k + 0], out[k].nodes = h[5 * k + 1], out[k].tris = h[5 * k + 2], out[k].instances = h[5 * k + 3];
-        out[k].max_stack = h[5 * k + 4];
+        const unsigned long long *w = h + TRAV_COUNTER_WORDS * k;
+        out[k].rays = w[0], out[k].nodes = w[1], out[k].tris = w[2], out[k].instances = w[3], out[k].max_stack = w[4], out[k].nodes4 = w[5];
     }
     if (reset) {
         HIP_TRY(hipMemsetAsync(c->trav_counters.p, 0, sizeof(h), c->stream));
@@ -1235,13 +1282,15 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     const uint32_t n = uint32_t(count);
     HIP_TRY(hipMemcpyAsync(c->ray_count(0), &n, 4, hipMemcpyHostToDevice, s));
     unsigned long long *tc = c->trav_counters.as<unsigned long long>();
-    unsigned long long before[5], after[5];
+    unsigned long long before[TRAV_COUNTER_WORDS], after[TRAV_COUNTER_WORDS];
     HIP_TRY(hipMemcpyAsync(before, tc, sizeof(before), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemsetAsync(tc, 0, sizeof(before), s));
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     const RayQueue q = c->ray_queue(0, size_t(count), 1);
-    if (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) { // instrumented walk of the reference's BVH2
+    if ((flags & RAYHIP_FLAG_COUNT_WIDE) && c->sc.nodes4) { // the product walk with counters
+        k_trace_closest<true, true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
+    } else if (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) { // instrumented walk of the reference's BVH2
         k_trace_closest<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
     } else if (c->sc.nodes4 && c->refill_waves) { // what rayhip_render launches
         k_trace_closest_refill<<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
@@ -1258,7 +1307,7 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     if (out_counters) {
         out_counters->rays = after[0], out_counters->nodes = after[1];
         out_counters->tris = after[2], out_counters->instances = after[3];
-        out_counters->max_stack = after[4];
+        out_counters->max_stack = after[4], out_counters->nodes4 = after[5];
     }
     HIP_TRY(hipMemcpyAsync(pl[2].data(), c->ray_planes[0][2].p, size_t(count) * 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(xd.data(), c->ray_planes[0][4].p, size_t(count) * 8, hipMemcpyDeviceToHost, s));
@@ -1302,8 +1351,8 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     }
     const uint32_t n = uint32_t(count);
     HIP_TRY(hipMemcpyAsync(c->shadow_count(0), &n, 4, hipMemcpyHostToDevice, s));
-    unsigned long long *tc = c->trav_counters.as<unsigned long long>() + 5;
-    unsigned long long before[5], after[5];
+    unsigned long long *tc = c->trav_counters.as<unsigned long long>() + TRAV_COUNTER_WORDS;
+    unsigned long long before[TRAV_COUNTER_WORDS], after[TRAV_COUNTER_WORDS];
     HIP_TRY(hipMemcpyAsync(before, tc, sizeof(before), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemsetAsync(tc, 0, sizeof(before), s));
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
@@ -1319,10 +1368,88 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     if (out_counters) {
         out_counters->rays = after[0], out_counters->nodes = after[1];
         out_counters->tris = after[2], out_counters->instances = after[3];
-        out_counters->max_stack = after[4];
+        out_counters->max_stack = after[4], out_counters->nodes4 = after[5];
     }
     HIP_TRY(hipMemcpyAsync(out_rc, c->hit_planes[0].p, size_t(count) * 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int rayhip_k_shade(rayhip_ctx *c, const rayhip_camera *cam, int bounce, int iteration, const rayhip_ray *rays, const rayhip_hit *hits,
+                   int count, float *inout_color, rayhip_ray *out_secondary, int *out_secondary_count, rayhip_shadow_ray *out_shadow,
+                   int *out_shadow_count) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->have_scene || !c->pmj.p || !c->w) {
+        return fail("k_shade needs resize + upload_static + scene_upload first");
+    }
+    if (count < 0 || size_t(count) > size_t(c->w) * size_t(c->h)) {
+        return fail("ray count exceeds the wavefront buffers (w*h)");
+    }
+    if (bounce < 0 || bounce + 2 > MAX_BOUNCE_SLOTS || iteration < 1) {
+        return fail("bad bounce / iteration");
+    }
+    hipStream_t s = c->stream;
+    const size_t npix = size_t(c->w) * size_t(c->h);
+    std::vector<float4> pl[4], hp(static_cast<size_t>(count));
+    std::vector<uint2> xd;
+    std::vector<float> hv(static_cast<size_t>(count));
+    rays_to_soa(rays, count, pl, xd);
+    for (int i = 0; i < count; ++i) {
+        float oi, pi;
+        memcpy(&oi, &hits[i].obj_index, 4), memcpy(&pi, &hits[i].prim_index, 4);
+        hp[i] = make_float4(oi, pi, hits[i].t, hits[i].u);
+        hv[i] = hits[i].v;
+    }
+    for (int k = 0; k < 4; ++k) {
+        HIP_TRY(hipMemcpyAsync(c->ray_planes[0][k].p, pl[k].data(), size_t(count) * 16, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipMemcpyAsync(c->ray_planes[0][4].p, xd.data(), size_t(count) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->hit_planes[0].p, hp.data(), size_t(count) * 16, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->hit_planes[1].p, hv.data(), size_t(count) * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->px.temp, inout_color, npix * 16, hipMemcpyHostToDevice, s));
+    if (c->clear_queues(bounce + 2, s)) {
+        return fail("queue counter clear failed");
+    }
+    const uint32_t n = uint32_t(count);
+    HIP_TRY(hipMemcpyAsync(c->ray_count(bounce), &n, 4, hipMemcpyHostToDevice, s));
+    const int g = std::max(1, int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE)));
+    // one dense stripe, so the host sees plain arrays; the kernels are the ones rayhip_render launches
+    launch_shade(c, *cam, iteration, bounce, 0, size_t(count), 1, g, c->w, 1.0f / float(iteration), single_layer(c->w, c->h));
+    HIP_TRY(hipGetLastError());
+    uint32_t n_sec = 0, n_sh = 0;
+    HIP_TRY(hipMemcpyAsync(&n_sec, c->ray_count(bounce + 1), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&n_sh, c->shadow_count(bounce), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(inout_color, c->px.temp, npix * 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < 4; ++k) {
+        pl[k].resize(n_sec);
+        HIP_TRY(hipMemcpyAsync(pl[k].data(), c->ray_planes[1][k].p, size_t(n_sec) * 16, hipMemcpyDeviceToHost, s));
+    }
+    xd.resize(n_sec);
+    HIP_TRY(hipMemcpyAsync(xd.data(), c->ray_planes[1][4].p, size_t(n_sec) * 8, hipMemcpyDeviceToHost, s));
+    std::vector<float4> sp_[3];
+    for (int k = 0; k < 3; ++k) {
+        sp_[k].resize(n_sh);
+        HIP_TRY(hipMemcpyAsync(sp_[k].data(), c->shadow_planes[k].p, size_t(n_sh) * 16, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < n_sec; ++i) {
+        rayhip_ray &r = out_secondary[i];
+        r.o[0] = pl[0][i].x, r.o[1] = pl[0][i].y, r.o[2] = pl[0][i].z, r.pdf = pl[0][i].w;
+        r.d[0] = pl[1][i].x, r.d[1] = pl[1][i].y, r.d[2] = pl[1][i].z, r.cone_width = pl[1][i].w;
+        r.c[0] = pl[2][i].x, r.c[1] = pl[2][i].y, r.c[2] = pl[2][i].z, r.cone_spread = pl[2][i].w;
+        r.ior[0] = pl[3][i].x, r.ior[1] = pl[3][i].y, r.ior[2] = pl[3][i].z, r.ior[3] = pl[3][i].w;
+        r.xy = xd[i].x, r.depth = xd[i].y;
+    }
+    for (uint32_t i = 0; i < n_sh; ++i) {
+        rayhip_shadow_ray &r = out_shadow[i];
+        r.o[0] = sp_[0][i].x, r.o[1] = sp_[0][i].y, r.o[2] = sp_[0][i].z, memcpy(&r.depth, &sp_[0][i].w, 4);
+        r.d[0] = sp_[1][i].x, r.d[1] = sp_[1][i].y, r.d[2] = sp_[1][i].z, r.dist = sp_[1][i].w;
+        r.c[0] = sp_[2][i].x, r.c[1] = sp_[2][i].y, r.c[2] = sp_[2][i].z, memcpy(&r.xy, &sp_[2][i].w, 4);
+    }
+    *out_secondary_count = int(n_sec), *out_shadow_count = int(n_sh);
     return 0;
 }
 
@@ -1369,3 +1496,5 @@ __attribute__((visibility("default"))) int rayhip_tuning_read_profile(rayhip_ctx
 #endif
 
 } // extern "C"
+
+#include "comm.hip.h"

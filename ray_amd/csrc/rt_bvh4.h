@@ -105,8 +105,12 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
 // `cur`, continues with the nearest one that was hit and pushes the others (farthest first), or pops when none was hit.
 template <class Stack>
 RT_HD void bvh4_visit(const Bvh4Node *nodes4, const f3 ro, const f3 inv_d, const float t, Stack &st, uint32_t &cur, uint32_t &tos,
-                      uint32_t &size) {
+                      uint32_t &size, TravCount *cnt = nullptr) {
     uint32_t ref[4], n_hit;
+    if (cnt) {
+        ++cnt->nodes4;
+        cnt->max_stack = size > cnt->max_stack ? size : cnt->max_stack;
+    }
     bvh4_test_node(nodes4, cur, ro, inv_d, t, ref, n_hit);
     if (n_hit == 0) {
         cur = tos;
@@ -144,7 +148,7 @@ RT_HD void bvh4_visit(const Bvh4Node *nodes4, const f3 ro, const f3 inv_d, const
 //     can spill to HBM.
 template <class Stack, class LeafFn>
 RT_HD bool walk_bvh4(const Bvh4Node *nodes4, const uint32_t root, const f3 ro, const f3 inv_d, const float &t_ref, Stack &st,
-                     LeafFn &&leaf) {
+                     LeafFn &&leaf, TravCount *cnt = nullptr) {
     const uint32_t base = st.size;
     uint32_t size = base;
     st.write_at(size++, BVH4_SENTINEL); // second sentinel, so that the read-ahead of a pop never leaves this level
@@ -172,7 +176,7 @@ RT_HD bool walk_bvh4(const Bvh4Node *nodes4, const uint32_t root, const f3 ro, c
 #endif
         if (n_node >= n_leaf) { // weights 2:1, 3:2, 2:3, 1:2 measured: all within 1 % or slower
             if (at_node) {
-                bvh4_visit(nodes4, ro, inv_d, t_ref, st, cur, tos, size);
+                bvh4_visit(nodes4, ro, inv_d, t_ref, st, cur, tos, size, cnt);
             }
         } else if (at_leaf) {
             if (leaf(cur)) {
@@ -191,7 +195,7 @@ RT_HD bool walk_bvh4(const Bvh4Node *nodes4, const uint32_t root, const f3 ro, c
 #else // one ray at a time (host build of the same walk; tests/hostsim)
     for (;;) {
         while ((cur & BVH2_PRIM_COUNT_BITS) == 0 && cur != BVH4_SENTINEL) {
-            bvh4_visit(nodes4, ro, inv_d, t_ref, st, cur, tos, size);
+            bvh4_visit(nodes4, ro, inv_d, t_ref, st, cur, tos, size, cnt);
             RT_PROF_T(19)
         }
         if (cur == BVH4_SENTINEL) {

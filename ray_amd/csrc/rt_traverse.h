@@ -159,7 +159,8 @@ RT_HD bool intersect_tris_any(const f3 ro, const f3 rd, const rayhip_tri_accel *
 
 // Traverse_TLAS_WithStack_ClosestHit(bvh2), CoreRef.cpp:1943-2025 (+ BLAS :2428-2493)
 // WIDE: the BLAS level walks the 4-wide quantised tree (rt_bvh4.h) instead of the reference's BVH2 -- same leaves,
-// same triangle tests, conservative culling; no visit counters (those describe the reference algorithm).
+// same triangle tests, conservative culling.  Counters: `nodes` = BVH2 nodes (TLAS level in the WIDE walk), `nodes4` =
+// 4-wide nodes, so the product kernel's own algorithmic bytes can be stated next to the reference algorithm's.
 template <bool WIDE = false, class Stack>
 RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const uint32_t ray_flags,
                             const uint32_t root_index, Hit &inter, Stack &st, TravCount *cnt) {
@@ -188,7 +189,7 @@ RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const
                 return false;
             };
             if (WIDE) {
-                walk_bvh4(sc.nodes4, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn);
+                walk_bvh4(sc.nodes4, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn, cnt);
             } else {
                 walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, blas_leaf_fn);
             }
@@ -242,7 +243,7 @@ RT_HD bool traverse_any(const SceneView &sc, const f3 ro, const f3 rd, const int
                 return false;
             };
             if (WIDE) {
-                return walk_bvh4(sc.nodes4, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn);
+                return walk_bvh4(sc.nodes4, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn, cnt);
             }
             return walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, blas_leaf_fn);
         }

@@ -181,6 +181,7 @@ RT_HD void store_hit(const HitSoA &s, uint32_t i, const Hit &h) {
 struct TravCount {
     uint32_t nodes, tris, instances;
     uint32_t max_stack; // deepest stack use (entries), to size the LDS stack
+    uint32_t nodes4;    // 4-wide quantised BLAS nodes fetched (rt_bvh4.h; 64 B each) -- the WIDE walk only
 };
 
 } // namespace rt

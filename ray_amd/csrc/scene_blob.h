@@ -134,14 +134,22 @@ inline bool deserialize(const void *blob, size_t size, rayhip_scene_desc &d, ray
     for (uint32_t i = 0; i < h.section_count; ++i) {
         Section s;
         memcpy(&s, b + sizeof(Header) + size_t(i) * sizeof(Section), sizeof(s));
-        if (s.offset + s.size > size) {
+        if (s.offset > size || s.size > size - s.offset) { // (written so that offset + size cannot wrap)
             err = "scene blob section out of range";
+            return false;
+        }
+        if (s.offset % 16 != 0) { // sections are reinterpreted as arrays of 16-byte aligned structs
+            err = "scene blob section is not 16-byte aligned";
             return false;
         }
         const uint8_t *p = b + s.offset;
         const std::string name(s.name, strnlen(s.name, sizeof(s.name)));
 #define ARR(field, type)                                                                                               \
     if (name == #field) {                                                                                              \
+        if (s.size % sizeof(type) != 0) {                                                                             \
+            err = "scene blob section " #field " is not a whole number of elements";                                  \
+            return false;                                                                                              \
+        }                                                                                                              \
         d.field = reinterpret_cast<const type *>(p);                                                                  \
         d.field##_count = uint32_t(s.size / sizeof(type));                                                            \
         continue;                                                                                                      \

@@ -13,10 +13,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 RAYHIP_LIB = os.path.join(_HERE, "csrc", "_build", "librayhip.so")
 
-BUF_FINAL, BUF_RAW, BUF_BASE_COLOR, BUF_DEPTH_NORMALS = 0, 1, 2, 3
+BUF_FINAL, BUF_RAW, BUF_BASE_COLOR, BUF_DEPTH_NORMALS, BUF_VARIANCE = 0, 1, 2, 3, 4
+REDUCE_RADIANCE, REDUCE_BASE_COLOR, REDUCE_DEPTH_NORMALS, REDUCE_VARIANCE, REDUCE_ALL = 1, 2, 4, 8, 15
+COMM_ID_BYTES = 128
 FLAG_SORT_RAYS = 1 << 0
 FLAG_COUNT_TRAVERSAL = 1 << 1
 FLAG_TIME_STAGES = 1 << 2
+FLAG_COUNT_WIDE = 1 << 3
 
 
 class PassSettings(C.Structure):
@@ -56,11 +59,11 @@ class Stats(C.Structure):
 
 class TravCounters(C.Structure):
     _fields_ = [("rays", C.c_ulonglong), ("nodes", C.c_ulonglong), ("tris", C.c_ulonglong), ("instances", C.c_ulonglong),
-                ("max_stack", C.c_ulonglong)]
+                ("max_stack", C.c_ulonglong), ("nodes4", C.c_ulonglong)]
 
     def as_dict(self):
         return {"rays": int(self.rays), "nodes": int(self.nodes), "tris": int(self.tris), "instances": int(self.instances),
-                "max_stack": int(self.max_stack)}
+                "max_stack": int(self.max_stack), "nodes4": int(self.nodes4)}
 
 
 RAY_DTYPE = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("pdf", "<f4"), ("c", "<f4", 3), ("ior", "<f4", 4),
@@ -75,7 +78,9 @@ ENTRY_POINTS = (
     "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
     "scene_upload", "scene_upload_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
-    "k_intersect_shadow", "k_scrambled_rand",
+    "k_intersect_shadow", "k_scrambled_rand", "k_shade",
+    "comm_create", "comm_unique_id", "comm_create_rank", "comm_bind", "comm_reduce_framebuffers", "comm_destroy",
+    "export_shard_device",
 )
 
 
@@ -119,9 +124,19 @@ class Library:
         f("k_intersect_closest").argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_int, C.c_int, C.c_uint32, C.POINTER(TravCounters)]
         f("k_intersect_shadow").argtypes = [vp, C.POINTER(Camera), vp, C.c_int, C.c_int, vp, C.POINTER(TravCounters)]
         f("k_scrambled_rand").argtypes = [vp, vp, vp, vp, C.c_int, vp]
+        f("k_shade").argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int), vp,
+                                 C.POINTER(C.c_int)]
         if prefix == "rayhip_":
             f("readback_device").argtypes = [vp, C.c_int, vp, C.c_int]
             f("set_raw_device").argtypes = [vp, vp, C.c_int, C.POINTER(Camera)]
+            f("export_shard_device").argtypes = [vp, C.c_int, vp]
+            f("comm_create").argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+            f("comm_unique_id").argtypes = [vp, C.c_size_t]
+            f("comm_create_rank").argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+            f("comm_bind").argtypes = [vp, C.c_int, vp]
+            f("comm_reduce_framebuffers").argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(Camera)]
+            f("comm_destroy").argtypes = [vp]
+            f("comm_destroy").restype = None
             f("get_trav_timing").argtypes = [vp, C.POINTER(C.c_double * 2), C.POINTER(C.c_ulonglong * 2), C.c_int]
             f("get_stage_times").argtypes = [vp, C.POINTER(Stats), C.c_int]
 
@@ -232,6 +247,10 @@ class Context:
         cam = cam or self.cam
         self.L.check(self.L.fn("set_raw_device")(self._ctx, C.c_void_p(device_ptr), pitch_px or self.w, C.byref(cam)))
 
+    def export_shard_device(self, which: int, device_ptr: int):
+        """this rank's OWNED pixels of image `which` (zero elsewhere) into device memory: the operand of the frame reduce"""
+        self.L.check(self.L.fn("export_shard_device")(self._ctx, which, C.c_void_p(device_ptr)))
+
     def set_shard(self, tile: int, shard_count: int, shard_index: int):
         """multi-GPU tile sharding: render only the tiles whose ordinal % shard_count == shard_index"""
         self.L.check(self.L.fn("set_shard")(self._ctx, tile, shard_count, shard_index))
@@ -285,6 +304,20 @@ class Context:
                                                      iteration, out.ctypes.data, C.byref(tc)))
         return out, tc.as_dict()
 
+    def k_shade(self, bounce: int, iteration: int, rays: np.ndarray, hits: np.ndarray, color: np.ndarray, cam: Camera = None):
+        """ShadePrimary (bounce 0) / ShadeSecondary on host (ray, hit) pairs; returns (color, secondary rays, shadow rays)
+        -- the twin of the oracle's refk_shade.  Emitted rays come back in no particular order."""
+        rays, hits = np.ascontiguousarray(rays), np.ascontiguousarray(hits)
+        color = np.ascontiguousarray(color.copy(), dtype=np.float32)
+        assert color.shape == (self.h, self.w, 4)
+        n = len(rays)
+        sec = np.zeros(n + 1, dtype=RAY_DTYPE)
+        sh = np.zeros(n + 1, dtype=SHADOW_RAY_DTYPE)
+        nsec, nsh = C.c_int(), C.c_int()
+        self.L.check(self.L.fn("k_shade")(self._ctx, C.byref(cam or self.cam), bounce, iteration, rays.ctypes.data, hits.ctypes.data, n,
+                                          color.ctypes.data, sec.ctypes.data, C.byref(nsec), sh.ctypes.data, C.byref(nsh)))
+        return color, sec[:nsec.value], sh[:nsh.value]
+
     def k_scrambled_rand(self, dims, seeds, samples):
         dims = np.ascontiguousarray(dims, dtype=np.uint32)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
@@ -293,3 +326,46 @@ class Context:
         self.L.check(self.L.fn("k_scrambled_rand")(self._ctx, dims.ctypes.data, seeds.ctypes.data, samples.ctypes.data,
                                                    len(dims), out.ctypes.data))
         return out
+
+
+class Comm:
+    """rayhip_comm: the frame reduce over RCCL behind the C ABI.  `Comm(lib, devices)` drives all GPUs from this process
+    (what a C++ host does); `Comm.for_rank(lib, id, nranks, rank, ctx)` is the one-process-per-GPU form."""
+
+    def __init__(self, library: Library, devices=None, _handle=None):
+        self.L = library
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+            return
+        devs = (C.c_int * len(devices))(*devices)
+        self.L.check(self.L.fn("comm_create")(len(devices), devs, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id(library: Library) -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        library.check(library.fn("comm_unique_id")(buf, COMM_ID_BYTES))
+        return buf.raw
+
+    @classmethod
+    def for_rank(cls, library: Library, unique_id: bytes, nranks: int, rank: int, ctx: "Context"):
+        h = C.c_void_p()
+        library.check(library.fn("comm_create_rank")(C.c_char_p(unique_id), nranks, rank, ctx._ctx, C.byref(h)))
+        return cls(library, _handle=h)
+
+    def bind(self, rank: int, ctx: "Context"):
+        self.L.check(self.L.fn("comm_bind")(self._h, rank, ctx._ctx))
+
+    def reduce_framebuffers(self, root: int, cam: Camera, what: int = REDUCE_ALL):
+        self.L.check(self.L.fn("comm_reduce_framebuffers")(self._h, root, what, C.byref(cam)))
+
+    def close(self):
+        if self._h:
+            self.L.fn("comm_destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

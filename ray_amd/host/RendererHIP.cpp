@@ -37,8 +37,16 @@ extern const uint32_t *transform_luts[];
 
 namespace Hip {
 
+// Versions come from ONE process-wide counter: every Scene instance and every mutation gets an id no other (scene, state)
+// pair ever had, so a renderer's "is what I uploaded still current?" test cannot be fooled by a new scene that the
+// allocator placed at the address of a deleted one with the same number of mutator calls behind it.
+inline uint64_t next_scene_version() {
+    static std::atomic<uint64_t> counter{1};
+    return counter.fetch_add(1);
+}
+
 class Scene final : public Cpu::Scene {
-    std::atomic<uint64_t> version_{1};
+    std::atomic<uint64_t> version_{next_scene_version()};
 
   public:
     Scene(ILog *log, const bool use_tex_compression)
@@ -49,7 +57,7 @@ class Scene final : public Cpu::Scene {
 // every mutator that changes an uploaded array bumps the version (cameras are passed per RenderScene call)
 #define BUMP(ret, name, params, args)                                                                                  \
     ret name params override {                                                                                        \
-        ++version_;                                                                                                    \
+        version_ = next_scene_version();                                                                               \
         return Cpu::Scene::name args;                                                                                  \
     }
     BUMP(void, SetEnvironment, (const environment_desc_t &env), (env))
@@ -247,9 +255,15 @@ class Renderer final : public RendererBase {
             try {
                 FlatScene flat;
                 SceneAccess::Export(*s, flat);
-                check(rayhip_scene_upload(ctx_, &flat.desc), "rayhip_scene_upload");
+                if (rayhip_scene_upload(ctx_, &flat.desc) != 0) {
+                    // nothing usable is on the device: forget what was there, so that the next RenderScene tries again
+                    log_->Error("RendererHIP: rayhip_scene_upload failed: %s", rayhip_last_error());
+                    uploaded_scene_ = nullptr, uploaded_version_ = 0;
+                    return;
+                }
             } catch (std::exception &e) {
                 log_->Error("RendererHIP: %s", e.what());
+                uploaded_scene_ = nullptr, uploaded_version_ = 0;
                 return;
             }
             uploaded_scene_ = s;

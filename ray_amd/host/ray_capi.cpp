@@ -245,11 +245,16 @@ void ray_renderer_get_stats(ray_renderer *r, ray_stats *st) {
 void ray_renderer_reset_stats(ray_renderer *r) { r->r->ResetStats(); }
 
 double ray_renderer_render_tiled_mt(ray_renderer *r, ray_scene *s, int tile, int spp, int threads) {
+    return ray_renderer_render_tiled_from(r, s, tile, 0, spp, threads);
+}
+
+double ray_renderer_render_tiled_from(ray_renderer *r, ray_scene *s, int tile, int iterations_done, int spp, int threads) {
     const auto sz = r->r->size();
     std::vector<Ray::RegionContext> regions;
     for (int y = 0; y < sz.second; y += tile) {
         for (int x = 0; x < sz.first; x += tile) {
             regions.emplace_back(Ray::rect_t{x, y, std::min(tile, sz.first - x), std::min(tile, sz.second - y)});
+            regions.back().iteration = iterations_done; // continue a progressive render: RenderScene increments first
         }
     }
     std::atomic_int next{0};

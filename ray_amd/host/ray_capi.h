@@ -176,6 +176,8 @@ void ray_renderer_reset_stats(ray_renderer *r);              /* RendererBase::Re
  * pull tile x tile regions from a shared counter and run `spp` RenderScene iterations on each.  Returns wall
  * seconds.  Only for backends where RendererSupportsMultithreading() holds. */
 double ray_renderer_render_tiled_mt(ray_renderer *r, ray_scene *s, int tile, int spp, int threads);
+/* the same, continuing a progressive render: every tile starts at RegionContext::iteration = iterations_done */
+double ray_renderer_render_tiled_from(ray_renderer *r, ray_scene *s, int tile, int iterations_done, int spp, int threads);
 
 ray_region *ray_region_create(int x, int y, int w, int h); /* Ray::RegionContext */
 void ray_region_destroy(ray_region *g);

@@ -7,7 +7,11 @@ The reference has no multi-GPU mode; this is new.  Desig
   * pixels are independent (RNG keyed by x, y, iteration), so every rank's RAW buffer is exact on its tiles and
     zero elsewhere; ONE sum-reduce of the W*H*4 fp32 frame to rank 0 (torch.distributed, backend "nccl" == RCCL
     over xGMI; 33 MB at 1080p) assembles a frame that is bit-identical to a single-GPU render
-  * rank 0 re-runs the tonemap pass on the combined frame (rayhip_set_raw_device)
+  * rank 0 re-runs the tonemap pass on the combined frame (rayhip_set_raw_device); a rank only ever contributes the
+    pixels it owns (rayhip_export_shard_device), so the combined values rank 0 now holds on foreign pixels never re-enter
+    a later reduce: render more iterations, reduce again -- still exact
+  * C++ hosts get the same exchange behind the C ABI (rayhip_comm_*: RCCL called from librayhip, aux images and variance
+    estimate included so that DenoiseImage works on the root)
 The same code runs on CPU tensors over gloo with the host build of the kernels (tests/test_distributed.py).
 """
 from typing import Iterable, Optional
@@ -53,11 +57,14 @@ def render_sharded(ctx: hip.Context, iterations: Iterable[int], rank: int, world
         done += n
     if dist is None or (world <= 1 and frame is None):
         return None  # (world == 1 with a frame: the exchange step is still run -- a one-rank reduce -- for testing)
+    # the operand of the reduce: this rank's OWNED pixels, zero elsewhere -- whatever the buffers hold on other ranks'
+    # pixels (the clear colour; on rank 0 the combined frame of an earlier reduce) must not enter the sum
     if frame.is_cuda:
-        ctx.readback_device(hip.BUF_RAW, frame.data_ptr())
+        ctx.export_shard_device(hip.BUF_RAW, frame.data_ptr())
     else:
         import torch
-        frame.copy_(torch.from_numpy(ctx.readback(hip.BUF_RAW)))
+        own = owned_pixel_mask(ctx.w, ctx.h, rank, world, tile)
+        frame.copy_(torch.from_numpy(ctx.readback(hip.BUF_RAW) * own[..., None]))
     dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
     if frame.is_cuda:
         # the collective is only enqueued (torch stream); librayhip works on its own stream, so wait for it here

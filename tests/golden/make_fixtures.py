@@ -12,7 +12,10 @@ Files
   <scene>_ref.npz                        RendererRef outputs: raw_spp1, raw_spp8 (get_raw_pixels_ref), final_spp8,
                                          base_color_spp8, depth_normals_spp8; kernel-level dumps for iteration 1:
                                          primary rays/hits (GeneratePrimaryRays), hits after IntersectScene,
-                                         shadow rays of bounce 0 and their IntersectScene(shadow) results
+                                         ShadePrimary's image + secondary rays + shadow rays (shade0_color,
+                                         secondary_rays, shadow_rays), the shadow rays' IntersectScene(shadow) results;
+                                         bounce 1: the secondary rays after IntersectScene (+ their hits) and
+                                         ShadeSecondary's image / rays (shade1_color, secondary_rays1, shadow_rays1)
   rng_vectors.npz                        get_scrambled_2d_rand known answers
 """
 import os
@@ -53,9 +56,18 @@ def main():
         out["primary_rays"], out["primary_hits_in"] = rays, hits
         rays2, hits2 = O.ref_intersect_closest(s, rays, hits, 1)
         out["primary_hits"] = hits2
+        out["primary_rays_traced"] = rays2  # throughput / depth as IntersectScene left them (transparent surfaces crossed)
         color, sec, sh = O.ref_shade(s, W, H, 0, 1, rays2, hits2, np.zeros((H, W, 4), np.float32))
         out["shade0_color"], out["secondary_rays"], out["shadow_rays"] = color, sec, sh
         out["shadow_rc"] = O.ref_intersect_shadow(s, sh, 1)
+        # bounce 1 of the same iteration: the secondary rays traced (hits preset like RendererCPU.h:533-535) and shaded by
+        # ShadeSecondary on top of the bounce-0 image
+        hits_in = np.zeros(len(sec), dtype=hits.dtype)
+        hits_in["obj_index"], hits_in["prim_index"], hits_in["t"], hits_in["v"] = -1, -1, 3.402823466e+30, -1.0
+        sec1, hits1 = O.ref_intersect_closest(s, sec, hits_in, 1)
+        out["secondary_rays_traced"], out["secondary_hits"] = sec1, hits1
+        color1, sec2, sh1 = O.ref_shade(s, W, H, 1, 1, sec1, hits1, color)
+        out["shade1_color"], out["secondary_rays1"], out["shadow_rays1"] = color1, sec2, sh1
         # frames
         region = api.RegionContext((0, 0, W, H))
         for it in range(1, 9):

@@ -25,6 +25,7 @@
 #include "../../ray_amd/csrc/rt_params.h"
 #include "../../ray_amd/csrc/rt_pixel.h"
 #include "../../ray_amd/csrc/scene_blob.h"
+#include "../../ray_amd/csrc/scene_validate.h"
 
 using namespace rt;
 
@@ -113,6 +114,9 @@ HS_API int hostsim_clear(hostsim_ctx *c, const float rgba[4]) { // RendererCPU.h
 HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     const rayhip_layout::AlignedDesc aligned(*d_in);
     const rayhip_scene_desc *d = &aligned.d;
+    if (!rayhip_validate::validate(*d, g_err)) {
+        return 1;
+    }
     HostScene &s = c->hs;
 #define CP(field) s.field.assign(d->field, d->field + d->field##_count)
     CP(nodes);
@@ -227,7 +231,9 @@ HS_API int hostsim_scene_upload_blob(hostsim_ctx *c, const void *blob, size_t si
     if (extras.tonemap_lut && out_cam->view_transform != 0) {
         hostsim_set_tonemap_lut(c, out_cam->view_transform, extras.tonemap_lut, extras.tonemap_lut_dims);
     }
-    hostsim_scene_upload(c, &d);
+    if (hostsim_scene_upload(c, &d)) {
+        return 1;
+    }
     if (ft) {
         hostsim_set_filter_table(c, ft, ftn);
     }
@@ -237,24 +243,24 @@ HS_API int hostsim_scene_upload_blob(hostsim_ctx *c, const void *blob, size_t si
 template <class Stack>
 static void trace_closest(const hostsim_ctx *c, const TraceParams &tp, Ray &r, Hit &h, Stack &st, TravCount *cnt) {
     if (c->wide) {
-        intersect_scene_closest<true>(c->sc, tp, r, h, st, nullptr);
+        intersect_scene_closest<true>(c->sc, tp, r, h, st, cnt);
     } else {
         intersect_scene_closest<false>(c->sc, tp, r, h, st, cnt);
     }
 }
 template <class Stack>
 static f3 trace_shadow(const hostsim_ctx *c, const TraceParams &tp, const ShadowRay &r, Stack &st, TravCount *cnt) {
-    return c->wide ? intersect_scene_shadow<true>(c->sc, tp, r, st, nullptr) : intersect_scene_shadow<false>(c->sc, tp, r, st, cnt);
+    return c->wide ? intersect_scene_shadow<true>(c->sc, tp, r, st, cnt) : intersect_scene_shadow<false>(c->sc, tp, r, st, cnt);
 }
 
 static void add_counters(rayhip_trav_counters &dst, const TravCount &tc) {
-    dst.rays += 1, dst.nodes += tc.nodes, dst.tris += tc.tris, dst.instances += tc.instances;
+    dst.rays += 1, dst.nodes += tc.nodes, dst.tris += tc.tris, dst.instances += tc.instances, dst.nodes4 += tc.nodes4;
     dst.max_stack = tc.max_stack > dst.max_stack ? tc.max_stack : dst.max_stack;
 }
 
 HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int rect[4], int iteration, uint32_t flags,
                           rayhip_stats *) {
-    const bool count = (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) != 0;
+    const bool count = (flags & (RAYHIP_FLAG_COUNT_TRAVERSAL | RAYHIP_FLAG_COUNT_WIDE)) != 0;
     const int w = c->w;
     const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
@@ -501,7 +507,7 @@ HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam,
         Hit h = {hits[i].obj_index, hits[i].prim_index, hits[i].t, hits[i].u, hits[i].v};
         TravCount tc = {};
         if (wide) {
-            intersect_scene_closest<true>(c->sc, tp, r, h, st, nullptr);
+            intersect_scene_closest<true>(c->sc, tp, r, h, st, &tc);
         } else {
             intersect_scene_closest<false>(c->sc, tp, r, h, st, &tc);
         }
@@ -532,6 +538,38 @@ HS_API int hostsim_k_intersect_shadow(hostsim_ctx *c, const rayhip_camera *cam, 
     if (out_counters) {
         *out_counters = acc;
     }
+    return 0;
+}
+
+HS_API int hostsim_k_shade(hostsim_ctx *c, const rayhip_camera *cam, int bounce, int iteration, const rayhip_ray *rays,
+                           const rayhip_hit *hits, int count, float *inout_color, rayhip_ray *out_secondary, int *out_secondary_count,
+                           rayhip_shadow_ray *out_shadow, int *out_shadow_count) {
+    const ShadeParams sp = make_shade_params(*cam, iteration, bounce);
+    float4 *color = reinterpret_cast<float4 *>(inout_color);
+    std::vector<float4> base(size_t(c->w) * c->h), dn(size_t(c->w) * c->h);
+    int n_sec = 0, n_sh = 0;
+    for (int i = 0; i < count; ++i) {
+        const Ray r = from_abi(rays[i]);
+        const Hit h = {hits[i].obj_index, hits[i].prim_index, hits[i].t, hits[i].u, hits[i].v};
+        Ray nr;
+        ShadowRay sr;
+        const ShadeResult res = shade_surface(c->sc, sp, h, r, nr, sr);
+        if (bounce == 0) {
+            write_primary_pixel(res, r.xy, c->w, 1.0f / float(iteration), color, base.data(), dn.data());
+        } else {
+            add_secondary_pixel(res, r.xy, c->w, color);
+        }
+        if (res.emit_secondary) {
+            out_secondary[n_sec++] = to_abi(nr);
+        }
+        if (res.emit_shadow) {
+            rayhip_shadow_ray &o = out_shadow[n_sh++];
+            o.o[0] = sr.o.x, o.o[1] = sr.o.y, o.o[2] = sr.o.z, o.depth = sr.depth;
+            o.d[0] = sr.d.x, o.d[1] = sr.d.y, o.d[2] = sr.d.z, o.dist = sr.dist;
+            o.c[0] = sr.c.x, o.c[1] = sr.c.y, o.c[2] = sr.c.z, o.xy = sr.xy;
+        }
+    }
+    *out_secondary_count = n_sec, *out_shadow_count = n_sh;
     return 0;
 }
 

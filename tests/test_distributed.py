@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, w, h, spp, out_dir, batch=1):
+def _worker(rank, world, port, w, h, spp, out_dir, batch=1, refine=0, clear=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -40,13 +40,20 @@ def _worker(rank, world, port, w, h, spp, out_dir, batch=1):
     lib = hip.Library(O2.HOSTSIM_LIB, prefix="hostsim_")
     ctx = U.make_context(lib, "cornell_basic", w, h)
     frame = torch.zeros((h, w, 4), dtype=torch.float32)
+    if clear is not None:  # whatever a rank's buffers hold on pixels it does not own must not enter the sum
+        ctx.clear(clear)
     multigpu.render_sharded(ctx, range(1, spp + 1), rank, world, dist=dist, frame=frame, tile=32, batch=batch)
     part = ctx.readback(hip.BUF_RAW)
     mask = multigpu.owned_pixel_mask(w, h, rank, world, tile=32)
-    assert not part[~mask].any(), "a rank wrote pixels it does not own"
+    if clear is None:
+        assert not part[~mask].any(), "a rank wrote pixels it does not own"
     assert part[mask][..., 3].any()
     if rank == 0:
         np.save(os.path.join(out_dir, "frame.npy"), frame.numpy())
+    if refine:  # progressive refinement: more iterations on the same contexts, one more reduce
+        multigpu.render_sharded(ctx, range(spp + 1, spp + 1 + refine), rank, world, dist=dist, frame=frame, tile=32, batch=batch)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "frame_refined.npy"), frame.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,3 +86,24 @@ def test_three_ranks_batched_gloo_bit_identical(tmp_path):
     full = util.render_frames(util.make_context(lib, "cornell_basic", w, h), spp)
     got = np.load(os.path.join(str(tmp_path), "frame.npy"))
     assert np.array_equal(got, full)
+
+
+@pytest.mark.skipif(not O.have_hostsim(), reason="tests/hostsim not built")
+def test_two_ranks_refine_after_a_reduce_and_nonzero_clear_colour(tmp_path):
+    """render, reduce, render more, reduce again -- with the buffers cleared to a non-zero colour first, so that every
+    rank holds non-zero values on pixels it does not own: only owned pixels may enter the sums"""
+    import torch.multiprocessing as mp
+
+    w, h, spp, refine, world = 96, 80, 2, 2, 2
+    clear = (0.25, 0.5, 0.125, 1.0)
+    mp.spawn(_worker, args=(world, _free_port(), w, h, spp, str(tmp_path), 1, refine, clear), nprocs=world, join=True)
+    from ray_amd import hip
+
+    lib = hip.Library(O.HOSTSIM_LIB, prefix="hostsim_")
+    ctx = util.make_context(lib, "cornell_basic", w, h)
+    ctx.clear(clear)
+    full = util.render_frames(ctx, spp)
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "frame.npy")), full)
+    for it in range(spp + 1, spp + refine + 1):
+        ctx.render(it)
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "frame_refined.npy")), ctx.readback(hip.BUF_RAW))
