@@ -61,6 +61,13 @@ struct DevBuf {
         }
         HIP_TRY(hipMalloc(&p, n));
         bytes = n;
+        // touch it now: the first write to fresh device memory is several times slower than the following ones, and the
+        // wavefront-state buffers would otherwise pay that inside the first large pass (measured: ray generation 31 ms
+        // instead of 0.8 ms in a 20-iteration pass that followed a 5-iteration warm-up)
+        // (the null stream does not order against the context's non-blocking stream: wait, or the memset could land
+        // after the first copy into the buffer)
+        HIP_TRY(hipMemset(p, 0, n));
+        HIP_TRY(hipDeviceSynchronize());
         return 0;
     }
     void release() {
@@ -105,12 +112,16 @@ struct rayhip_ctx {
     PixelBuffers px = {};
 
     // wavefront state, sized w*h
-    DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3], deferred_planes[2];
+    DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3], deferred_planes[2], point_planes[7];
+    PointSoA points = {};
+    // how the shade stage is cut into launches (kernels.hip.h): bit 0 = the light pick as its own kernel, bit 1 = next-event
+    // estimation and continuation as two scatter launches.  RAYHIP_SHADE_SPLIT overrides (A/B measurements).
+    int shade_split = 1;
     RaySoA rays[2] = {};
     HitSoA hits = {};
     ShadowSoA shadow = {};
     DeferredSoA deferred = {};
-    DevBuf counters;      // uint32 [MAX_BOUNCE_SLOTS][2: rays, shadow rays][QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE]
+    DevBuf counters;      // uint32 [MAX_BOUNCE_SLOTS][4: rays, shadow rays, deferred emitters, shade points][QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE]
     DevBuf trav_counters; // u64 [2][TRAV_COUNTER_WORDS]
     DevBuf stack_spill;   // per-wave overflow slabs of the traversal stack
     DevBuf sort_keys[2], sort_idx[2], sort_temp;
@@ -131,9 +142,10 @@ struct rayhip_ctx {
     double stage_us[11] = {};
 
     static constexpr size_t QUEUE_WORDS = size_t(QUEUE_MAX_STRIPES) * QUEUE_COUNTER_STRIDE;
-    uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + size_t(3 * b) * QUEUE_WORDS; }
-    uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + size_t(3 * b + 1) * QUEUE_WORDS; }
-    uint32_t *deferred_count(int b) const { return counters.as<uint32_t>() + size_t(3 * b + 2) * QUEUE_WORDS; }
+    uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + size_t(4 * b) * QUEUE_WORDS; }
+    uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + size_t(4 * b + 1) * QUEUE_WORDS; }
+    uint32_t *deferred_count(int b) const { return counters.as<uint32_t>() + size_t(4 * b + 2) * QUEUE_WORDS; }
+    uint32_t *point_count(int b) const { return counters.as<uint32_t>() + size_t(4 * b + 3) * QUEUE_WORDS; }
     // queue geometry for a frame of `items` pixels split over `stripes` stripes
     static RayQueue make_queue(uint32_t *counts, size_t items, uint32_t stripes) {
         const size_t chunks = (items + WAVE - 1) / WAVE;
@@ -142,8 +154,9 @@ struct rayhip_ctx {
     RayQueue ray_queue(int b, size_t items, uint32_t stripes) const { return make_queue(ray_count(b), items, stripes); }
     RayQueue shadow_queue(int b, size_t items, uint32_t stripes) const { return make_queue(shadow_count(b), items, stripes); }
     RayQueue deferred_queue(int b, size_t items, uint32_t stripes) const { return make_queue(deferred_count(b), items, stripes); }
+    RayQueue point_queue(int b, size_t items, uint32_t stripes) const { return make_queue(point_count(b), items, stripes); }
     int clear_queues(int bounces, hipStream_t s) const {
-        return hipMemsetAsync(counters.p, 0, size_t(3 * bounces) * QUEUE_WORDS * sizeof(uint32_t), s) == hipSuccess ? 0 : 1;
+        return hipMemsetAsync(counters.p, 0, size_t(4 * bounces) * QUEUE_WORDS * sizeof(uint32_t), s) == hipSuccess ? 0 : 1;
     }
 };
 
@@ -244,6 +257,15 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
         return 1;
     }
     c->deferred.a = c->deferred_planes[0].as<float4>(), c->deferred.b = c->deferred_planes[1].as<float4>();
+    for (int pl = 0; pl < 7; ++pl) {
+        if (c->point_planes[pl].alloc(n * 16)) {
+            return 1;
+        }
+    }
+    c->points.p_slot = c->point_planes[0].as<float4>(), c->points.n_gx = c->point_planes[1].as<float4>();
+    c->points.b_gy = c->point_planes[2].as<float4>(), c->points.base_gz = c->point_planes[3].as<float4>();
+    c->points.scalars = c->point_planes[4].as<float4>(), c->points.misc = c->point_planes[5].as<float4>();
+    c->points.light = c->point_planes[6].as<float4>();
     // the ray sort only runs on single-iteration passes
     const size_t n_sort = tile_slots(w, h) + size_t(WAVE) * QUEUE_MAX_STRIPES;
     size_t temp_bytes = 0;
@@ -376,6 +398,9 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         }
     }
     c->grid_waves = c->props.multiProcessorCount * per_cu * grid_mult;
+    if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
+        c->shade_split = atoi(e) & 3;
+    }
     // the persistent ray-refill form of the closest-hit kernel (opt-in, RAYHIP_REFILL=1: measured equal or slower, see
     // kernels.hip.h) runs one block per resident wave slot
     if (getenv("RAYHIP_REFILL") != nullptr && atoi(getenv("RAYHIP_REFILL")) != 0) {
@@ -393,7 +418,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         delete c;
         return 1;
     }
-    if (c->counters.alloc(sizeof(uint32_t) * 3 * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS)) {
+    if (c->counters.alloc(sizeof(uint32_t) * 4 * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS)) {
         delete c;
         return 1;
     }
@@ -425,6 +450,9 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         for (int pl = 0; pl < 5; ++pl) {
             c->ray_planes[k][pl].release();
         }
+    }
+    for (DevBuf &b : c->point_planes) {
+        b.release();
     }
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -602,7 +630,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     UP(lights)
     UP(li_indices)
     UP(light_cwnodes)
-    { // node-only half of the light-tree importance, evaluated once per scene (rt_lights.h: decode_lnode_child)
+    { // node-only half of the light-tree importance, evaluated once per scene (shade_lights.h: decode_light_child)
         std::vector<float4> lc(size_t(d->light_cwnodes_count) * LIGHT_CHILDREN_STRIDE);
         for (uint32_t n = 0; n < d->light_cwnodes_count; ++n) {
             fill_light_children(d->light_cwnodes[n], &lc[size_t(n) * LIGHT_CHILDREN_STRIDE]);
@@ -611,7 +639,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             return 1;
         }
         UPLOAD_TRACE("light_children done")
-        { // vertices gathered per triangle (rt_shade.h: fill_tri_verts)
+        { // vertices gathered per triangle (shade_point.h: fill_tri_verts)
             const uint32_t n_tris = d->vtx_indices_count / 3;
             std::vector<float4> tv(size_t(n_tris) * TRI_VERTS_STRIDE);
             for (uint32_t t = 0; t < n_tris; ++t) {
@@ -623,7 +651,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             HIP_TRY(hipStreamSynchronize(c->stream)); // `tv` goes out of scope
         }
         UPLOAD_TRACE("tri_verts done")
-        // world-space corners of the TRI lights (rt_lights.h: fill_light_tri_geom)
+        // world-space corners of the TRI lights (shade_lights.h: fill_light_tri_geom)
         // (the light array is a sparse pool: only the slots li_indices[] names hold lights)
         std::vector<float4> tg(size_t(d->lights_count) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         for (uint32_t k = 0; k < d->li_indices_count; ++k) {
@@ -781,19 +809,36 @@ static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration,
                          int gtrace, int vw, float mix_factor, const Layering &layers) {
     hipStream_t s = c->stream;
     const ShadeParams sp = make_shade_params(cam, iteration, bounce);
+    const RayQueue in = c->ray_queue(bounce, nslots, stripes), pts = c->point_queue(bounce, nslots, stripes);
+    const RayQueue out_rays = c->ray_queue(bounce + 1, nslots, stripes), out_shadow = c->shadow_queue(bounce, nslots, stripes);
+    const RayQueue out_deferred = c->deferred_queue(bounce, nslots, stripes);
+    const bool pick_apart = (c->shade_split & 1) != 0 && c->sc.light_cwnodes_count != 0;
+    // stage 1: what was hit
     if (bounce == 0) {
-        k_shade<true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
-                                              c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
-                                              c->shadow_queue(bounce, nslots, stripes), c->deferred,
-                                              c->deferred_queue(bounce, nslots, stripes), c->px, vw, mix_factor, layers);
+        if (pick_apart) {
+            k_surface<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, in, c->points, pts, c->deferred, out_deferred, c->px, vw, mix_factor, layers);
+        } else {
+            k_surface<true, true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, in, c->points, pts, c->deferred, out_deferred, c->px, vw, mix_factor, layers);
+        }
     } else {
-        k_shade<false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes),
-                                               c->rays[cur ^ 1], c->ray_queue(bounce + 1, nslots, stripes), c->shadow,
-                                               c->shadow_queue(bounce, nslots, stripes), c->deferred,
-                                               c->deferred_queue(bounce, nslots, stripes), c->px, vw, mix_factor, layers);
-        // emitter hits whose MIS weight was deferred (kernels.hip.h); an empty queue costs a few microseconds
-        k_shade_emissive<<<std::min(gtrace, 2048), WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred,
-                                                                 c->deferred_queue(bounce, nslots, stripes), c->px, vw);
+        if (pick_apart) {
+            k_surface<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, in, c->points, pts, c->deferred, out_deferred, c->px, vw, mix_factor, layers);
+        } else {
+            k_surface<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, in, c->points, pts, c->deferred, out_deferred, c->px, vw, mix_factor, layers);
+        }
+    }
+    // emitter hits whose MIS weight was deferred; an empty queue costs a few microseconds
+    k_shade_emissive<<<std::min(gtrace, 2048), WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred, out_deferred, c->px, vw);
+    // stage 2: which light
+    if (pick_apart) {
+        k_light_pick<<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->points, pts, layers);
+    }
+    // stage 3: shadow ray + continuation
+    if ((c->shade_split & 2) != 0) {
+        k_scatter<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->points, pts, c->rays[cur ^ 1], out_rays, c->shadow, out_shadow, c->px, vw, layers);
+        k_scatter<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->points, pts, c->rays[cur ^ 1], out_rays, c->shadow, out_shadow, c->px, vw, layers);
+    } else {
+        k_scatter<true, true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->points, pts, c->rays[cur ^ 1], out_rays, c->shadow, out_shadow, c->px, vw, layers);
     }
 }
 

@@ -16,7 +16,7 @@
 // and this kernel only runs when the scene has visible / blocker analytic lights.
 #pragma once
 
-#include "rt_lights.h"
+#include "shade_lights.h"
 #include "rt_traverse.h"
 
 namespace rt {
@@ -107,7 +107,7 @@ RT_HD uint32_t bbox_test_oct(const f3 o, const f3 inv_d, const float t, const ra
     uint32_t mask = 0;
     for (int i = 0; i < 8; ++i) {
         float bmin[3], bmax[3];
-        cw_child_bounds(n, i, bmin, bmax);
+        light_child_box(n, i, bmin, bmax);
         if (bbox_test(o, inv_d, t, bmin, bmax, out_dist[i])) {
             mask |= (1u << i);
         }
@@ -223,8 +223,8 @@ RT_HD void intersect_area_lights(const SceneView &sc, const f3 ro, const f3 rd, 
                 break;
             }
             float factors[8];
-            calc_lnode_importance(sc, cur.index, ro, factors);
-            const float total_importance = total_importance8(factors);
+            light_node_importances(sc, cur.index, ro, factors);
+            const float total_importance = sum8_sse_order(factors);
             if (total_importance == 0.0f) {
                 reached_leaf = false;
                 break;

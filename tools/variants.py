@@ -43,7 +43,8 @@ def build_one(name, flags):
         if "Function Name:" in line:
             cur = line.split("Function Name:")[1].split("[")[0].strip()
             cur = "refill" if "k_trace_closest_refill" in cur else "closest" if "k_trace_closestILb0" in cur else "shadow" if "k_trace_shadowILb0" in cur else \
-                "shade" if "k_shadeILb0" in cur else None
+                "surface" if "k_surfaceILb0ELb0" in cur else "scatter" if "k_scatterILb1ELb1" in cur else "scatter_nee" if "k_scatterILb1ELb0" in cur else \
+                "scatter_cont" if "k_scatterILb0ELb1" in cur else "pick" if "k_light_pick" in cur else None
         elif cur and any(k in line for k in ("VGPRs:", "ScratchSize", "Occupancy", "LDS Size")):
             body = line.split("remark:")[1].rsplit("[-Rpass", 1)[0]
             k, v = body.rsplit(":", 1)
@@ -54,8 +55,9 @@ def build_one(name, flags):
 
 
 def build():
+    todo = {k: v for k, v in VARIANTS.items() if not any(f.startswith("+build:") for f in v)}  # "+build:<name>": reuse that build
     with cf.ThreadPoolExecutor(4) as ex:
-        for name, res in ex.map(lambda kv: build_one(*kv), VARIANTS.items()):
+        for name, res in ex.map(lambda kv: build_one(*kv), todo.items()):
             print(name, json.dumps(res))
 
 
@@ -65,7 +67,8 @@ def run(workload="sponza", K=16):
     import bench
     bench.get_scene_blob(workload, bench.WORKLOADS[workload], 0, 1, lambda: None)  # build + cache once
     for name in VARIANTS:
-        if os.path.exists(os.path.join(VDIR, name, "librayhip.so")):
+        build_name = next((f[7:] for f in VARIANTS[name] if f.startswith("+build:")), name)
+        if os.path.exists(os.path.join(VDIR, build_name, "librayhip.so")):
             subprocess.run([sys.executable, __file__, "run1", name, workload, str(K)])
 
 
@@ -87,7 +90,8 @@ def run1(name, workload="sponza", K=16):
             k, v = f[5:].split("=", 1)
             os.environ[k] = v
     if True:
-        path = os.path.join(VDIR, name, "librayhip.so")
+        build_name = next((f[7:] for f in VARIANTS[name] if f.startswith("+build:")), name)
+        path = os.path.join(VDIR, build_name, "librayhip.so")
         L = hip.Library(path)
         ctx = hip.Context(0, L)
         ctx.upload_static(pmj)
