@@ -34,6 +34,10 @@ inline float half_area(const Box &b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
+// plane q of the node grid as a real number: org and q * step (a power of two times an 8-bit integer) are fp32 values, so
+// their sum is exact in double
+inline double real_plane(const uint32_t q, const float step, const float org) { return double(org) + double(q) * double(step); }
+
 // Quantise `n_slots` child boxes onto the node grid.  Returns false if a box cannot be represented conservatively
 // (non-finite coordinates): the caller then keeps the BVH2 for the whole scene.
 inline bool quantise(const Slot *slots, const int n_slots, rt::Bvh4Node &out) {
@@ -64,7 +68,7 @@ inline bool quantise(const Slot *slots, const int n_slots, rt::Bvh4Node &out) {
                 e = 1;
             }
         }
-        while (e < 254 && rt::bvh4_dequant(255u, rt::uint_as_float(uint32_t(e) << 23), lo[a]) < hi[a]) {
+        while (e < 254 && real_plane(255u, rt::uint_as_float(uint32_t(e) << 23), lo[a]) < double(hi[a])) {
             ++e;
         }
         if (e >= 254) {
@@ -82,15 +86,16 @@ inline bool quantise(const Slot *slots, const int n_slots, rt::Bvh4Node &out) {
             const float flo = std::floor((slots[c].box.lo[a] - lo[a]) / scale[a]);
             const float fhi = std::ceil((slots[c].box.hi[a] - lo[a]) / scale[a]);
             int qlo = int(std::fmin(std::fmax(flo, 0.0f), 255.0f)), qhi = int(std::fmin(std::fmax(fhi, 0.0f), 255.0f));
-            // make it hold for the value the device computes
-            while (qlo > 0 && rt::bvh4_dequant(uint32_t(qlo), scale[a], lo[a]) > slots[c].box.lo[a]) {
+            // containment in REAL arithmetic (org + q * step is exact in double): what the error budget of the device's
+            // parameter-space slab test starts from (rt_bvh4.h: bvh4_test_node)
+            while (qlo > 0 && real_plane(uint32_t(qlo), scale[a], lo[a]) > double(slots[c].box.lo[a])) {
                 --qlo;
             }
-            while (qhi < 255 && rt::bvh4_dequant(uint32_t(qhi), scale[a], lo[a]) < slots[c].box.hi[a]) {
+            while (qhi < 255 && real_plane(uint32_t(qhi), scale[a], lo[a]) < double(slots[c].box.hi[a])) {
                 ++qhi;
             }
-            if (rt::bvh4_dequant(uint32_t(qlo), scale[a], lo[a]) > slots[c].box.lo[a] ||
-                rt::bvh4_dequant(uint32_t(qhi), scale[a], lo[a]) < slots[c].box.hi[a]) {
+            if (real_plane(uint32_t(qlo), scale[a], lo[a]) > double(slots[c].box.lo[a]) ||
+                real_plane(uint32_t(qhi), scale[a], lo[a]) < double(slots[c].box.hi[a])) {
                 return false;
             }
             out.qlo[a] |= uint32_t(qlo) << (8 * c);

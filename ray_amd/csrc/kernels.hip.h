@@ -348,18 +348,14 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
         }
         RT_PROF_T(24)
         const uint32_t i = slot0 + lane;
+        // Only what the walk needs is held in registers: origin, direction, the ray type.  Throughput, pixel and depth
+        // counters stay in the ray planes and are fetched by `tail` if -- and only if -- the ray meets a non-solid surface
+        // (they used to be spilled to scratch around the walk: ~170 B of scratch traffic per ray).
         Ray r;
         load_ray_od(rays, i, r);
-        {
-            const float4 c = rays.c_cs[i];
-            const uint2 xd = rays.xy_depth[i];
-            r.c = {c.x, c.y, c.z};
-            r.cone_spread = c.w;
-            r.xy = xd.x, r.depth = xd.y;
-        }
+        r.depth = rays.xy_depth[i].y;
+        r.c = {0.0f, 0.0f, 0.0f}, r.cone_spread = 0.0f, r.xy = 0;
         Hit h = init_hits ? make_hit() : load_hit(hits, i);
-        const uint32_t depth_in = r.depth;
-        const f3 c_in = r.c;
 
         LdsStack st;
         st.lane_base = &lds_stack[lane];
@@ -367,25 +363,36 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
         st.size = 0;
         TravCount tc = {0, 0, 0, 0, 0};
         RT_PROF_T(25)
-        const uint32_t xy_virtual = r.xy, layer = xy_layer(xy_virtual, layers);
-        if (layer == 0) {
-            intersect_scene_closest<WIDE>(sc, tp, r, h, st, COUNT ? &tc : nullptr);
-        } else { // a later iteration of the batch: its own sample index / seed, random numbers keyed by the real pixel
-            TraceParams tpl = tp;
-            tpl.iteration = tp.iteration + int(layer);
-            tpl.rand_seed = layer_rand_seed(tpl.iteration);
-            r.xy = xy_real(xy_virtual, layers, layer);
-            intersect_scene_closest<WIDE>(sc, tpl, r, h, st, COUNT ? &tc : nullptr);
-            r.xy = xy_virtual;
-        }
+        struct Tail {
+            const RaySoA &rays;
+            const Layering &layers;
+            uint32_t i;
+            bool fetched;
+            uint32_t xy_virtual;
+            __device__ void operator()(Ray &r, TraceParams &tp) {
+                const float4 c = rays.c_cs[i];
+                const uint2 xd = rays.xy_depth[i];
+                r.c = {c.x, c.y, c.z}, r.cone_spread = c.w;
+                r.depth = xd.y;
+                // a later iteration of a batched pass: its own sample index / seed, random numbers keyed by the real pixel
+                xy_virtual = xd.x;
+                const uint32_t layer = xy_layer(xy_virtual, layers);
+                r.xy = xy_real(xy_virtual, layers, layer);
+                if (layer != 0) {
+                    tp.iteration += int(layer);
+                    tp.rand_seed = layer_rand_seed(tp.iteration);
+                }
+                fetched = true;
+            }
+        } tail = {rays, layers, i, false, 0u};
+        intersect_scene_closest<WIDE>(sc, tp, r, h, st, COUNT ? &tc : nullptr, tail);
         RT_PROF_T(26)
 
         store_hit(hits, i, h);
-        // only rays that crossed (or died on) a transparent surface changed throughput / depth
-        if (r.depth != depth_in || r.c.x != c_in.x || r.c.y != c_in.y || r.c.z != c_in.z) {
+        if (tail.fetched) { // (a ray that only met solid surfaces has nothing to write back)
             rays.c_cs[i] = mkfloat4(r.c.x, r.c.y, r.c.z, r.cone_spread);
             uint2 xd;
-            xd.x = r.xy, xd.y = r.depth;
+            xd.x = tail.xy_virtual, xd.y = r.depth;
             rays.xy_depth[i] = xd;
         }
         if (COUNT) {
@@ -692,16 +699,12 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_shadow(const SceneView sc,
         TravCount tc = {0, 0, 0, 0, 0};
         f3 rc;
         const uint32_t layer = xy_layer(r.xy, layers);
-        if (layer == 0) {
-            rc = intersect_scene_shadow<WIDE>(sc, tp, r, st, COUNT ? &tc : nullptr);
-        } else {
-            TraceParams tpl = tp;
-            tpl.iteration = tp.iteration + int(layer);
-            tpl.rand_seed = layer_rand_seed(tpl.iteration);
-            ShadowRay rl = r;
-            rl.xy = xy_real(r.xy, layers, layer);
-            rc = intersect_scene_shadow<WIDE>(sc, tpl, rl, st, COUNT ? &tc : nullptr);
-        }
+        TraceParams tpl = tp;
+        tpl.iteration = tp.iteration + int(layer);
+        tpl.rand_seed = layer == 0 ? tp.rand_seed : layer_rand_seed(tpl.iteration);
+        ShadowRay rl = r;
+        rl.xy = xy_real(r.xy, layers, layer);
+        rc = intersect_scene_shadow<WIDE>(sc, tpl, rl, st, COUNT ? &tc : nullptr);
         if (out_rc) {
             out_rc[i] = mkfloat4(rc.x, rc.y, rc.z, 0.0f);
         } else {

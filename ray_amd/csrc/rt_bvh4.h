@@ -55,6 +55,21 @@ RT_HD float bvh4_dequant(const uint32_t q, const float scale, const float org) {
 
 // One visit of a 4-wide node: test the four children against [0, t] and return them sorted by entry distance
 // (ref[0] nearest); n_hit = number of children hit.
+//
+// The slab test runs in the ray's parameter space (the compressed-wide-BVH formulation of Ylitie et al. 2017): plane q of
+// axis a of this node's grid is crossed at  t = q * (step_a * inv_d_a) + (org_a - o_a) * inv_d_a,  so a child costs one
+// byte-to-float conversion and one fma per plane instead of de-quantise, subtract, multiply, and the sign of inv_d_a says
+// which of (qlo, qhi) is the entry plane -- no min / max per axis.  The box test only CULLS, so it does not have to be the
+// reference's arithmetic, it has to be CONSERVATIVE against it: whenever the reference's bbox_test (rt_isect.h) accepts the
+// exact fp32 child box, this test accepts the quantised box that contains it.  Error budget (eps = 2^-24):
+//   * base_a = fl(fl(org_a - o_a) * inv_d_a): relative 2 eps;  step_a * inv_d_a: exact (step is a power of two);  the fma:
+//     relative eps of its result  ->  |computed - real| <= (3 |base_a| + 255 |k_a|) eps  <  E_a = (|base_a| + 255 |k_a|) 2^-22.
+//     Entry planes are moved back by E_a, exit planes forward (folded into the fma's addend: one more rounding of the same
+//     size, inside the same bound);
+//   * the reference's own result is within relative 3 eps of the real value for ITS box and it multiplies tmax by 1 + 2^-22
+//     (rt_isect.h: bbox_test); the final tmin / tmax here get a relative slack of 2^-21 = 8 eps;
+//   * the quantised box contains the child box in REAL arithmetic (bvh4_build.h checks org + q * step in double).
+// Checked by the bit-exact frame / hit tests of the wide walk against the BVH2 walk and the oracle.
 RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 ro, const f3 inv_d, const float t, uint32_t ref[4],
                           uint32_t &n_hit) {
     RT_PROF_T(16)
@@ -64,23 +79,37 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
     RT_PROF_WAIT(w0, w1, w2, w3)
     RT_PROF_T(17)
     const uint32_t exps = float_as_uint(w0.w);
-    const float sx = bvh4_scale(exps, 0), sy = bvh4_scale(exps, 1), sz = bvh4_scale(exps, 2);
     const uint32_t child[4] = {float_as_uint(w1.x), float_as_uint(w1.y), float_as_uint(w1.z), float_as_uint(w1.w)};
-    const uint32_t qlx = float_as_uint(w2.x), qly = float_as_uint(w2.y), qlz = float_as_uint(w2.z);
-    const uint32_t qhx = float_as_uint(w2.w), qhy = float_as_uint(w3.x), qhz = float_as_uint(w3.y);
 
-    const float none = 3.402823466e+38f;
+    // the grid in ray-parameter space, per axis: t(q) = q * k + base, padded by the error bound on the side that matters
+    const float org[3] = {w0.x, w0.y, w0.z}, o[3] = {ro.x, ro.y, ro.z}, id[3] = {inv_d.x, inv_d.y, inv_d.z};
+    const uint32_t qlo_w[3] = {float_as_uint(w2.x), float_as_uint(w2.y), float_as_uint(w2.z)};
+    const uint32_t qhi_w[3] = {float_as_uint(w2.w), float_as_uint(w3.x), float_as_uint(w3.y)};
+    float k[3], base_in[3], base_out[3];
+    uint32_t q_in[3], q_out[3]; // the four children's entry / exit plane indices of this axis, one byte each
+    for (int a = 0; a < 3; ++a) {
+        k[a] = bvh4_scale(exps, a) * id[a];
+        const float base = (org[a] - o[a]) * id[a];
+        const float err = __builtin_fmaf(255.0f, fabsf(k[a]), fabsf(base)) * 2.384185791015625e-07f; // 2^-22
+        base_in[a] = base - err, base_out[a] = base + err;
+        const bool forward = id[a] >= 0.0f;
+        q_in[a] = forward ? qlo_w[a] : qhi_w[a], q_out[a] = forward ? qhi_w[a] : qlo_w[a];
+    }
+
+    const float none = 3.402823466e+38f, slack = 4.76837158203125e-07f; // 2^-21
     float dist[4];
     n_hit = 0;
     for (int c = 0; c < 4; ++c) {
         const int sh = 8 * c;
-        const float lo[3] = {bvh4_dequant((qlx >> sh) & 0xffu, sx, w0.x), bvh4_dequant((qly >> sh) & 0xffu, sy, w0.y),
-                             bvh4_dequant((qlz >> sh) & 0xffu, sz, w0.z)};
-        const float hi[3] = {bvh4_dequant((qhx >> sh) & 0xffu, sx, w0.x), bvh4_dequant((qhy >> sh) & 0xffu, sy, w0.y),
-                             bvh4_dequant((qhz >> sh) & 0xffu, sz, w0.z)};
-        float d;
-        const bool hit = bbox_test(ro, inv_d, t, lo, hi, d) && child[c] != BVH4_EMPTY;
-        dist[c] = hit ? d : none;
+        float t_in[3], t_out[3];
+        for (int a = 0; a < 3; ++a) {
+            t_in[a] = __builtin_fmaf(float((q_in[a] >> sh) & 0xffu), k[a], base_in[a]);
+            t_out[a] = __builtin_fmaf(float((q_out[a] >> sh) & 0xffu), k[a], base_out[a]);
+        }
+        const float tmin = fmaxf(fmaxf(t_in[0], t_in[1]), t_in[2]), tmax = fminf(fminf(t_out[0], t_out[1]), t_out[2]);
+        const float tmin_c = __builtin_fmaf(-fabsf(tmin), slack, tmin), tmax_c = __builtin_fmaf(fabsf(tmax), slack, tmax);
+        const bool hit = tmin_c <= tmax_c && tmin_c <= t && tmax_c > 0.0f && child[c] != BVH4_EMPTY;
+        dist[c] = hit ? tmin : none;
         ref[c] = child[c];
         n_hit += hit ? 1u : 0u;
     }

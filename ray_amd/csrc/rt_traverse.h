@@ -344,27 +344,46 @@ RT_HD bool closest_resolve_transparency(const SceneView &sc, const TraceParams &
     return true;
 }
 
+// is the surface the hit landed on opaque for the transparency loop?  (the first test of closest_resolve_transparency,
+// CoreRef.cpp:3071-3079 -- true for almost every hit, and it needs nothing of the ray)
+RT_HD bool hit_side_is_solid(const SceneView &sc, const Hit &inter) {
+    const bool is_backfacing = (inter.prim_index < 0);
+    const uint32_t tri_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
+    const rayhip_tri_mat_data md = sc.tri_materials[tri_index];
+    return (!is_backfacing && (md.front_mi & MATERIAL_SOLID_BIT)) || (is_backfacing && (md.back_mi & MATERIAL_SOLID_BIT));
+}
+
 // Ref::IntersectScene, closest hit + transparency/mix resolve loop.  CoreRef.cpp:3041-3158.
-// In: r (o,d,c,depth,xy), inter (t preset by the caller: clip range for primary rays, MAX_DIST otherwise).
+// In: r (o, d and the ray type in depth), inter (t preset by the caller: clip range for primary rays, MAX_DIST otherwise).
 // Out: inter; r.c and r.depth are updated when transparent surfaces are crossed.
-template <bool WIDE = false, class Stack>
-RT_HD void intersect_scene_closest(const SceneView &sc, const TraceParams &tp, Ray &r, Hit &inter, Stack &st,
-                                   TravCount *cnt) {
+// `tail(r, tp)`: called once, right before the first non-solid hit is resolved, to complete what the walk itself never
+// touches -- throughput, pixel, depth counters, and the per-layer parameters that depend on the pixel.  The device keeps
+// those in memory instead of in registers across the walk (k_trace_closest); the default does nothing (ray complete).
+struct RayTailComplete {
+    RT_HD void operator()(Ray &, TraceParams &) const {}
+};
+template <bool WIDE = false, class Stack, class Tail = RayTailComplete>
+RT_HD void intersect_scene_closest(const SceneView &sc, const TraceParams &tp_in, Ray &r, Hit &inter, Stack &st, TravCount *cnt,
+                                   Tail &&tail = Tail()) {
     const f3 rd = r.d;
     f3 ro = r.o;
-
     const uint32_t ray_flags = (1u << get_ray_type(r.depth));
 
-    const uint32_t px_hash = hash(r.xy);
-    const uint32_t rand_hash = hash_combine(px_hash, tp.rand_seed);
-
-    uint32_t rand_dim = RAND_DIM_BASE_COUNT + get_total_depth(r.depth) * RAND_DIM_BOUNCE_COUNT;
+    TraceParams tp = tp_in;
+    bool resolving = false;
+    uint32_t rand_hash = 0, rand_dim = 0;
     while (true) {
         const float t_val = inter.t;
 
         const bool hit_found = traverse_closest<WIDE>(sc, ro, rd, ray_flags, tp.root_index, inter, st, cnt);
-        if (!hit_found) {
+        if (!hit_found || hit_side_is_solid(sc, inter)) {
             break;
+        }
+        if (!resolving) {
+            tail(r, tp);
+            rand_hash = hash_combine(hash(r.xy), tp.rand_seed);
+            rand_dim = RAND_DIM_BASE_COUNT + get_total_depth(r.depth) * RAND_DIM_BOUNCE_COUNT;
+            resolving = true;
         }
         if (!closest_resolve_transparency(sc, tp, r, inter, t_val, rd, ro, rand_dim, rand_hash)) {
             break;
