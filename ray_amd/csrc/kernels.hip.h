@@ -7,7 +7,7 @@
 //                                               reference's BVH2 with visit counters), k_trace_closest_refill (opt-in)
 //   K3  intersect_scene_shadow.comp.glsl     -> k_trace_shadow
 //   K4  intersect_area_lights.comp.glsl      -> k_intersect_area_lights (+ k_shadow_blockers for the shadow-ray form)
-//   K5  shade.comp.glsl (PRIMARY/SECONDARY)  -> k_shade<PRIMARY>
+//   K5  shade.comp.glsl (PRIMARY/SECONDARY)  -> shade_kernels.hip: k_surface / k_light_pick / k_scatter / k_shade_emissive
 //   K9  prepare_indir_args.comp.glsl         -> (gone) ray counts stay in HBM; every stage is launched with a
 //                                               fixed grid and grid-strides over the count it reads there, so the
 //                                               bounce loop never returns to the host (RendererVK.cpp:641-712 records
@@ -63,6 +63,7 @@ __device__ __forceinline__ void prof_wait(float4 &a, float4 &b, float4 &c, float
 #include "rt_params.h"
 #include "rt_pixel.h"
 #include "rt_sort.h"
+#include "wavefront.hip.h"
 
 namespace rt {
 
@@ -83,7 +84,6 @@ namespace rt {
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 3 // 168 VGPRs: with the final kernels 2.10 ms/iteration vs 2.32 at 2 waves (215 VGPRs) and at 4 (128 VGPRs, 284 B scratch)
 #endif
-constexpr int WAVE = 64;
 constexpr int LDS_STACK_DEPTH = RT_LDS_STACK_DEPTH;
 constexpr int STACK_TOTAL_DEPTH = 2 * MAX_STACK_SIZE; // TLAS + BLAS, 48 each in the reference
 constexpr int STACK_SPILL_DEPTH = STACK_TOTAL_DEPTH - LDS_STACK_DEPTH;
@@ -129,100 +129,7 @@ struct LdsStack {
     }
 };
 
-// Reserve one output slot per lane with `pred` set: one atomicAdd per wavefront.
-__device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter, const bool pred) {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) {
-        return 0u;
-    }
-    const uint32_t lane = __lane_id();
-    const uint32_t prefix = uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (int(lane) == leader) {
-        base = atomicAdd(counter, uint32_t(__popcll(mask)));
-    }
-    base = uint32_t(__shfl(int(base), leader));
-    return base + prefix;
-}
-
-// Striped ray queue.  The slots of a wavefront-state buffer are split into `stripes` equal segments, each with its
-// own fill counter on its own 256-byte line.  A 64-ray chunk read from stripe s writes its survivors to stripe s of
-// the output queue, so (a) a stripe can never overflow -- it receives at most what it held, and the ray generator
-// deals pixel chunks round-robin -- and (b) the one-atomic-per-wavefront slot allocation is spread over `stripes`
-// addresses.  Measured on MI355X (tools/atomic_bench.hip): 11.5 ns per atomic on one counter, 0.37 ns on 64; with
-// one counter the 250 k allocations of a 1080p frame were half of the shade kernels' time.  Rays stay densely packed
-// inside each stripe, so wavefronts stay full; stripes == 1 is the plain dense queue (kernel-level test hooks, ray
-// sort).
-constexpr uint32_t QUEUE_COUNTER_STRIDE = 64; // uint32 words between stripe counters
-constexpr uint32_t QUEUE_MAX_STRIPES = 64;
-struct RayQueue {
-    uint32_t *counts; // counts[s * QUEUE_COUNTER_STRIDE] = rays in stripe s
-    uint32_t stripes;
-    uint32_t chunks_per_stripe; // stripe capacity / 64
-
-    __device__ __forceinline__ uint32_t total_chunks() const { return stripes * chunks_per_stripe; }
-    // Chunk indices that can hold rays: chunks are numbered stripe-minor, so nothing lives beyond the fullest stripe's
-    // last chunk.  A consumer that walks [0, live_chunks()) instead of [0, total_chunks()) does not poll the empty tail of
-    // the queue (late bounces fill a few per cent of it; with a 16x oversubscribed grid the polling was 16 % of the shade
-    // kernel's wave time).  Wavefront-collective: call with all 64 lanes active.
-    __device__ __forceinline__ uint32_t live_chunks() const {
-        const uint32_t lane = __lane_id();
-        uint32_t fill = lane < stripes ? counts[lane * QUEUE_COUNTER_STRIDE] : 0u;
-        for (int m = 32; m >= 1; m >>= 1) {
-            fill = max(fill, uint32_t(__shfl_xor(int(fill), m)));
-        }
-        return uint32_t(__builtin_amdgcn_readfirstlane(int(min(total_chunks(), stripes * ((fill + WAVE - 1) / WAVE)))));
-    }
-    // chunk c (wave-uniform) -> its stripe, first slot and number of live lanes; false if the chunk is empty.
-    // Chunks are numbered stripe-minor so that consecutive wavefronts work on different stripes.
-    __device__ __forceinline__ bool chunk(const uint32_t c, uint32_t &stripe, uint32_t &slot0, uint32_t &n_live) const {
-        stripe = c % stripes;
-        const uint32_t j = c / stripes;
-        const uint32_t n = counts[stripe * QUEUE_COUNTER_STRIDE];
-        if (j * WAVE >= n) {
-            return false;
-        }
-        slot0 = (stripe * chunks_per_stripe + j) * WAVE;
-        n_live = n - j * WAVE < uint32_t(WAVE) ? n - j * WAVE : uint32_t(WAVE);
-        return true;
-    }
-    __device__ __forceinline__ uint32_t alloc(const uint32_t stripe, const bool pred) const {
-        return stripe * chunks_per_stripe * WAVE + wave_alloc(counts + stripe * QUEUE_COUNTER_STRIDE, pred);
-    }
-};
-
-// hits of importance-sampled emitters whose MIS weight is evaluated by k_shade_emissive
-struct DeferredSoA {
-    float4 *a; // ray slot, tri_index, material index (bits), mix_weight
-    float4 *b; // base_color.rgb
-};
-
-struct PixelBuffers {
-    float4 *temp; // [layers][h][w]: radiance of the iteration(s) in flight
-    float4 *full, *half, *raw, *final_, *base_color, *depth_normals;
-    uint16_t *required_samples;
-    float4 *aux_base_layers, *aux_dn_layers; // [layers][h][w], batched passes only (rt_pixel.h)
-    float4 *variance; // [h][w]: the variance estimate of the last accumulate (the reference leaves it in its temp buffer,
-                      // RendererCPU.h:641-645; DenoiseImage reads it from there)
-};
-
-// per-layer part of AccumParams for a batched pass
-struct AccumLayer {
-    int iteration;
-    float mix_factor, half_mix_factor;
-    int is_class_a;
-    float variance_threshold;
-};
-#ifndef RT_MAX_BATCH
-#define RT_MAX_BATCH 64
-#endif
-constexpr int MAX_BATCH = RT_MAX_BATCH;
-struct AccumLayers {
-    AccumLayer l[MAX_BATCH];
-};
-
-__device__ __forceinline__ uint32_t layer_rand_seed(const int iteration) { return hash(uint32_t((iteration - 1) / RAND_SAMPLES_COUNT)); }
+// (wave_alloc, RayQueue, the SoA / pixel-buffer structs: wavefront.hip.h; the shade kernels K5: shade_kernels.hip)
 
 // which 8x8 pixel tiles the ray generator walks (see k_raygen)
 struct RayGenTiling {
@@ -759,246 +666,6 @@ __global__ void __launch_bounds__(WAVE) k_shadow_blockers(const SceneView sc, co
             cx.x = cx.y = cx.z = 0.0f;
             shadow.c_xy[i] = cx;
         }
-    }
-}
-
-// ---- K5: shade, as three stages with a queue of shade points between them ------------------------------------------------
-// (reference kernel: shade.comp.glsl, one thread per ray doing everything; here cut where the working set changes --
-// shade_point.h has the rationale)
-//   k_surface      (ray, hit) -> pixel radiance for paths that end (miss, emitter hit, culled back face, emissive surface)
-//                  or a ShadePoint (7 float4 planes) appended to the point queue of its stripe; first-hit feature images
-//   k_light_pick   light-tree descent for every point: reads 16 B, writes 16 B per point, nothing else live
-//   k_scatter      samples the picked light, evaluates the material towards it (-> shadow ray), draws the continuation
-//                  (-> secondary ray), Russian roulette.  <NEE, CONTINUE> lets the two halves run as one launch or two.
-// Occupancy hints (waves per SIMD) are per stage; the register budget of the old one-kernel form was set by the sum of
-// all three working sets (168 VGPRs, 3 waves).
-#ifndef RT_SURFACE_MIN_WAVES
-#define RT_SURFACE_MIN_WAVES 4
-#endif
-#ifndef RT_PICK_MIN_WAVES
-#define RT_PICK_MIN_WAVES 8
-#endif
-#ifndef RT_SCATTER_MIN_WAVES
-#define RT_SCATTER_MIN_WAVES 4
-#endif
-
-// ShadePoint in memory: SoA float4 planes, one store / load instruction per plane and wavefront (1 KiB each)
-struct PointSoA {
-    float4 *p_slot;  // P.xyz | slot of the ray that produced the point
-    float4 *n_gx;    // N.xyz | plane_N.x
-    float4 *b_gy;    // B.xyz | plane_N.y
-    float4 *base_gz; // base.rgb | plane_N.z
-    float4 *scalars; // roughness, metallic, specular, mix_weight
-    float4 *misc;    // mix_pick, material | backfacing << 31, cone_width, -
-    float4 *light;   // written by k_light_pick: light index, 1 / pick probability, rest of the random number, -
-};
-__device__ __forceinline__ void store_point(const PointSoA &s, const uint32_t i, const ShadePoint &pt, const uint32_t ray_slot) {
-    s.p_slot[i] = mkfloat4(pt.P.x, pt.P.y, pt.P.z, uint_as_float(ray_slot));
-    s.n_gx[i] = mkfloat4(pt.N.x, pt.N.y, pt.N.z, pt.plane_N.x);
-    s.b_gy[i] = mkfloat4(pt.B.x, pt.B.y, pt.B.z, pt.plane_N.y);
-    s.base_gz[i] = mkfloat4(pt.base.x, pt.base.y, pt.base.z, pt.plane_N.z);
-    s.scalars[i] = mkfloat4(pt.roughness, pt.metallic, pt.specular, pt.mix_weight);
-    s.misc[i] = mkfloat4(pt.mix_pick, uint_as_float(pt.material | (pt.backfacing ? 0x80000000u : 0u)), pt.cone_width, 0.0f);
-}
-__device__ __forceinline__ ShadePoint load_point(const PointSoA &s, const uint32_t i, uint32_t &ray_slot) {
-    const float4 a = s.p_slot[i], b = s.n_gx[i], c = s.b_gy[i], d = s.base_gz[i], e = s.scalars[i], f = s.misc[i];
-    ShadePoint pt;
-    pt.P = {a.x, a.y, a.z}, ray_slot = float_as_uint(a.w);
-    pt.N = {b.x, b.y, b.z}, pt.B = {c.x, c.y, c.z}, pt.plane_N = {b.w, c.w, d.w};
-    pt.base = {d.x, d.y, d.z};
-    pt.roughness = e.x, pt.metallic = e.y, pt.specular = e.z, pt.mix_weight = e.w;
-    pt.mix_pick = f.x;
-    const uint32_t m = float_as_uint(f.y);
-    pt.material = m & 0x7fffffffu, pt.backfacing = (m >> 31) != 0;
-    pt.cone_width = f.z;
-    return pt;
-}
-__device__ __forceinline__ void store_pick(const PointSoA &s, const uint32_t i, const LightPick &k) {
-    s.light[i] = mkfloat4(uint_as_float(k.light), k.inv_prob, k.u_left, 0.0f);
-}
-__device__ __forceinline__ LightPick load_pick(const PointSoA &s, const uint32_t i) {
-    const float4 v = s.light[i];
-    return LightPick{float_as_uint(v.x), v.y, v.z};
-}
-
-// the parameters of the layer a (virtual) pixel belongs to: later iterations of a batched pass carry their own sample
-// index and seed, and their random numbers are keyed by the REAL pixel (rt_base.h: Layering)
-__device__ __forceinline__ ShadeParams layer_params(const ShadeParams &sp, const uint32_t layer) {
-    ShadeParams p = sp;
-    if (layer != 0) {
-        p.iteration = sp.iteration + int(layer);
-        p.rand_seed = layer_rand_seed(p.iteration);
-    }
-    return p;
-}
-
-template <bool PRIMARY, bool PICK>
-__global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
-                                                                       const RayQueue in, const PointSoA points, const RayQueue out_points,
-                                                                       const DeferredSoA deferred_out, const RayQueue out_deferred,
-                                                                       const PixelBuffers px, const int img_w, const float mix_factor,
-                                                                       const Layering layers) {
-    const uint32_t n_live_chunks = in.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
-        uint32_t stripe, slot0, n_live;
-        if (!in.chunk(c, stripe, slot0, n_live)) {
-            continue;
-        }
-        const uint32_t i = slot0 + threadIdx.x; // (the whole wavefront stays in the body for the ballots)
-        const bool active = threadIdx.x < n_live;
-        bool continues = false, defer = false;
-        ShadePoint pt;
-        SurfaceOut so;
-        LightPick pick = no_light_pick();
-        if (active) {
-            Ray ray = load_ray(rays_in, i);
-            const Hit hit = load_hit(hits, i);
-            const uint32_t xy = ray.xy; // virtual (layered) pixel: where the pixel writes go
-            const uint32_t layer = xy_layer(xy, layers);
-            const ShadeParams spl = layer_params(sp, layer);
-            ray.xy = xy_real(xy, layers, layer);
-            continues = surface_stage<true>(sc, spl, hit, ray, pt, so); // (emitter MIS weights: k_shade_emissive)
-            defer = so.deferred_emitter;
-            if (PRIMARY) {
-                // the pixel of a continuing path starts at (0, 0, 0, 1); the scatter stage adds what shadow-less lights give
-                ShadeResult res;
-                res.col = continues ? f4{0.0f, 0.0f, 0.0f, 1.0f} : so.radiance;
-                res.base_color = so.base_color, res.depth_normal = so.normal_depth;
-                if (layers.count > 1) {
-                    write_primary_pixel_layered(res, xy, img_w, px.temp, px.aux_base_layers, px.aux_dn_layers);
-                } else {
-                    write_primary_pixel(res, xy, img_w, mix_factor, px.temp, px.base_color, px.depth_normals);
-                }
-            } else if (!continues) {
-                ShadeResult res;
-                res.col = so.radiance;
-                add_secondary_pixel(res, xy, img_w, px.temp);
-            }
-            if (PICK && continues && sc.light_cwnodes_count != 0) {
-                pick = pick_light(sc, pt.P, light_pick_random(sc, spl, ray.xy, ray.depth));
-            }
-        }
-        // survivors go to the stripe they came from (RayQueue)
-        const uint32_t p_slot = out_points.alloc(stripe, continues);
-        if (continues) {
-            store_point(points, p_slot, pt, i);
-            if (PICK) {
-                store_pick(points, p_slot, pick);
-            }
-        }
-        if (__any(defer)) { // rare
-            const uint32_t d_slot = out_deferred.alloc(stripe, defer);
-            if (defer) {
-                deferred_out.a[d_slot] = mkfloat4(uint_as_float(i), uint_as_float(so.emitter_triangle), uint_as_float(pt.material), so.emitter_mix_weight);
-                deferred_out.b[d_slot] = mkfloat4(pt.base.x, pt.base.y, pt.base.z, 0.0f);
-            }
-        }
-    }
-}
-
-__global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
-                                                                       const PointSoA points, const RayQueue queue, const Layering layers) {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t n_live_chunks = queue.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
-        uint32_t stripe, slot0, n_live;
-        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
-            continue;
-        }
-        const uint32_t i = slot0 + lane;
-        const float4 ps = points.p_slot[i];
-        const uint2 xd = rays_in.xy_depth[float_as_uint(ps.w)];
-        const uint32_t layer = xy_layer(xd.x, layers);
-        const ShadeParams spl = layer_params(sp, layer);
-        store_pick(points, i, pick_light(sc, f3{ps.x, ps.y, ps.z}, light_pick_random(sc, spl, xy_real(xd.x, layers, layer), xd.y)));
-    }
-}
-
-template <bool NEE, bool CONTINUE>
-__global__ void __launch_bounds__(WAVE, RT_SCATTER_MIN_WAVES) k_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
-                                                                       const PointSoA points, const RayQueue in, const RaySoA rays_out,
-                                                                       const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
-                                                                       const PixelBuffers px, const int img_w, const Layering layers) {
-    const uint32_t n_live_chunks = in.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
-        uint32_t stripe, slot0, n_live;
-        if (!in.chunk(c, stripe, slot0, n_live)) {
-            continue;
-        }
-        const bool active = threadIdx.x < n_live;
-        Scatter sct;
-        sct.has_next = sct.has_shadow = false;
-        uint32_t xy = 0;
-        if (active) {
-            uint32_t ray_slot;
-            const ShadePoint pt = load_point(points, slot0 + threadIdx.x, ray_slot);
-            const LightPick pick = (NEE && sc.light_cwnodes_count != 0) ? load_pick(points, slot0 + threadIdx.x) : no_light_pick();
-            Ray ray;
-            {
-                const float4 d = rays_in.d_cw[ray_slot], cc = rays_in.c_cs[ray_slot], io = rays_in.ior[ray_slot];
-                const uint2 xd = rays_in.xy_depth[ray_slot];
-                ray.o = pt.P, ray.pdf = 0.0f; // (not read by the scatter stage)
-                ray.d = {d.x, d.y, d.z}, ray.cone_width = d.w;
-                ray.c = {cc.x, cc.y, cc.z}, ray.cone_spread = cc.w;
-                ray.ior[0] = io.x, ray.ior[1] = io.y, ray.ior[2] = io.z, ray.ior[3] = io.w;
-                ray.xy = xd.x, ray.depth = xd.y;
-            }
-            xy = ray.xy;
-            const uint32_t layer = xy_layer(xy, layers);
-            const ShadeParams spl = layer_params(sp, layer);
-            ray.xy = xy_real(xy, layers, layer);
-            scatter_stage<NEE, CONTINUE>(sc, spl, ray, pt, pick, sct);
-            sct.next.xy = xy, sct.shadow.xy = xy;
-            if (NEE) {
-                const f3 col = direct_radiance(spl, sct, ray.c);
-                if (col.x != 0.0f || col.y != 0.0f || col.z != 0.0f) { // (x + 0 == x: the add is skipped when nothing is booked)
-                    ShadeResult res;
-                    res.col = mk4(col, 1.0f);
-                    add_secondary_pixel(res, xy, img_w, px.temp);
-                }
-            }
-        }
-        if (NEE) {
-            const uint32_t sh_slot = out_shadow.alloc(stripe, sct.has_shadow);
-            if (sct.has_shadow) {
-                store_shadow(shadow_out, sh_slot, sct.shadow);
-            }
-        }
-        if (CONTINUE) {
-            const uint32_t ray_slot = out_rays.alloc(stripe, sct.has_next);
-            if (sct.has_next) {
-                store_ray(rays_out, ray_slot, sct.next);
-            }
-        }
-    }
-}
-
-// MIS-weighted radiance of importance-sampled emitters that secondary rays hit (shade_point.h: emissive_hit_mis_weight): a
-// light-tree walk + a spherical-triangle density per hit -- rare, but every wavefront containing one used to pay for it.
-// Runs after k_surface of the same bounce on the ray / hit buffers that kernel read; such a path ends there (k_surface booked
-// zero radiance for it), so this is the only contribution of its pixel in this bounce and the per-pixel addition order of
-// the reference is kept.  (First bounce: only camera rays that crossed a transparent surface can get here.)
-__global__ void __launch_bounds__(WAVE) k_shade_emissive(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
-                                                        const DeferredSoA deferred, const RayQueue queue, const PixelBuffers px,
-                                                        const int img_w) {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t n_live_chunks = queue.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
-        uint32_t stripe, slot0, n_live;
-        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
-            continue;
-        }
-        const float4 a = deferred.a[slot0 + lane], b = deferred.b[slot0 + lane];
-        const uint32_t i = float_as_uint(a.x), tri = float_as_uint(a.y), material = float_as_uint(a.z);
-        const float4 o = rays_in.o_pdf[i], d = rays_in.d_cw[i], throughput = rays_in.c_cs[i];
-        const uint32_t xy = rays_in.xy_depth[i].x;
-        const Hit hit = load_hit(hits, i);
-        const f3 origin = {o.x, o.y, o.z}, dir = {d.x, d.y, d.z};
-        const float mis = emissive_hit_mis_weight(sc, origin, dir, origin + hit.t * dir, hit.t, o.w, tri, &sc.mesh_instances[hit.obj_index]);
-        ShadeResult res;
-        res.col = emissive_hit_radiance(sp, a.w, mis, sc.materials[material].tangent_rotation_or_strength, f3{b.x, b.y, b.z},
-                                        f3{throughput.x, throughput.y, throughput.z});
-        add_secondary_pixel(res, xy, img_w, px.temp);
     }
 }
 

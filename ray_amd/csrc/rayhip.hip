@@ -17,6 +17,7 @@
 
 #include "../../include/rayhip.h"
 #include "kernels.hip.h" // first: it configures the profiling macros the rt_*.h headers expand
+#include "shade_launch.h"
 #include "bvh4_build.h"
 #include "bvh_layout.h"
 #include "scene_blob.h"
@@ -92,7 +93,7 @@ struct rayhip_ctx {
     DevBuf pmj, filter_table;
     // scene
     DevBuf nodes, tris, tri_indices, tri_materials, materials, vertices, vtx_indices, mesh_instances, lights, li_indices,
-        light_cwnodes, light_children, light_tri_geom, tri_verts, textures, texels, nodes4, blas_root4, env_qtree;
+        light_cwnodes, light_children, light_tri_geom, tri_verts, tri_bitangents, textures, texels, nodes4, blas_root4, env_qtree;
     SceneView sc = {};
     float bbox_min[3] = {}, bbox_max[3] = {};
     bool have_scene = false;
@@ -423,6 +424,15 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         return 1;
     }
     (void)hipMemsetAsync(c->trav_counters.p, 0, sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS, c->stream);
+    // the stage stopwatch's events exist up front: creating them lazily put ~30 ms of runtime initialisation into the first
+    // timed pass of a process
+    for (int k = 0; k < 256; ++k) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+            break;
+        }
+        c->events.push_back(e);
+    }
     *out_ctx = c;
     return 0;
 }
@@ -437,7 +447,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         (void)hipEventDestroy(e);
     }
     DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
-                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->light_tri_geom, &c->tri_verts, &c->nodes4, &c->blas_root4, &c->env_qtree,
+                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->light_tri_geom, &c->tri_verts, &c->tri_bitangents, &c->nodes4, &c->blas_root4, &c->env_qtree,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
                      &c->px_dn, &c->px_req, &c->px_aux_base, &c->px_aux_dn, &c->px_variance, &c->nlm_tm, &c->nlm_var_h, &c->nlm_var,
                      &c->tonemap_lut, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
@@ -641,14 +651,14 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         UPLOAD_TRACE("light_children done")
         { // vertices gathered per triangle (shade_point.h: fill_tri_verts)
             const uint32_t n_tris = d->vtx_indices_count / 3;
-            std::vector<float4> tv(size_t(n_tris) * TRI_VERTS_STRIDE);
+            std::vector<float4> tv(size_t(n_tris) * TRI_VERTS_STRIDE), tb(size_t(n_tris) * TRI_BITANGENTS_STRIDE);
             for (uint32_t t = 0; t < n_tris; ++t) {
-                fill_tri_verts(d->vertices, d->vertices_count, d->vtx_indices, t, &tv[size_t(t) * TRI_VERTS_STRIDE]);
+                fill_tri_verts(d->vertices, d->vertices_count, d->vtx_indices, t, &tv[size_t(t) * TRI_VERTS_STRIDE], &tb[size_t(t) * TRI_BITANGENTS_STRIDE]);
             }
-            if (upload(c, c->tri_verts, tv.data(), tv.size() * sizeof(float4))) {
+            if (upload(c, c->tri_verts, tv.data(), tv.size() * sizeof(float4)) || upload(c, c->tri_bitangents, tb.data(), tb.size() * sizeof(float4))) {
                 return 1;
             }
-            HIP_TRY(hipStreamSynchronize(c->stream)); // `tv` goes out of scope
+            HIP_TRY(hipStreamSynchronize(c->stream)); // `tv`, `tb` go out of scope
         }
         UPLOAD_TRACE("tri_verts done")
         // world-space corners of the TRI lights (shade_lights.h: fill_light_tri_geom)
@@ -687,6 +697,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     v.light_children = c->light_children.as<float4>();
     v.light_tri_geom = c->light_tri_geom.as<float4>();
     v.tri_verts = c->tri_verts.as<float4>();
+    v.tri_bitangents = c->tri_bitangents.as<float4>();
     v.env_qtree = c->env_qtree.as<float4>();
     for (int lod = 0, off = 0; lod < 16; ++lod) {
         v.env_qtree_offset[lod] = uint32_t(off);
@@ -807,39 +818,17 @@ static int ensure_pass(rayhip_ctx *c, const int rect[4], int n) {
 // rayhip_render and the kernel-level hook rayhip_k_shade.
 static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration, int bounce, int cur, size_t nslots, uint32_t stripes,
                          int gtrace, int vw, float mix_factor, const Layering &layers) {
-    hipStream_t s = c->stream;
-    const ShadeParams sp = make_shade_params(cam, iteration, bounce);
-    const RayQueue in = c->ray_queue(bounce, nslots, stripes), pts = c->point_queue(bounce, nslots, stripes);
-    const RayQueue out_rays = c->ray_queue(bounce + 1, nslots, stripes), out_shadow = c->shadow_queue(bounce, nslots, stripes);
-    const RayQueue out_deferred = c->deferred_queue(bounce, nslots, stripes);
-    const bool pick_apart = (c->shade_split & 1) != 0 && c->sc.light_cwnodes_count != 0;
-    // stage 1: what was hit
-    if (bounce == 0) {
-        if (pick_apart) {
-            k_surface<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, in, c->points, pts, c->deferred, out_deferred, c->px, vw, mix_factor, layers);
-        } else {
-            k_surface<true, true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, in, c->points, pts, c->deferred, out_deferred, c->px, vw, mix_factor, layers);
-        }
-    } else {
-        if (pick_apart) {
-            k_surface<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, in, c->points, pts, c->deferred, out_deferred, c->px, vw, mix_factor, layers);
-        } else {
-            k_surface<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, in, c->points, pts, c->deferred, out_deferred, c->px, vw, mix_factor, layers);
-        }
-    }
-    // emitter hits whose MIS weight was deferred; an empty queue costs a few microseconds
-    k_shade_emissive<<<std::min(gtrace, 2048), WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->hits, c->deferred, out_deferred, c->px, vw);
-    // stage 2: which light
-    if (pick_apart) {
-        k_light_pick<<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->points, pts, layers);
-    }
-    // stage 3: shadow ray + continuation
-    if ((c->shade_split & 2) != 0) {
-        k_scatter<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->points, pts, c->rays[cur ^ 1], out_rays, c->shadow, out_shadow, c->px, vw, layers);
-        k_scatter<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->points, pts, c->rays[cur ^ 1], out_rays, c->shadow, out_shadow, c->px, vw, layers);
-    } else {
-        k_scatter<true, true><<<gtrace, WAVE, 0, s>>>(c->sc, sp, c->rays[cur], c->points, pts, c->rays[cur ^ 1], out_rays, c->shadow, out_shadow, c->px, vw, layers);
-    }
+    ShadeLaunch a;
+    a.sc = c->sc;
+    a.sp = make_shade_params(cam, iteration, bounce);
+    a.rays_in = c->rays[cur], a.rays_out = c->rays[cur ^ 1];
+    a.hits = c->hits, a.shadow = c->shadow, a.deferred = c->deferred, a.points = c->points;
+    a.in = c->ray_queue(bounce, nslots, stripes), a.pts = c->point_queue(bounce, nslots, stripes);
+    a.out_rays = c->ray_queue(bounce + 1, nslots, stripes), a.out_shadow = c->shadow_queue(bounce, nslots, stripes);
+    a.out_deferred = c->deferred_queue(bounce, nslots, stripes);
+    a.px = c->px, a.layers = layers, a.vw = vw, a.mix_factor = mix_factor;
+    a.bounce = bounce, a.grid = gtrace, a.split = c->shade_split, a.stream = c->stream;
+    shade::launch(a);
 }
 
 // One wavefront pass over `count` consecutive iterations of the rect (count == 1: the plain case; > 1: layered, see

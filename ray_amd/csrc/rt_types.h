@@ -34,7 +34,8 @@ struct SceneView {
     const uint32_t *li_indices;
     const rayhip_light_cwbvh_node *light_cwnodes;
     const float4 *light_children; // LIGHT_CHILDREN_STRIDE float4 per light-tree node (shade_lights.h: fill_light_children)
-    const float4 *tri_verts;      // 9 float4 per triangle: its three vertices, gathered and 16-byte aligned (shade_point.h: fill_tri_verts)
+    const float4 *tri_verts;      // 8 float4 per triangle: corners (position, normal, uv) + plane + uv area (shade_point.h: fill_tri_verts)
+    const float4 *tri_bitangents; // 4 float4 per triangle: the corners' bitangents (normal-mapped materials only)
     const float4 *light_tri_geom; // 4 float4 per light: world-space corners + uvs of a TRI light (shade_lights.h: fill_light_tri_geom)
     const rayhip_texture *textures;
     const uint32_t *texels;

@@ -1,0 +1,289 @@
+// shade_kernels.hip -- K5, the shade stage of the wavefront path tracer, as its own translation unit.
+//
+// Why a separate unit: the shade kernels are two thirds of the device code of the library (k_scatter alone is ~20 k
+// instructions); compiled next to the traversal kernels in parallel they halve the build time, and build-time experiments
+// on one side do not touch the other.
+// One such experiment is recorded here because its result shapes the code: compiling this unit with
+// -fno-hip-fp32-correctly-rounded-divide-sqrt (division = v_rcp_f32 + multiply, <= 2.5 ulp; square root = v_sqrt_f32) removes
+// a quarter of the instructions -- the stage is bound by VALU issue, k_scatter holds 464 correctly rounded divisions at ~10
+// instructions each -- and makes it 0.3 ms per 1080p iteration faster (1.94 -> 1.66 ms, MI355X, Bistro-class scene).  It also
+// moves 0.47 % of the pixels of a 1-spp frame out of the stated tolerance (PSNR 37.8 dB against the oracle instead of 133 dB):
+// the solid angle of a triangle emitter is computed as alpha + beta + gamma - pi (Arvo), a difference of O(1) angles that is
+// O(1e-3) for the light triangles of that scene, so 2-ulp operations upstream become 1e-3 relative errors in the density.
+// The shade stage therefore keeps IEEE division and square root (only the light-tree importance heuristic, which steers
+// probabilities the estimator divides out again, uses the hardware reciprocal / square root: shade_lights.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "shade_launch.h"
+
+namespace rt {
+namespace shade {
+
+// ---- K5: shade, as three stages with a queue of shade points between them ------------------------------------------------
+// (reference kernel: shade.comp.glsl, one thread per ray doing everything; here cut where the working set changes --
+// shade_point.h has the rationale)
+//   k_surface      (ray, hit) -> pixel radiance for paths that end (miss, emitter hit, culled back face, emissive surface)
+//                  or a ShadePoint (7 float4 planes) appended to the point queue of its stripe; first-hit feature images
+//   k_light_pick   light-tree descent for every point: reads 16 B, writes 16 B per point, nothing else live
+//   k_scatter      samples the picked light, evaluates the material towards it (-> shadow ray), draws the continuation
+//                  (-> secondary ray), Russian roulette.  <NEE, CONTINUE> lets the two halves run as one launch or two.
+// Occupancy hints (waves per SIMD) are per stage; the register budget of the old one-kernel form was set by the sum of
+// all three working sets (168 VGPRs, 3 waves).
+#ifndef RT_SURFACE_MIN_WAVES
+#define RT_SURFACE_MIN_WAVES 4
+#endif
+#ifndef RT_PICK_MIN_WAVES
+#define RT_PICK_MIN_WAVES 8
+#endif
+#ifndef RT_SCATTER_MIN_WAVES
+#define RT_SCATTER_MIN_WAVES 4
+#endif
+
+__device__ __forceinline__ void store_point(const PointSoA &s, const uint32_t i, const ShadePoint &pt, const uint32_t ray_slot) {
+    s.p_slot[i] = mkfloat4(pt.P.x, pt.P.y, pt.P.z, uint_as_float(ray_slot));
+    s.n_gx[i] = mkfloat4(pt.N.x, pt.N.y, pt.N.z, pt.plane_N.x);
+    s.b_gy[i] = mkfloat4(pt.B.x, pt.B.y, pt.B.z, pt.plane_N.y);
+    s.base_gz[i] = mkfloat4(pt.base.x, pt.base.y, pt.base.z, pt.plane_N.z);
+    s.scalars[i] = mkfloat4(pt.roughness, pt.metallic, pt.specular, pt.mix_weight);
+    s.misc[i] = mkfloat4(pt.mix_pick, uint_as_float(pt.material | (pt.backfacing ? 0x80000000u : 0u)), pt.cone_width, 0.0f);
+}
+__device__ __forceinline__ ShadePoint load_point(const PointSoA &s, const uint32_t i, uint32_t &ray_slot) {
+    const float4 a = s.p_slot[i], b = s.n_gx[i], c = s.b_gy[i], d = s.base_gz[i], e = s.scalars[i], f = s.misc[i];
+    ShadePoint pt;
+    pt.P = {a.x, a.y, a.z}, ray_slot = float_as_uint(a.w);
+    pt.N = {b.x, b.y, b.z}, pt.B = {c.x, c.y, c.z}, pt.plane_N = {b.w, c.w, d.w};
+    pt.base = {d.x, d.y, d.z};
+    pt.roughness = e.x, pt.metallic = e.y, pt.specular = e.z, pt.mix_weight = e.w;
+    pt.mix_pick = f.x;
+    const uint32_t m = float_as_uint(f.y);
+    pt.material = m & 0x7fffffffu, pt.backfacing = (m >> 31) != 0;
+    pt.cone_width = f.z;
+    return pt;
+}
+__device__ __forceinline__ void store_pick(const PointSoA &s, const uint32_t i, const LightPick &k) {
+    s.light[i] = mkfloat4(uint_as_float(k.light), k.inv_prob, k.u_left, 0.0f);
+}
+__device__ __forceinline__ LightPick load_pick(const PointSoA &s, const uint32_t i) {
+    const float4 v = s.light[i];
+    return LightPick{float_as_uint(v.x), v.y, v.z};
+}
+
+// the parameters of the layer a (virtual) pixel belongs to: later iterations of a batched pass carry their own sample
+// index and seed, and their random numbers are keyed by the REAL pixel (rt_base.h: Layering)
+__device__ __forceinline__ ShadeParams layer_params(const ShadeParams &sp, const uint32_t layer) {
+    ShadeParams p = sp;
+    if (layer != 0) {
+        p.iteration = sp.iteration + int(layer);
+        p.rand_seed = layer_rand_seed(p.iteration);
+    }
+    return p;
+}
+
+template <bool PRIMARY, bool PICK>
+__global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
+                                                                       const RayQueue in, const PointSoA points, const RayQueue out_points,
+                                                                       const DeferredSoA deferred_out, const RayQueue out_deferred,
+                                                                       const PixelBuffers px, const int img_w, const float mix_factor,
+                                                                       const Layering layers) {
+    const uint32_t n_live_chunks = in.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!in.chunk(c, stripe, slot0, n_live)) {
+            continue;
+        }
+        const uint32_t i = slot0 + threadIdx.x; // (the whole wavefront stays in the body for the ballots)
+        const bool active = threadIdx.x < n_live;
+        bool continues = false, defer = false;
+        ShadePoint pt;
+        SurfaceOut so;
+        LightPick pick = no_light_pick();
+        if (active) {
+            Ray ray = load_ray(rays_in, i);
+            const Hit hit = load_hit(hits, i);
+            const uint32_t xy = ray.xy; // virtual (layered) pixel: where the pixel writes go
+            const uint32_t layer = xy_layer(xy, layers);
+            const ShadeParams spl = layer_params(sp, layer);
+            ray.xy = xy_real(xy, layers, layer);
+            continues = surface_stage<true>(sc, spl, hit, ray, pt, so); // (emitter MIS weights: k_shade_emissive)
+            defer = so.deferred_emitter;
+            if (PRIMARY) {
+                // the pixel of a continuing path starts at (0, 0, 0, 1); the scatter stage adds what shadow-less lights give
+                ShadeResult res;
+                res.col = continues ? f4{0.0f, 0.0f, 0.0f, 1.0f} : so.radiance;
+                res.base_color = so.base_color, res.depth_normal = so.normal_depth;
+                if (layers.count > 1) {
+                    write_primary_pixel_layered(res, xy, img_w, px.temp, px.aux_base_layers, px.aux_dn_layers);
+                } else {
+                    write_primary_pixel(res, xy, img_w, mix_factor, px.temp, px.base_color, px.depth_normals);
+                }
+            } else if (!continues) {
+                ShadeResult res;
+                res.col = so.radiance;
+                add_secondary_pixel(res, xy, img_w, px.temp);
+            }
+            if (PICK && continues && sc.light_cwnodes_count != 0) {
+                pick = pick_light(sc, pt.P, light_pick_random(sc, spl, ray.xy, ray.depth));
+            }
+        }
+        // survivors go to the stripe they came from (RayQueue)
+        const uint32_t p_slot = out_points.alloc(stripe, continues);
+        if (continues) {
+            store_point(points, p_slot, pt, i);
+            if (PICK) {
+                store_pick(points, p_slot, pick);
+            }
+        }
+        if (__any(defer)) { // rare
+            const uint32_t d_slot = out_deferred.alloc(stripe, defer);
+            if (defer) {
+                deferred_out.a[d_slot] = mkfloat4(uint_as_float(i), uint_as_float(so.emitter_triangle), uint_as_float(pt.material), so.emitter_mix_weight);
+                deferred_out.b[d_slot] = mkfloat4(pt.base.x, pt.base.y, pt.base.z, 0.0f);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
+                                                                       const PointSoA points, const RayQueue queue, const Layering layers) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_live_chunks = queue.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
+            continue;
+        }
+        const uint32_t i = slot0 + lane;
+        const float4 ps = points.p_slot[i];
+        const uint2 xd = rays_in.xy_depth[float_as_uint(ps.w)];
+        const uint32_t layer = xy_layer(xd.x, layers);
+        const ShadeParams spl = layer_params(sp, layer);
+        store_pick(points, i, pick_light(sc, f3{ps.x, ps.y, ps.z}, light_pick_random(sc, spl, xy_real(xd.x, layers, layer), xd.y)));
+    }
+}
+
+template <bool NEE, bool CONTINUE>
+__global__ void __launch_bounds__(WAVE, RT_SCATTER_MIN_WAVES) k_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
+                                                                       const PointSoA points, const RayQueue in, const RaySoA rays_out,
+                                                                       const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
+                                                                       const PixelBuffers px, const int img_w, const Layering layers) {
+    const uint32_t n_live_chunks = in.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!in.chunk(c, stripe, slot0, n_live)) {
+            continue;
+        }
+        const bool active = threadIdx.x < n_live;
+        Scatter sct;
+        sct.has_next = sct.has_shadow = false;
+        uint32_t xy = 0;
+        if (active) {
+            uint32_t ray_slot;
+            const ShadePoint pt = load_point(points, slot0 + threadIdx.x, ray_slot);
+            const LightPick pick = (NEE && sc.light_cwnodes_count != 0) ? load_pick(points, slot0 + threadIdx.x) : no_light_pick();
+            Ray ray;
+            {
+                const float4 d = rays_in.d_cw[ray_slot], cc = rays_in.c_cs[ray_slot], io = rays_in.ior[ray_slot];
+                const uint2 xd = rays_in.xy_depth[ray_slot];
+                ray.o = pt.P, ray.pdf = 0.0f; // (not read by the scatter stage)
+                ray.d = {d.x, d.y, d.z}, ray.cone_width = d.w;
+                ray.c = {cc.x, cc.y, cc.z}, ray.cone_spread = cc.w;
+                ray.ior[0] = io.x, ray.ior[1] = io.y, ray.ior[2] = io.z, ray.ior[3] = io.w;
+                ray.xy = xd.x, ray.depth = xd.y;
+            }
+            xy = ray.xy;
+            const uint32_t layer = xy_layer(xy, layers);
+            const ShadeParams spl = layer_params(sp, layer);
+            ray.xy = xy_real(xy, layers, layer);
+            scatter_stage<NEE, CONTINUE>(sc, spl, ray, pt, pick, sct);
+            sct.next.xy = xy, sct.shadow.xy = xy;
+            if (NEE) {
+                const f3 col = direct_radiance(spl, sct, ray.c);
+                if (col.x != 0.0f || col.y != 0.0f || col.z != 0.0f) { // (x + 0 == x: the add is skipped when nothing is booked)
+                    ShadeResult res;
+                    res.col = mk4(col, 1.0f);
+                    add_secondary_pixel(res, xy, img_w, px.temp);
+                }
+            }
+        }
+        if (NEE) {
+            const uint32_t sh_slot = out_shadow.alloc(stripe, sct.has_shadow);
+            if (sct.has_shadow) {
+                store_shadow(shadow_out, sh_slot, sct.shadow);
+            }
+        }
+        if (CONTINUE) {
+            const uint32_t ray_slot = out_rays.alloc(stripe, sct.has_next);
+            if (sct.has_next) {
+                store_ray(rays_out, ray_slot, sct.next);
+            }
+        }
+    }
+}
+
+// MIS-weighted radiance of importance-sampled emitters that secondary rays hit (shade_point.h: emissive_hit_mis_weight): a
+// light-tree walk + a spherical-triangle density per hit -- rare, but every wavefront containing one used to pay for it.
+// Runs after k_surface of the same bounce on the ray / hit buffers that kernel read; such a path ends there (k_surface booked
+// zero radiance for it), so this is the only contribution of its pixel in this bounce and the per-pixel addition order of
+// the reference is kept.  (First bounce: only camera rays that crossed a transparent surface can get here.)
+__global__ void __launch_bounds__(WAVE) k_shade_emissive(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
+                                                        const DeferredSoA deferred, const RayQueue queue, const PixelBuffers px,
+                                                        const int img_w) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_live_chunks = queue.live_chunks();
+    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+        uint32_t stripe, slot0, n_live;
+        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
+            continue;
+        }
+        const float4 a = deferred.a[slot0 + lane], b = deferred.b[slot0 + lane];
+        const uint32_t i = float_as_uint(a.x), tri = float_as_uint(a.y), material = float_as_uint(a.z);
+        const float4 o = rays_in.o_pdf[i], d = rays_in.d_cw[i], throughput = rays_in.c_cs[i];
+        const uint32_t xy = rays_in.xy_depth[i].x;
+        const Hit hit = load_hit(hits, i);
+        const f3 origin = {o.x, o.y, o.z}, dir = {d.x, d.y, d.z};
+        const float mis = emissive_hit_mis_weight(sc, origin, dir, origin + hit.t * dir, hit.t, o.w, tri, &sc.mesh_instances[hit.obj_index]);
+        ShadeResult res;
+        res.col = emissive_hit_radiance(sp, a.w, mis, sc.materials[material].tangent_rotation_or_strength, f3{b.x, b.y, b.z},
+                                        f3{throughput.x, throughput.y, throughput.z});
+        add_secondary_pixel(res, xy, img_w, px.temp);
+    }
+}
+
+// ---- launcher ---------------------------------------------------------------------------------------------------------------
+void launch(const ShadeLaunch &a) {
+    hipStream_t s = a.stream;
+    const int g = a.grid;
+    const bool pick_apart = (a.split & 1) != 0 && a.sc.light_cwnodes_count != 0;
+    // stage 1: what was hit
+    if (a.bounce == 0) {
+        if (pick_apart) {
+            k_surface<true, false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers);
+        } else {
+            k_surface<true, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers);
+        }
+    } else {
+        if (pick_apart) {
+            k_surface<false, false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers);
+        } else {
+            k_surface<false, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers);
+        }
+    }
+    // emitter hits whose MIS weight was deferred; an empty queue costs a few microseconds
+    k_shade_emissive<<<std::min(g, 2048), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.deferred, a.out_deferred, a.px, a.vw);
+    // stage 2: which light
+    if (pick_apart) {
+        k_light_pick<<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.layers);
+    }
+    // stage 3: shadow ray + continuation
+    if ((a.split & 2) != 0) {
+        k_scatter<true, false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers);
+        k_scatter<false, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers);
+    } else {
+        k_scatter<true, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers);
+    }
+}
+
+} // namespace shade
+} // namespace rt

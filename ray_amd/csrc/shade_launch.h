@@ -1,0 +1,44 @@
+// shade_launch.h -- the interface between the host launcher (rayhip.hip) and the shade-stage translation unit
+// (shade_kernels.hip).
+#pragma once
+
+#include "rt_shade.h"
+#include "wavefront.hip.h"
+
+namespace rt {
+
+// ShadePoint in memory: SoA float4 planes, one store / load instruction per plane and wavefront (1 KiB each)
+struct PointSoA {
+    float4 *p_slot;  // P.xyz | slot of the ray that produced the point
+    float4 *n_gx;    // N.xyz | plane_N.x
+    float4 *b_gy;    // B.xyz | plane_N.y
+    float4 *base_gz; // base.rgb | plane_N.z
+    float4 *scalars; // roughness, metallic, specular, mix_weight
+    float4 *misc;    // mix_pick, material | backfacing << 31, cone_width, -
+    float4 *light;   // written by k_light_pick: light index, 1 / pick probability, rest of the random number, -
+};
+
+// one bounce of K5: shade the rays of queue `in` (ray buffer rays_in + hits) -> shade points (pts) -> secondary rays into
+// out_rays of rays_out, shadow rays into out_shadow, radiance into the per-iteration pixel buffer
+struct ShadeLaunch {
+    SceneView sc;
+    ShadeParams sp;
+    RaySoA rays_in, rays_out;
+    HitSoA hits;
+    ShadowSoA shadow;
+    DeferredSoA deferred;
+    PointSoA points;
+    RayQueue in, pts, out_rays, out_shadow, out_deferred;
+    PixelBuffers px;
+    Layering layers;
+    int vw;           // row pitch of the per-iteration pixel buffers (virtual frame width)
+    float mix_factor; // 1 / iteration: blend of the first-hit feature images (single-layer passes)
+    int bounce, grid;
+    int split;        // bit 0: the light pick as its own kernel; bit 1: next-event estimation and continuation as two launches
+    hipStream_t stream;
+};
+namespace shade {
+void launch(const ShadeLaunch &a);
+}
+
+} // namespace rt

@@ -310,7 +310,16 @@ RT_HD float light_child_importance(const LightChild &c, const f3 P) {
     return importance;
 }
 // the eight importances of a node, and their sum in the oracle's SSE association order
-RT_HD void light_node_importances(const SceneView &sc, const uint32_t node, const f3 P, float imp[8]) {
+RT_HD void light_node_importances(const SceneView &sc, uint32_t node, const f3 P, float imp[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Near the root every lane of a wavefront sits at the same node.  When that is the case the node index is made
+    // wave-uniform for the compiler (readfirstlane), which turns the 26 per-lane 16-byte gathers of the node's table rows into
+    // scalar loads through the constant cache: same values, a fraction of the memory-pipeline work.
+    const uint32_t first = uint32_t(__builtin_amdgcn_readfirstlane(int(node)));
+    if (__builtin_amdgcn_ballot_w64(node != first) == 0ull) {
+        node = first;
+    }
+#endif
     const float4 *t = sc.light_children + size_t(node) * LIGHT_CHILDREN_STRIDE;
     const float4 f0 = t[0], f1 = t[1];
     const float flux[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
@@ -576,7 +585,8 @@ RT_HD void sample_directional_light(const rayhip_light &l, const f3 P, const f2 
     }
 }
 
-RT_HD void sample_rect_light(const SceneView &sc, const rayhip_light &l, const f3 P, const f2 u, const f2 tex_jitter, LightSample &s) {
+template <class Jitter>
+RT_HD void sample_rect_light(const SceneView &sc, const rayhip_light &l, const f3 P, const f2 u, Jitter &&tex_jitter, LightSample &s) {
     const f3 centre = mk3(&l.params[0]);
     const f3 side_u = mk3(&l.params[4]), side_v = mk3(&l.params[8]);
     const f3 facing = normalize(cross(side_u, side_v));
@@ -595,13 +605,14 @@ RT_HD void sample_rect_light(const SceneView &sc, const rayhip_light &l, const f
         s.pdf = (sa_pdf > 0.0f) ? sa_pdf : (dist * dist) / (rect_area * cos_theta);
         s.area = light_visible(l) ? rect_area : 0.0f;
         if (light_sky_portal(l)) {
-            s.radiance *= env_radiance_towards(sc, s.dir, tex_jitter);
+            s.radiance *= env_radiance_towards(sc, s.dir, tex_jitter());
             s.is_env = true;
         }
     }
 }
 
-RT_HD void sample_disk_light(const SceneView &sc, const rayhip_light &l, const f3 P, const f2 u, const f2 tex_jitter, LightSample &s) {
+template <class Jitter>
+RT_HD void sample_disk_light(const SceneView &sc, const rayhip_light &l, const f3 P, const f2 u, Jitter &&tex_jitter, LightSample &s) {
     const f3 centre = mk3(&l.params[0]);
     const f3 side_u = mk3(&l.params[4]), side_v = mk3(&l.params[8]);
     f2 disk = {2.0f * u.x - 1.0f, 2.0f * u.y - 1.0f};
@@ -627,7 +638,7 @@ RT_HD void sample_disk_light(const SceneView &sc, const rayhip_light &l, const f
         s.area = 0.0f;
     }
     if (light_sky_portal(l)) {
-        s.radiance *= env_radiance_towards(sc, s.dir, tex_jitter);
+        s.radiance *= env_radiance_towards(sc, s.dir, tex_jitter());
         s.is_env = true;
     }
 }
@@ -657,8 +668,9 @@ RT_HD void sample_line_light(const rayhip_light &l, const f3 P, const f2 u, Ligh
     }
 }
 
+template <class Jitter>
 RT_HD void sample_triangle_light(const SceneView &sc, const rayhip_light &l, const uint32_t light_index, const f3 P, const f2 u,
-                                 const f2 tex_jitter, LightSample &s) {
+                                 Jitter &&tex_jitter, LightSample &s) {
     const uint32_t texture = float_as_uint(l.params[2]);
     const float4 *geom = sc.light_tri_geom + size_t(light_index) * 4;
     const float4 g0 = geom[0], g1 = geom[1], g2 = geom[2], g3 = geom[3];
@@ -698,13 +710,14 @@ RT_HD void sample_triangle_light(const SceneView &sc, const rayhip_light &l, con
     if (cos_theta > 0.0f) {
         s.pdf = pdf;
         if (texture != 0xffffffff) {
-            s.radiance *= xyz(sample_color(sc, texture, uv, 0, tex_jitter));
+            s.radiance *= xyz(sample_color(sc, texture, uv, 0, tex_jitter()));
         }
     }
 }
 
+template <class Jitter>
 RT_HD void sample_env_light(const SceneView &sc, const rayhip_light &l, const f3 P, const f3 T, const f3 B, const f3 N, const float u_tree,
-                            const f2 u, const f2 tex_jitter, LightSample &s) {
+                            const f2 u, Jitter &&tex_jitter, LightSample &s) {
     float pdf;
     if (sc.env.qtree_levels) {
         const f4 d = env_quadtree_draw(sc, sc.env.env_map_rotation, u_tree, u.x, u.y);
@@ -718,7 +731,7 @@ RT_HD void sample_env_light(const SceneView &sc, const rayhip_light &l, const f3
     }
     s.radiance *= mk3(sc.env.env_col);
     if (sc.env.env_map != 0xffffffff) {
-        s.radiance *= latlong_rgbe(sc, sc.env.env_map, s.dir, sc.env.env_map_rotation, tex_jitter);
+        s.radiance *= latlong_rgbe(sc, sc.env.env_map, s.dir, sc.env.env_map_rotation, tex_jitter());
     }
     s.area = 1.0f;
     s.point = P + s.dir;
@@ -728,8 +741,11 @@ RT_HD void sample_env_light(const SceneView &sc, const rayhip_light &l, const f3
     s.ray_mask = light_ray_visibility(l);
 }
 
+// `tex_jitter()`: the texture-lookup random pair of this path vertex, asked for only by emitters that look something up
+// (textured triangles, sky portals, the environment)
+template <class Jitter>
 RT_HD LightSample sample_light(const SceneView &sc, const LightPick &pick, const f3 P, const f3 T, const f3 B, const f3 N, const f2 u,
-                               const f2 tex_jitter) {
+                               Jitter &&tex_jitter) {
     LightSample s = no_light_sample();
     if (pick.inv_prob == 0.0f) {
         return s;

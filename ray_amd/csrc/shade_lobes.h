@@ -243,20 +243,29 @@ RT_HD PrincipledLobes principled_lobes(const ScatterFrame &fr, const ShadePoint 
     L.gloss.f0 = reflectance_at_normal(L.gloss.ior);
     L.gloss.alpha = ggx_alpha(pt.roughness, float(m.anisotropic_unorm) / unorm, fr.floor_alpha);
 
-    L.coat_ior = ior_from_specular(clearcoat);
-    L.coat_f0 = reflectance_at_normal(L.coat_ior);
-    const f2 coat_alpha2 = ggx_alpha(clearcoat_roughness, 0.0f, fr.floor_alpha);
-    L.coat_alpha = coat_alpha2.x;
-    L.coat_singular = alpha_is_singular(coat_alpha2);
-
-    const float transmit_roughness = 1.0f - (1.0f - pt.roughness) * (1.0f - float(m.transmission_roughness_unorm) / unorm);
+    // the clearcoat and transmission lobes exist only when the material switches them on; their parameters are never read
+    // otherwise (probability 0), so they are not computed (each costs a square root, divisions and a Fresnel term)
+    L.coat_alpha = L.coat_ior = L.coat_f0 = 0.0f;
+    L.coat_singular = true;
+    if (clearcoat != 0.0f) {
+        L.coat_ior = ior_from_specular(clearcoat);
+        L.coat_f0 = reflectance_at_normal(L.coat_ior);
+        const f2 coat_alpha2 = ggx_alpha(clearcoat_roughness, 0.0f, fr.floor_alpha);
+        L.coat_alpha = coat_alpha2.x;
+        L.coat_singular = alpha_is_singular(coat_alpha2);
+    }
     L.inside_ior = m.ior;
-    L.eta = pt.backfacing ? (m.ior / outside_ior) : (outside_ior / m.ior);
-    L.fresnel = fresnel_dielectric(dot(fr.I, fr.N), 1.0f / L.eta);
-    L.transmit_alpha = ggx_alpha(transmit_roughness, 0.0f, fr.floor_alpha);
-    L.clear_gloss.alpha = ggx_alpha(pt.roughness, 0.0f, fr.floor_alpha);
+    L.eta = 1.0f, L.fresnel = 0.0f;
+    L.transmit_alpha = L.clear_gloss.alpha = f2{0.0f, 0.0f};
     L.clear_gloss.ior = 1.0f, L.clear_gloss.f0 = 0.0f;
     L.clear_gloss.tint0 = L.clear_gloss.tint90 = splat3(1.0f);
+    if (transmission != 0.0f) {
+        const float transmit_roughness = 1.0f - (1.0f - pt.roughness) * (1.0f - float(m.transmission_roughness_unorm) / unorm);
+        L.eta = pt.backfacing ? (m.ior / outside_ior) : (outside_ior / m.ior);
+        L.fresnel = fresnel_dielectric(dot(fr.I, fr.N), 1.0f / L.eta);
+        L.transmit_alpha = ggx_alpha(transmit_roughness, 0.0f, fr.floor_alpha);
+        L.clear_gloss.alpha = ggx_alpha(pt.roughness, 0.0f, fr.floor_alpha);
+    }
 
     // luminance the reflection lobe shows at this view angle (shading normal standing in for the half vector)
     const float grazing = fresnel_blend(dot(fr.I, fr.N), L.gloss.ior, L.gloss.f0);
@@ -403,7 +412,7 @@ RT_HD void scatter_stage(const SceneView &sc, const ShadeParams &sp, const Ray &
     // the light sample (stage 2 picked the light)
     LightSample ls = no_light_sample();
     if (NEE && sc.light_cwnodes_count != 0) {
-        ls = sample_light(sc, pick, pt.P, fr.T, fr.B, fr.N, rnd.get(RAND_DIM_LIGHT), rnd.get(RAND_DIM_TEX));
+        ls = sample_light(sc, pick, pt.P, fr.T, fr.B, fr.N, rnd.get(RAND_DIM_LIGHT), [&]() { return rnd.get(RAND_DIM_TEX); });
     }
     const bool light_usable = NEE && ls.pdf > 0.0f;
 

@@ -11,7 +11,7 @@
 //   3 scatter   (shade_lobes.h) sample the picked light and evaluate the material towards it (shadow ray), draw the
 //               continuation direction from the material (secondary ray), Russian roulette.
 //
-// A ShadePoint is 104 bytes in six SoA planes -- what stage 3 cannot recompute from the ray it re-reads: position, two
+// A ShadePoint is 112 bytes in seven SoA planes -- what stage 3 cannot recompute from the ray it re-reads: position, two
 // frame vectors + the geometric normal (the tangent is N x B), base colour, three scalars, the mix bookkeeping, the
 // material index.
 //
@@ -73,14 +73,27 @@ struct SurfaceOut {
     float emitter_mix_weight;
 };
 
-// `tri_verts` table: the three vertices of every triangle, gathered through vtx_indices[] once per scene and laid out as
-// 3 x 3 float4 -- (p, n.x) (n.yz, b.xy) (b.z, t, -) per vertex: ONE round trip of nine 16-byte loads per shade point instead
-// of three index loads followed by 33 dword loads of 44-byte vertices.  144 B per triangle; pure data movement.
-constexpr int TRI_VERTS_STRIDE = 9;
+// `tri_verts` table: what the surface stage needs of a triangle, gathered through vtx_indices[] once per scene.  One row
+// of 8 float4 = 128 bytes = exactly two 64-byte lines per triangle, fetched in ONE round trip (the reference follows three
+// indices to three 44-byte vertices: 3 + 33 dword loads, two dependent trips):
+//   [2k]   vertex k: position, normal.x        [2k+1]  vertex k: normal.yz, uv
+//   [6]    object-space geometric normal (unit) and the length of the edge cross product (twice the area)
+//   [7]    twice the area of the triangle in uv space, -, -, -
+// Rows 6-7 are values every shade point of the triangle would compute from the corners with the same operations (same
+// IEEE results on host and device); the vertex bitangents, which only normal-mapped materials read, live in their own
+// table (`tri_bitangents`, 4 float4 per triangle: b0, b1, b2, -).  Pure data movement otherwise.
+constexpr int TRI_VERTS_STRIDE = 8, TRI_BITANGENTS_STRIDE = 4;
+struct Corner {
+    f3 p, n;
+    f2 uv;
+};
 RT_HD void fill_tri_verts(const rayhip_vertex *vertices, const uint32_t vertices_count, const uint32_t *vtx_indices, const uint32_t tri,
-                          float4 *out /* [9] */) {
-    for (int k = 0; k < 9; ++k) {
+                          float4 *out /* [TRI_VERTS_STRIDE] */, float4 *out_bitangents /* [TRI_BITANGENTS_STRIDE] */) {
+    for (int k = 0; k < TRI_VERTS_STRIDE; ++k) {
         out[k] = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    for (int k = 0; k < TRI_BITANGENTS_STRIDE; ++k) {
+        out_bitangents[k] = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     // (vtx_indices is a sparse pool: slots no mesh owns hold anything -- those rows stay zero, nothing reads them)
     for (int k = 0; k < 3; ++k) {
@@ -88,20 +101,21 @@ RT_HD void fill_tri_verts(const rayhip_vertex *vertices, const uint32_t vertices
             return;
         }
     }
+    const rayhip_vertex *v[3] = {&vertices[vtx_indices[tri * 3 + 0]], &vertices[vtx_indices[tri * 3 + 1]], &vertices[vtx_indices[tri * 3 + 2]]};
     for (int k = 0; k < 3; ++k) {
-        const rayhip_vertex &v = vertices[vtx_indices[tri * 3 + k]];
-        out[3 * k + 0] = mkfloat4(v.p[0], v.p[1], v.p[2], v.n[0]);
-        out[3 * k + 1] = mkfloat4(v.n[1], v.n[2], v.b[0], v.b[1]);
-        out[3 * k + 2] = mkfloat4(v.b[2], v.t[0], v.t[1], 0.0f);
+        out[2 * k + 0] = mkfloat4(v[k]->p[0], v[k]->p[1], v[k]->p[2], v[k]->n[0]);
+        out[2 * k + 1] = mkfloat4(v[k]->n[1], v[k]->n[2], v[k]->t[0], v[k]->t[1]);
+        out_bitangents[k] = mkfloat4(v[k]->b[0], v[k]->b[1], v[k]->b[2], 0.0f);
     }
+    float twice_area;
+    const f3 ng = normalize_len(cross(mk3(v[1]->p) - mk3(v[0]->p), mk3(v[2]->p) - mk3(v[0]->p)), twice_area);
+    out[6] = mkfloat4(ng.x, ng.y, ng.z, twice_area);
+    const float uv_area = fabsf((v[1]->t[0] - v[0]->t[0]) * (v[2]->t[1] - v[0]->t[1]) - (v[2]->t[0] - v[0]->t[0]) * (v[1]->t[1] - v[0]->t[1]));
+    out[7] = mkfloat4(uv_area, 0.0f, 0.0f, 0.0f);
 }
-struct Corner {
-    f3 p, n, b;
-    f2 uv;
-};
 RT_HD Corner load_corner(const float4 *t) {
-    const float4 a = t[0], b = t[1], c = t[2];
-    return Corner{f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f3{b.z, b.w, c.x}, f2{c.y, c.z}};
+    const float4 a = t[0], b = t[1];
+    return Corner{f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, f2{b.z, b.w}};
 }
 
 // hue-preserving clamp on the rgb sum (ShadeRef.cpp:1646-1649)
@@ -115,14 +129,15 @@ RT_HD f3 clamp_radiance_sum(f3 c, const float limit) {
 
 // ---- terminal: the ray left the scene (ShadeRef.cpp:1030-1066) ----------------------------------------------------------------
 // `inv_pick_prob` < 0: no MIS against next-event estimation (the path could not have continued)
-RT_HD f4 environment_radiance(const SceneView &sc, const Ray &ray, const float inv_pick_prob, const f2 jitter) {
+template <class Jitter>
+RT_HD f4 environment_radiance(const SceneView &sc, const Ray &ray, const float inv_pick_prob, Jitter &&jitter) {
     const rayhip_environment &env = sc.env;
     const bool indirect = is_indirect(ray.depth);
     const uint32_t map = indirect ? env.env_map : env.back_map;
     const float rotation = indirect ? env.env_map_rotation : env.back_map_rotation;
     f4 c = {1.0f, 1.0f, 1.0f, 1.0f};
     if (map != 0xffffffff) {
-        c = mk4(latlong_rgbe(sc, map, ray.d, rotation, jitter), 1.0f);
+        c = mk4(latlong_rgbe(sc, map, ray.d, rotation, jitter()), 1.0f);
     }
     if (env.light_index != 0xffffffff && inv_pick_prob >= 0.0f && indirect) {
         const float light_pdf = env.qtree_levels ? safe_div_pos(env_quadtree_pdf(sc, rotation, ray.d), inv_pick_prob)
@@ -137,12 +152,13 @@ RT_HD f4 environment_radiance(const SceneView &sc, const Ray &ray, const float i
 // ---- terminal: the ray hit a visible analytic emitter (ShadeRef.cpp:1068-1172) ------------------------------------------------------
 // hit.u carries the pick probability of that emitter as seen from the ray origin (rt_arealights.h); the emission is weighted
 // against the density next-event estimation has for the same direction
-RT_HD f3 emitter_radiance(const SceneView &sc, const Ray &ray, const Hit &hit, const f2 jitter) {
+template <class Jitter>
+RT_HD f3 emitter_radiance(const SceneView &sc, const Ray &ray, const Hit &hit, Jitter &&jitter) {
     const rayhip_light &l = sc.lights[-hit.obj_index - 1];
     const float inv_pick_prob = (1.0f / hit.u);
     f3 c = mk3(l.col);
     if (light_sky_portal(l)) {
-        c *= env_radiance_towards(sc, ray.d, jitter);
+        c *= env_radiance_towards(sc, ray.d, jitter());
     }
     float nee_pdf = 0.0f;
     bool weighted = true;
@@ -239,7 +255,19 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     out.deferred_emitter = false;
 
     const PathRandom rnd = path_random(sc, sp, ray.xy, ray.depth);
-    const f2 tex_jitter = rnd.get(RAND_DIM_TEX);
+    // the texture-lookup random pair of this path vertex: computed where a lookup happens (an integer hash chain + two
+    // table reads that untextured surfaces never need); every use gets the same pair
+    struct {
+        const PathRandom &rnd;
+        bool have;
+        f2 v;
+        RT_HD f2 operator()() {
+            if (!have) {
+                v = rnd.get(RAND_DIM_TEX), have = true;
+            }
+            return v;
+        }
+    } tex_jitter = {rnd, false, f2{0.0f, 0.0f}};
 
     if (hit.v < 0.0f) { // nothing hit
         const float inv_pick_prob = (get_total_depth(ray.depth) < sp.ps.max_total_depth) ? safe_div_pos(1.0f, hit.u) : -1.0f;
@@ -267,15 +295,15 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     const rayhip_tri_mat_data sides = sc.tri_materials[tri];
     const rayhip_mesh_instance *inst = &sc.mesh_instances[hit.obj_index];
     const float4 *rows = sc.tri_verts + size_t(tri) * TRI_VERTS_STRIDE;
-    const Corner c1 = load_corner(rows), c2 = load_corner(rows + 3), c3 = load_corner(rows + 6);
+    const Corner c1 = load_corner(rows), c2 = load_corner(rows + 2), c3 = load_corner(rows + 4);
+    const float4 plane = rows[6];
+    const float uv_area = rows[7].x;
 
     const float w1 = 1.0f - hit.u - hit.v;
-    f3 N = normalize(c1.n * w1 + c2.n * hit.u + c3.n * hit.v);
+    const f3 N_obj = normalize(c1.n * w1 + c2.n * hit.u + c3.n * hit.v);
     const f2 uv = c1.uv * w1 + c2.uv * hit.u + c3.uv * hit.v;
-    float twice_area_obj;
-    f3 Ng = normalize_len(cross(c2.p - c1.p, c3.p - c1.p), twice_area_obj);
-    f3 Bt = c1.b * w1 + c2.b * hit.u + c3.b * hit.v;
-    f3 Tg = cross(Bt, N);
+    const float twice_area_obj = plane.w;
+    f3 Ng = {plane.x, plane.y, plane.z}, N = N_obj;
 
     const rayhip_material *mat = &sc.materials[sides.front_mi & MATERIAL_INDEX_BITS];
     if (pt.backfacing) {
@@ -283,15 +311,12 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
             return false; // single-sided: nothing there from this side (radiance and coverage stay zero)
         }
         mat = &sc.materials[sides.back_mi & MATERIAL_INDEX_BITS];
-        Ng = -Ng, N = -N, Bt = -Bt, Tg = -Tg;
+        Ng = -Ng, N = -N;
     }
     Ng = safe_normalize(transform_normal(Ng, inst->inv_xform));
     N = safe_normalize(transform_normal(N, inst->inv_xform));
-    Bt = safe_normalize(transform_normal(Bt, inst->inv_xform));
-    Tg = safe_normalize(transform_normal(Tg, inst->inv_xform));
 
     // texture level of detail from the ray-cone footprint: uv area over surface area, times the cone width
-    const float uv_area = fabsf((c2.uv.x - c1.uv.x) * (c3.uv.y - c1.uv.y) - (c3.uv.x - c1.uv.x) * (c2.uv.y - c1.uv.y));
     pt.cone_width = ray.cone_width + ray.cone_spread * hit.t;
     float lod_lambda = 0.5f * fast_log2(uv_area / twice_area_obj);
     lod_lambda += fast_log2(pt.cone_width);
@@ -305,7 +330,7 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     while (mat->type == NODE_MIX) {
         float k = mat->tangent_rotation_or_strength;
         if (mat->textures[BASE_TEXTURE] != 0xffffffff) {
-            k *= sample_color(sc, mat->textures[BASE_TEXTURE], uv, 0, tex_jitter).x;
+            k *= sample_color(sc, mat->textures[BASE_TEXTURE], uv, 0, tex_jitter()).x;
         }
         const float eta = pt.backfacing ? safe_div_pos(outside_ior, mat->ior) : safe_div_pos(mat->ior, outside_ior);
         const float fresnel = mat->ior != 0.0f ? fresnel_dielectric(dot(view, N), eta) : 1.0f;
@@ -326,13 +351,24 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
 
     // ---- normal map, bent back above the horizon of the view direction ----
     if (mat->textures[NORMALS_TEXTURE] != 0xffffffff) {
-        f4 nm = sample_bilinear(sc, mat->textures[NORMALS_TEXTURE], uv, 0, tex_jitter);
+        f4 nm = sample_bilinear(sc, mat->textures[NORMALS_TEXTURE], uv, 0, tex_jitter());
         nm = nm * 2.0f;
         nm = {nm.x - 1.0f, nm.y - 1.0f, nm.z - 1.0f, nm.w - 1.0f};
         nm.z = 1.0f;
         if (mat->textures[NORMALS_TEXTURE] & TEX_RECONSTRUCT_Z_BIT) {
             nm.z = safe_sqrt(1.0f - nm.x * nm.x - nm.y * nm.y);
         }
+        // the vertex tangent frame is only needed here: interpolated bitangent, tangent = B x N in object space, both
+        // oriented and taken to world space like the normals
+        const float4 *brow = sc.tri_bitangents + size_t(tri) * TRI_BITANGENTS_STRIDE;
+        const float4 b1 = brow[0], b2 = brow[1], b3 = brow[2];
+        f3 Bt = f3{b1.x, b1.y, b1.z} * w1 + f3{b2.x, b2.y, b2.z} * hit.u + f3{b3.x, b3.y, b3.z} * hit.v;
+        f3 Tg = cross(Bt, N_obj);
+        if (pt.backfacing) {
+            Bt = -Bt, Tg = -Tg;
+        }
+        Bt = safe_normalize(transform_normal(Bt, inst->inv_xform));
+        Tg = safe_normalize(transform_normal(Tg, inst->inv_xform));
         const f3 smooth = N;
         N = normalize(nm.x * Tg + nm.z * N + nm.y * Bt);
         if (mat->normal_map_strength_unorm != 0xffff) {
@@ -358,7 +394,7 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     pt.base = mk3(mat->base_color);
     if (mat->textures[BASE_TEXTURE] != 0xffffffff) {
         const uint32_t tex = mat->textures[BASE_TEXTURE];
-        pt.base *= xyz(sample_color(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter));
+        pt.base *= xyz(sample_color(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter()));
     }
     out.base_color = pt.base;
     out.normal_depth = mk4(N, hit.t);
@@ -366,7 +402,7 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     pt.roughness = float(mat->roughness_unorm) / 65535.0f;
     if (mat->textures[ROUGH_TEXTURE] != 0xffffffff) {
         const uint32_t tex = mat->textures[ROUGH_TEXTURE];
-        const float r = sample_bilinear(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter).x;
+        const float r = sample_bilinear(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter()).x;
         f4 splat = {r, r, r, r};
         if (tex & TEX_SRGB_BIT) {
             splat = srgb_to_linear(splat);
@@ -378,12 +414,12 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
         pt.metallic = float(mat->metallic_unorm) / 65535.0f;
         if (mat->textures[METALLIC_TEXTURE] != 0xffffffff) {
             const uint32_t tex = mat->textures[METALLIC_TEXTURE];
-            pt.metallic *= sample_bilinear(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter).x;
+            pt.metallic *= sample_bilinear(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter()).x;
         }
         pt.specular = float(mat->specular_unorm) / 65535.0f;
         if (mat->textures[SPECULAR_TEXTURE] != 0xffffffff) {
             const uint32_t tex = mat->textures[SPECULAR_TEXTURE];
-            f4 s = sample_bilinear(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter);
+            f4 s = sample_bilinear(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter());
             if (tex & TEX_SRGB_BIT) {
                 s = srgb_to_linear(s);
             }

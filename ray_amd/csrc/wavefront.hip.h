@@ -1,0 +1,111 @@
+// wavefront.hip.h -- what every wavefront kernel of librayhip shares: the wave-level slot allocator, the striped ray
+// queues, the SoA views of deferred emitter hits and of the pixel buffers.  Included by kernels.hip.h (ray generation,
+// traversal, accumulate, ...) and by shade_kernels.hip (the shade stage, which is its own translation unit).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rt_pixel.h"
+#include "rt_rng.h"
+#include "rt_types.h"
+
+namespace rt {
+
+constexpr int WAVE = 64;
+
+// Reserve one output slot per lane with `pred` set: one atomicAdd per wavefront.
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter, const bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) {
+        return 0u;
+    }
+    const uint32_t lane = __lane_id();
+    const uint32_t prefix = uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (int(lane) == leader) {
+        base = atomicAdd(counter, uint32_t(__popcll(mask)));
+    }
+    base = uint32_t(__shfl(int(base), leader));
+    return base + prefix;
+}
+
+// Striped ray queue.  The slots of a wavefront-state buffer are split into `stripes` equal segments, each with its
+// own fill counter on its own 256-byte line.  A 64-ray chunk read from stripe s writes its survivors to stripe s of
+// the output queue, so (a) a stripe can never overflow -- it receives at most what it held, and the ray generator
+// deals pixel chunks round-robin -- and (b) the one-atomic-per-wavefront slot allocation is spread over `stripes`
+// addresses.  Measured on MI355X (tools/atomic_bench.hip): 11.5 ns per atomic on one counter, 0.37 ns on 64; with
+// one counter the 250 k allocations of a 1080p frame were half of the shade kernels' time.  Rays stay densely packed
+// inside each stripe, so wavefronts stay full; stripes == 1 is the plain dense queue (kernel-level test hooks, ray
+// sort).
+constexpr uint32_t QUEUE_COUNTER_STRIDE = 64; // uint32 words between stripe counters
+constexpr uint32_t QUEUE_MAX_STRIPES = 64;
+struct RayQueue {
+    uint32_t *counts; // counts[s * QUEUE_COUNTER_STRIDE] = rays in stripe s
+    uint32_t stripes;
+    uint32_t chunks_per_stripe; // stripe capacity / 64
+
+    __device__ __forceinline__ uint32_t total_chunks() const { return stripes * chunks_per_stripe; }
+    // Chunk indices that can hold rays: chunks are numbered stripe-minor, so nothing lives beyond the fullest stripe's
+    // last chunk.  A consumer that walks [0, live_chunks()) instead of [0, total_chunks()) does not poll the empty tail of
+    // the queue (late bounces fill a few per cent of it; with a 16x oversubscribed grid the polling was 16 % of the shade
+    // kernel's wave time).  Wavefront-collective: call with all 64 lanes active.
+    __device__ __forceinline__ uint32_t live_chunks() const {
+        const uint32_t lane = __lane_id();
+        uint32_t fill = lane < stripes ? counts[lane * QUEUE_COUNTER_STRIDE] : 0u;
+        for (int m = 32; m >= 1; m >>= 1) {
+            fill = max(fill, uint32_t(__shfl_xor(int(fill), m)));
+        }
+        return uint32_t(__builtin_amdgcn_readfirstlane(int(min(total_chunks(), stripes * ((fill + WAVE - 1) / WAVE)))));
+    }
+    // chunk c (wave-uniform) -> its stripe, first slot and number of live lanes; false if the chunk is empty.
+    // Chunks are numbered stripe-minor so that consecutive wavefronts work on different stripes.
+    __device__ __forceinline__ bool chunk(const uint32_t c, uint32_t &stripe, uint32_t &slot0, uint32_t &n_live) const {
+        stripe = c % stripes;
+        const uint32_t j = c / stripes;
+        const uint32_t n = counts[stripe * QUEUE_COUNTER_STRIDE];
+        if (j * WAVE >= n) {
+            return false;
+        }
+        slot0 = (stripe * chunks_per_stripe + j) * WAVE;
+        n_live = n - j * WAVE < uint32_t(WAVE) ? n - j * WAVE : uint32_t(WAVE);
+        return true;
+    }
+    __device__ __forceinline__ uint32_t alloc(const uint32_t stripe, const bool pred) const {
+        return stripe * chunks_per_stripe * WAVE + wave_alloc(counts + stripe * QUEUE_COUNTER_STRIDE, pred);
+    }
+};
+
+// hits of importance-sampled emitters whose MIS weight is evaluated by k_shade_emissive
+struct DeferredSoA {
+    float4 *a; // ray slot, tri_index, material index (bits), mix_weight
+    float4 *b; // base_color.rgb
+};
+
+struct PixelBuffers {
+    float4 *temp; // [layers][h][w]: radiance of the iteration(s) in flight
+    float4 *full, *half, *raw, *final_, *base_color, *depth_normals;
+    uint16_t *required_samples;
+    float4 *aux_base_layers, *aux_dn_layers; // [layers][h][w], batched passes only (rt_pixel.h)
+    float4 *variance; // [h][w]: the variance estimate of the last accumulate (the reference leaves it in its temp buffer,
+                      // RendererCPU.h:641-645; DenoiseImage reads it from there)
+};
+
+// per-layer part of AccumParams for a batched pass
+struct AccumLayer {
+    int iteration;
+    float mix_factor, half_mix_factor;
+    int is_class_a;
+    float variance_threshold;
+};
+#ifndef RT_MAX_BATCH
+#define RT_MAX_BATCH 64
+#endif
+constexpr int MAX_BATCH = RT_MAX_BATCH;
+struct AccumLayers {
+    AccumLayer l[MAX_BATCH];
+};
+
+__device__ __forceinline__ uint32_t layer_rand_seed(const int iteration) { return hash(uint32_t((iteration - 1) / RAND_SAMPLES_COUNT)); }
+
+} // namespace rt

@@ -44,7 +44,7 @@ struct HostScene {
     std::vector<rayhip_light> lights;
     std::vector<uint32_t> li_indices;
     std::vector<rayhip_light_cwbvh_node> light_cwnodes;
-    std::vector<float4> light_children, light_tri_geom, tri_verts;
+    std::vector<float4> light_children, light_tri_geom, tri_verts, tri_bitangents;
     std::vector<float> env_qtree;
     std::vector<Bvh4Node> nodes4;
     std::vector<uint32_t> blas_root4;
@@ -135,8 +135,10 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
         fill_light_children(d->light_cwnodes[n], &s.light_children[size_t(n) * LIGHT_CHILDREN_STRIDE]);
     }
     s.tri_verts.resize(size_t(d->vtx_indices_count / 3) * TRI_VERTS_STRIDE);
+    s.tri_bitangents.resize(size_t(d->vtx_indices_count / 3) * TRI_BITANGENTS_STRIDE);
     for (uint32_t t = 0; t < d->vtx_indices_count / 3; ++t) {
-        fill_tri_verts(d->vertices, d->vertices_count, d->vtx_indices, t, &s.tri_verts[size_t(t) * TRI_VERTS_STRIDE]);
+        fill_tri_verts(d->vertices, d->vertices_count, d->vtx_indices, t, &s.tri_verts[size_t(t) * TRI_VERTS_STRIDE],
+                       &s.tri_bitangents[size_t(t) * TRI_BITANGENTS_STRIDE]);
     }
     s.light_tri_geom.assign(size_t(d->lights_count) * 4, mkfloat4(0.0f, 0.0f, 0.0f, 0.0f));
     for (uint32_t k = 0; k < d->li_indices_count; ++k) { // (sparse pool: only the slots li_indices[] names hold lights)
@@ -188,6 +190,7 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     v.light_children = s.light_children.data();
     v.light_tri_geom = s.light_tri_geom.data();
     v.tri_verts = s.tri_verts.data();
+    v.tri_bitangents = s.tri_bitangents.data();
     v.env_qtree = reinterpret_cast<const float4 *>(s.env_qtree.data());
     for (int lod = 0, off = 0; lod < 16; ++lod) {
         v.env_qtree_offset[lod] = uint32_t(off);

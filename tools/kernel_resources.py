@@ -3,16 +3,18 @@
 Usage: python tools/kernel_resources.py [extra hipcc flags...]   (CPU only: the compiler reports the numbers)"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wno-unused-function",
-       "-Rpass-analysis=kernel-resource-usage", "-c", "rayhip.hip", "-o", "/tmp/_kr.o"] + sys.argv[1:]
-out = subprocess.run(cmd, cwd=os.path.join(ROOT, "ray_amd", "csrc"), capture_output=True, text=True).stderr
+base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wno-unused-function",
+        "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_kr.o"] + sys.argv[1:]
+out = ""
+for src, extra in (("rayhip.hip", []), ("shade_kernels.hip", [])):
+    out += subprocess.run(base + extra + ["-c", src], cwd=os.path.join(ROOT, "ray_amd", "csrc"), capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
     if m:
         cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-        cur = re.sub(r"\(.*", "", cur).replace("void rt::", "").replace("rt::", "")
+        cur = re.sub(r"\(rt::SceneView.*|\(.*", "", cur).replace("void rt::", "").replace("rt::", "")
         rows[cur] = {}
         continue
     m = re.search(r"remark:\s+(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", line)

@@ -33,9 +33,18 @@ def build_one(name, flags):
     os.makedirs(out, exist_ok=True)
     flags = [f for f in flags if not f.startswith("+")]
     base = [f for f in g.HIPCC_FLAGS if not (f.startswith("-ffp-contract") and any(x.startswith("-ffp-contract") for x in flags))]
-    cmd = [g._hipcc(), *base, *flags, "-Rpass-analysis=kernel-resource-usage", "-c", "rayhip.hip", "-o", os.path.join(out, "rayhip.o")]
-    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
-    subprocess.run([g._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(out, "rayhip.o"),
+    objs = {"rayhip": ("rayhip.hip", []),
+            "shade": ("shade_kernels.hip", [])}
+    class R:
+        stderr = ""
+        returncode = 0
+    r = R()
+    for o, (src, extra) in objs.items():
+        cmd = [g._hipcc(), *base, *flags, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.path.join(out, o + ".o")]
+        rr = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+        r.stderr += rr.stderr
+        r.returncode |= rr.returncode
+    subprocess.run([g._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *[os.path.join(out, o + ".o") for o in objs],
                     os.path.join(CSRC, "_build", "sort.o"), "-o", os.path.join(out, "librayhip.so")], cwd=CSRC, check=True)
     res = {}
     cur = None
