@@ -19,30 +19,34 @@ from ray_amd import api, hip, multigpu
 
 def main():
     workload = sys.argv[1] if len(sys.argv) > 1 else "bistro"
-    K = int(sys.argv[2]) if len(sys.argv) > 2 else 480
+    Ks = [int(x) for x in sys.argv[2:]] or [64, 20]
     wl = bench.WORKLOADS[workload]
     W, H = wl["w"], wl["h"]
     blob, _ = bench.get_scene_blob(workload, wl, 0, 1, lambda: None)
-    base = None
-    for world in (1, 2, 4, 8):
-        for limit in ((60, None) if world > 1 else (None,)):  # 60 = the old one-column limit at 1080p
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for K in Ks:
+        base = None
+        print(f"== {workload} {W}x{H}, {K} spp (what `bench.py --steps {K}` asks of every rank)")
+        for world in (1, 2, 4, 8):
             ctx = hip.Context(0)
             ctx.upload_static(api.pmj_table())
             ctx.resize(W, H)
             ctx.upload_scene_blob(blob)
             ctx.set_shard(bench.TILE, world, 0)
-            batch = multigpu.batch_size(W * H // world, min(ctx.max_batch(), limit or 1 << 30), K)
+            batch = multigpu.batch_size(W * H // world, ctx.max_batch(), K)
             ctx.reserve_batch(batch)
-            ctx.render_batch(1, batch)  # warm-up pass of the timed shape
+            ctx.render_batch(1, batch)  # set-up pass of the timed shape, like bench.py
             ctx.sync()
             t0 = time.perf_counter()
             multigpu.render_sharded(ctx, range(batch + 1, batch + 1 + K), 0, world, batch=batch)
+            # this rank's operand of the frame reduce (the collective itself: 33 MB over xGMI, not emulated here)
+            ctx.export_shard_device(hip.BUF_RAW, frame.data_ptr())
             ctx.sync()
             dt = time.perf_counter() - t0
             rate = W * H * K / world / dt / 1e6 * world
             base = base or rate
-            print(f"N={world} iterations/pass {batch:4d}  rank time {dt * 1e3:8.1f} ms  projected {rate:7.1f} Msamples/s  "
-                  f"efficiency {rate / (base * world):5.3f}", flush=True)
+            print(f"N={world} iterations/pass {batch:4d}  rays/pass {W * H // world * batch / 1e6:6.1f} M  rank time {dt * 1e3:8.1f} ms  "
+                  f"projected {rate:7.1f} Msamples/s  efficiency {rate / base:5.3f}", flush=True)
             ctx.close()
 
 
