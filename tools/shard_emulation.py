@@ -46,7 +46,7 @@ def main():
             rate = W * H * K / world / dt / 1e6 * world
             base = base or rate
             print(f"N={world} iterations/pass {batch:4d}  rays/pass {W * H // world * batch / 1e6:6.1f} M  rank time {dt * 1e3:8.1f} ms  "
-                  f"projected {rate:7.1f} Msamples/s  efficiency {rate / base:5.3f}", flush=True)
+                  f"projected {rate:7.1f} Msamples/s  efficiency {rate / (base * world):5.3f}", flush=True)
             ctx.close()
 
 
