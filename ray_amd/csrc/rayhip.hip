@@ -21,6 +21,7 @@
 #include "bvh4_build.h"
 #include "bvh_layout.h"
 #include "scene_blob.h"
+#include "scene_rebuild.h"
 #include "scene_validate.h"
 #include "sort.h"
 
@@ -577,6 +578,36 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         }
     }
     UPLOAD_TRACE("validated")
+    // Leaf refinement (scene_rebuild.h): the scene's trees are kept, every leaf with more than `leaf_max` triangles is replaced
+    // by a subtree of the linear builder.  RAYHIP_REFINE_LEAVES=<leaf_max> (0 = leave the trees as they are; default 2).
+    // RAYHIP_REBUILD_BVH=<leaf_max>: both levels rebuilt from the triangles and instance transforms instead (lbvh.h).
+    rayhip_rebuild::Rebuilt rebuilt;
+    rayhip_scene_desc d_rebuilt = *d;
+    {
+        int refine = 2, rebuild = 0;
+        if (const char *e = getenv("RAYHIP_REFINE_LEAVES")) {
+            refine = std::max(0, std::min(8, atoi(e)));
+        }
+        if (const char *e = getenv("RAYHIP_REBUILD_BVH")) {
+            rebuild = std::max(0, std::min(8, atoi(e)));
+        }
+        if (rebuild > 0 || refine > 0) {
+            rebuilt = rebuild > 0 ? rayhip_rebuild::rebuild_host(*d, uint32_t(rebuild)) : rayhip_rebuild::refine_host(*d, uint32_t(refine));
+            if (!rebuilt.ok) {
+                return fail("acceleration-structure %s failed: %s", rebuild > 0 ? "rebuild" : "refinement", rebuilt.why.c_str());
+            }
+            d_rebuilt.nodes = rebuilt.nodes.data(), d_rebuilt.nodes_count = uint32_t(rebuilt.nodes.size());
+            d_rebuilt.tris = rebuilt.tris.data(), d_rebuilt.tris_count = uint32_t(rebuilt.tris.size());
+            d_rebuilt.tri_indices = rebuilt.tri_indices.data(), d_rebuilt.tri_indices_count = uint32_t(rebuilt.tri_indices.size());
+            d_rebuilt.mesh_instances = rebuilt.mesh_instances.data();
+            d_rebuilt.tlas_root = rebuilt.tlas_root;
+            d = &d_rebuilt;
+            std::string why;
+            if (!rayhip_validate::validate(*d, why)) {
+                return fail("rebuilt scene: %s", why.c_str());
+            }
+        }
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
 #define UP(field)                                                                                                      \
     if (upload(c, c->field, d->field, size_t(d->field##_count) * sizeof(*d->field))) {                                 \

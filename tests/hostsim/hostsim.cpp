@@ -25,6 +25,7 @@
 #include "../../ray_amd/csrc/rt_params.h"
 #include "../../ray_amd/csrc/rt_pixel.h"
 #include "../../ray_amd/csrc/scene_blob.h"
+#include "../../ray_amd/csrc/scene_rebuild.h"
 #include "../../ray_amd/csrc/scene_validate.h"
 
 using namespace rt;
@@ -112,11 +113,44 @@ HS_API int hostsim_clear(hostsim_ctx *c, const float rgba[4]) { // RendererCPU.h
     return 0;
 }
 HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
-    const rayhip_layout::AlignedDesc aligned(*d_in);
-    const rayhip_scene_desc *d = &aligned.d;
-    if (!rayhip_validate::validate(*d, g_err)) {
+    const rayhip_layout::AlignedDesc aligned0(*d_in);
+    if (!rayhip_validate::validate(aligned0.d, g_err)) {
         return 1;
     }
+    // HOSTSIM_LBVH=<leaf_max>: both levels of the acceleration structure rebuilt by the linear builder (lbvh.h, the host loop
+    // over the element functions the device kernels call) instead of the trees the scene came with
+    rayhip_rebuild::Rebuilt rebuilt;
+    rayhip_scene_desc d_rebuilt = aligned0.d;
+    // HOSTSIM_REFINE=<leaf_max>: the scene's own trees with every larger leaf replaced by a subtree of the same builder -- what
+    // rayhip_scene_upload does by default (leaf_max 2).  Off by default here: the plain host build walks the reference's trees
+    // as they are, which also pins the order in which exactly-tied triangles are met
+    {
+        int refine = 0, rebuild = 0;
+        if (const char *e = getenv("HOSTSIM_REFINE")) {
+            refine = atoi(e);
+        }
+        if (const char *e = getenv("HOSTSIM_LBVH")) {
+            rebuild = atoi(e);
+        }
+        if (rebuild > 0 || refine > 0) {
+            rebuilt = rebuild > 0 ? rayhip_rebuild::rebuild_host(aligned0.d, uint32_t(rebuild)) : rayhip_rebuild::refine_host(aligned0.d, uint32_t(refine));
+            if (!rebuilt.ok) {
+                g_err = "scene rebuild failed: " + rebuilt.why;
+                return 1;
+            }
+            d_rebuilt.nodes = rebuilt.nodes.data(), d_rebuilt.nodes_count = uint32_t(rebuilt.nodes.size());
+            d_rebuilt.tris = rebuilt.tris.data(), d_rebuilt.tris_count = uint32_t(rebuilt.tris.size());
+            d_rebuilt.tri_indices = rebuilt.tri_indices.data(), d_rebuilt.tri_indices_count = uint32_t(rebuilt.tri_indices.size());
+            d_rebuilt.mesh_instances = rebuilt.mesh_instances.data();
+            d_rebuilt.tlas_root = rebuilt.tlas_root;
+            if (!rayhip_validate::validate(d_rebuilt, g_err)) {
+                g_err = "rebuilt scene: " + g_err;
+                return 1;
+            }
+        }
+    }
+    const rayhip_layout::AlignedDesc aligned(d_rebuilt);
+    const rayhip_scene_desc *d = &aligned.d;
     HostScene &s = c->hs;
 #define CP(field) s.field.assign(d->field, d->field + d->field##_count)
     CP(nodes);

@@ -96,8 +96,9 @@ def test_shadow_rays_on_reference_rays(gpu_lib, name):
 
 
 @pytest.mark.parametrize("name", SCENES)
-def test_traversal_work_counters_match_host(gpu_lib, hostsim_lib, name):
+def test_traversal_work_counters_match_host(gpu_lib, hostsim_lib, name, monkeypatch):
     """the visit counts that feed the algorithmic-bytes formula are the same on device and in the host build"""
+    monkeypatch.setenv("HOSTSIM_REFINE", "2")  # the trees librayhip walks: leaves refined to <= 2 triangles (scene_rebuild.h)
     g = util.golden_ref(name)
     gpu = util.make_context(gpu_lib, name)
     host = util.make_context(hostsim_lib, name)
