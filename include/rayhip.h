@@ -316,10 +316,23 @@ RAYHIP_API int rayhip_clear(rayhip_ctx *ctx, const float rgba[4]);
 /* flat-array upload after SceneBase::Finalize (what SceneVK does buffer by buffer, SceneGPU.h:62-104) */
 RAYHIP_API int rayhip_scene_upload(rayhip_ctx *ctx, const rayhip_scene_desc *desc);
 
+/* What SceneBase::SetMeshInstanceTransform / AddMeshInstance / RemoveMeshInstance / AddLight / RemoveLight /
+ * SetEnvironment / Finalize change (SceneCPU.cpp:1004-1094; RebuildTLAS SceneCPU.cpp:1103-1162; RebuildLightTree
+ * SceneCPU.cpp:1411-1521), without sending the geometry again: `desc` is the scene as after those calls -- its
+ * mesh_instances, lights, li_indices, light_cwnodes, env, env_qtree, tlas_root (+ nodes: only the top level is read, to
+ * learn which instance slots are alive), visible/blocker light counts and bounds are used, vertices / vtx_indices for
+ * the corners of triangle lights; textures / texels may be null.  The top-level tree is rebuilt on the device from the
+ * instance transforms (ray_amd/csrc/lbvh.hip.h).  Meshes, materials and textures must be the ones of the last
+ * rayhip_scene_upload.  Returns 0; 1 = error; 2 = this change needs rayhip_scene_upload (an instance of a mesh that was
+ * not in use at the last upload, geometry arrays of another size) -- nothing on the device was touched. */
+RAYHIP_API int rayhip_scene_update_instances(rayhip_ctx *ctx, const rayhip_scene_desc *desc);
+
 /* Same upload from a serialised scene (ray_amd/csrc/scene_blob.h; written by the reference-side SceneHIP or by
  * tests/golden/make_fixtures.py): uploads the arrays AND the filter table stored in the blob and returns the
  * camera stored with it.  `blob` must be 16-byte aligned. */
 RAYHIP_API int rayhip_scene_upload_blob(rayhip_ctx *ctx, const void *blob, size_t size, rayhip_camera *out_cam);
+/* rayhip_scene_update_instances from a serialised scene (same return values; the filter table in the blob is ignored) */
+RAYHIP_API int rayhip_scene_update_instances_blob(rayhip_ctx *ctx, const void *blob, size_t size, rayhip_camera *out_cam);
 
 /* 1024-entry inverse filter CDF (RendererCPU.h:1234-1258 UpdateFilterTable; upload RendererVK.cpp:386-424) */
 RAYHIP_API int rayhip_set_filter_table(rayhip_ctx *ctx, const float *table, int count);

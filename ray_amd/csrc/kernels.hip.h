@@ -835,6 +835,24 @@ __global__ void __launch_bounds__(256) k_nlm_filter(const DenoiseParams p, const
     }
 }
 
+// per-triangle vertex table (shade_point.h: fill_tri_verts) from the vertex and index arrays already in HBM: one thread per
+// triangle, the same function the host build runs (IEEE operations: the same bits)
+__global__ void __launch_bounds__(256) k_fill_tri_verts(const rayhip_vertex *__restrict__ vertices, const uint32_t vertices_count,
+                                                       const uint32_t *__restrict__ vtx_indices, const uint32_t n_tris, float4 *__restrict__ tri_verts,
+                                                       float4 *__restrict__ tri_bitangents) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tris) {
+        float4 rows[TRI_VERTS_STRIDE], brows[TRI_BITANGENTS_STRIDE];
+        fill_tri_verts(vertices, vertices_count, vtx_indices, t, rows, brows);
+        for (int k = 0; k < TRI_VERTS_STRIDE; ++k) {
+            tri_verts[size_t(t) * TRI_VERTS_STRIDE + k] = rows[k];
+        }
+        for (int k = 0; k < TRI_BITANGENTS_STRIDE; ++k) {
+            tri_bitangents[size_t(t) * TRI_BITANGENTS_STRIDE + k] = brows[k];
+        }
+    }
+}
+
 __global__ void k_fill_u16(uint16_t *p, const uint16_t v, const size_t n) {
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         p[i] = v;

@@ -168,6 +168,7 @@ RT_HD uint32_t leaf_word(const uint32_t first_entry, const uint32_t count) { ret
 struct Input {
     const Box *prim_box;       // N boxes (bottom level: object space of their mesh; top level: world space)
     const uint32_t *prim_group; // N group ids, < n_groups
+    const Box *group_centroids; // per group: box of its primitives' centroids (the Morton grid); null = computed here
     uint32_t n_prims, n_groups;
     uint32_t leaf_max;          // most primitives per leaf, 1 .. 8
     // top level: a leaf is ONE primitive and its word carries the primitive itself -- 1 << 29 | primitive, the reference's
@@ -197,6 +198,24 @@ inline void write_child(rayhip_bvh2_node &n, const int k, const Box &b, const ui
     }
 }
 
+RT_HD void centroid_of(const Box &b, float c[3]) {
+    for (int a = 0; a < 3; ++a) {
+        c[a] = 0.5f * (b.lo[a] + b.hi[a]);
+    }
+}
+inline std::vector<Box> centroid_boxes(const Input &in) {
+    if (in.group_centroids) {
+        return std::vector<Box>(in.group_centroids, in.group_centroids + in.n_groups);
+    }
+    std::vector<Box> cbox(in.n_groups, empty_box());
+    for (uint32_t p = 0; p < in.n_prims; ++p) {
+        float c[3];
+        centroid_of(in.prim_box[p], c);
+        grow_point(cbox[in.prim_group[p]], c);
+    }
+    return cbox;
+}
+
 // The whole pipeline as plain loops (same element functions the device kernels call).
 inline Output build_host(const Input &in) {
     Output out;
@@ -207,13 +226,10 @@ inline Output build_host(const Input &in) {
         return out;
     }
     // 1-2: centroid boxes per group, keys
-    std::vector<Box> cbox(in.n_groups, empty_box());
+    std::vector<Box> cbox = centroid_boxes(in);
     std::vector<float> cent(size_t(n) * 3);
     for (uint32_t p = 0; p < n; ++p) {
-        for (int a = 0; a < 3; ++a) {
-            cent[size_t(p) * 3 + a] = 0.5f * (in.prim_box[p].lo[a] + in.prim_box[p].hi[a]);
-        }
-        grow_point(cbox[in.prim_group[p]], &cent[size_t(p) * 3]);
+        centroid_of(in.prim_box[p], &cent[size_t(p) * 3]);
         grow(out.bounds, in.prim_box[p]);
     }
     std::vector<uint64_t> keys(n);

@@ -11,8 +11,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/rayhip.h"
@@ -20,6 +22,7 @@
 #include "shade_launch.h"
 #include "bvh4_build.h"
 #include "bvh_layout.h"
+#include "lbvh.hip.h"
 #include "scene_blob.h"
 #include "scene_rebuild.h"
 #include "scene_validate.h"
@@ -108,6 +111,18 @@ struct rayhip_ctx {
     DevBuf tonemap_lut;   // table of view transform `lut_transform` (rayhip_set_tonemap_lut)
     DevBuf shard_stage;   // [4][h][w] float4: this rank's owned pixels of full / base colour / depth-normals / variance, zero elsewhere
                           // (what the multi-GPU frame reduce sums; rayhip_comm_reduce_framebuffers, rayhip_export_shard_device)
+    // what rayhip_scene_update_instances needs of the last full upload: per mesh (key: mesh_instance_t::mesh_index) the roots
+    // of its bottom-level trees as uploaded and the object-space box of the tree; node slots reserved behind the uploaded
+    // nodes for top-level trees built later on the device
+    struct MeshRef {
+        uint32_t node_index, root4;
+        rayhip_lbvh::Box box;
+    };
+    std::unordered_map<uint32_t, MeshRef> mesh_refs;
+    uint32_t nodes_used = 0, nodes_reserved = 0;
+    bool have_wide = false;
+    uint32_t tex_table[8] = {}, textures_count = 0;
+    struct { uint32_t vertices, vtx_indices, tri_materials, materials; } geometry = {};
     bool adaptive_dirty = false; // a pass ran with variance_threshold != 0 since the last Clear / Resize: required_samples may
                                  // lie below the next iteration, so passes are not batched (rayhip_render_batch)
     int lut_transform = 0, lut_dims = 0;
@@ -538,6 +553,89 @@ int rayhip_clear(rayhip_ctx *c, const float rgba[4]) {
     return 0;
 }
 
+// lights, their index list, the light tree (+ its per-node importance table) and the world-space corners of the triangle
+// lights: everything an instance / light change replaces besides the top-level tree
+static int upload_lights(rayhip_ctx *c, const rayhip_scene_desc *d) {
+    if (upload(c, c->lights, d->lights, size_t(d->lights_count) * sizeof(*d->lights)) ||
+        upload(c, c->li_indices, d->li_indices, size_t(d->li_indices_count) * sizeof(uint32_t)) ||
+        upload(c, c->light_cwnodes, d->light_cwnodes, size_t(d->light_cwnodes_count) * sizeof(*d->light_cwnodes))) {
+        return 1;
+    }
+    // node-only half of the light-tree importance, evaluated once per scene (shade_lights.h: decode_light_child)
+    std::vector<float4> lc(size_t(d->light_cwnodes_count) * LIGHT_CHILDREN_STRIDE);
+    for (uint32_t n = 0; n < d->light_cwnodes_count; ++n) {
+        fill_light_children(d->light_cwnodes[n], &lc[size_t(n) * LIGHT_CHILDREN_STRIDE]);
+    }
+    if (upload(c, c->light_children, lc.data(), lc.size() * sizeof(float4))) {
+        return 1;
+    }
+    // world-space corners of the TRI lights (shade_lights.h: fill_light_tri_geom)
+    // (the light array is a sparse pool: only the slots li_indices[] names hold lights)
+    std::vector<float4> tg(size_t(d->lights_count) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    for (uint32_t k = 0; k < d->li_indices_count; ++k) {
+        const uint32_t i = d->li_indices[k];
+        if (i >= d->lights_count) {
+            return fail("li_indices[%u] = %u is outside the light array", k, i);
+        }
+        const rayhip_light &l = d->lights[i];
+        if (light_type(l) == LIGHT_TYPE_TRI) {
+            const uint32_t tri = float_as_uint(l.params[0]), mi = float_as_uint(l.params[1]);
+            if (mi >= d->mesh_instances_count || size_t(tri) * 3 + 2 >= d->vtx_indices_count) {
+                return fail("triangle light %u refers to triangle %u of instance %u: out of range", i, tri, mi);
+            }
+        }
+        fill_light_tri_geom(l, d->mesh_instances, d->vtx_indices, d->vertices, &tg[size_t(i) * 4]);
+    }
+    if (upload(c, c->light_tri_geom, tg.data(), tg.size() * sizeof(float4))) {
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream)); // `lc`, `tg` go out of scope
+    return 0;
+}
+
+
+// the kernels' view of what is on the device (SceneView), after a full upload or an instance update
+static void refresh_scene_view(rayhip_ctx *c, const rayhip_scene_desc *d, const uint32_t tlas_root, const rayhip_lbvh::Box &root_box) {
+    SceneView &v = c->sc;
+    v.nodes = c->nodes.as<rayhip_bvh2_node>(), v.tris = c->tris.as<rayhip_tri_accel>();
+    v.tri_indices = c->tri_indices.as<uint32_t>(), v.tri_materials = c->tri_materials.as<rayhip_tri_mat_data>();
+    v.materials = c->materials.as<rayhip_material>(), v.vertices = c->vertices.as<rayhip_vertex>();
+    v.vtx_indices = c->vtx_indices.as<uint32_t>(), v.mesh_instances = c->mesh_instances.as<rayhip_mesh_instance>();
+    v.lights = c->lights.as<rayhip_light>(), v.li_indices = c->li_indices.as<uint32_t>();
+    v.light_children = c->light_children.as<float4>();
+    v.light_tri_geom = c->light_tri_geom.as<float4>();
+    v.tri_verts = c->tri_verts.as<float4>();
+    v.tri_bitangents = c->tri_bitangents.as<float4>();
+    v.env_qtree = c->env_qtree.as<float4>();
+    for (int lod = 0, off = 0; lod < 16; ++lod) {
+        v.env_qtree_offset[lod] = uint32_t(off);
+        if (lod < d->env.qtree_levels) {
+            off += 1 << (2 * (d->env.qtree_levels - 1 - lod));
+        }
+    }
+    v.nodes4 = c->have_wide ? c->nodes4.as<Bvh4Node>() : nullptr;
+    v.blas_root4 = c->have_wide ? c->blas_root4.as<uint32_t>() : nullptr;
+    v.light_cwnodes = c->light_cwnodes.as<rayhip_light_cwbvh_node>(), v.textures = c->textures.as<rayhip_texture>();
+    v.texels = c->texels.as<uint32_t>();
+    memcpy(v.tex_table, c->tex_table, sizeof(v.tex_table));
+    v.li_indices_count = d->li_indices_count;
+    v.light_cwnodes_count = d->light_cwnodes_count;
+    v.visible_lights_count = d->visible_lights_count;
+    v.blocker_lights_count = d->blocker_lights_count;
+    v.tlas_root = tlas_root;
+    v.env = d->env;
+    memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
+    // ray-sort grid: true bounds of the TLAS root (Scene::GetBounds takes fminf for the max corner, SceneCPU.cpp:1553)
+    for (int i = 0; i < 3; ++i) {
+        const bool have = root_box.lo[i] <= root_box.hi[i];
+        const float mn = have ? root_box.lo[i] : d->bbox_min[i], mx = have ? root_box.hi[i] : d->bbox_max[i];
+        const float ext = mx - mn;
+        c->sort_grid.root_min[i] = mn;
+        c->sort_grid.inv_cell[i] = (ext > 0.0f && ext < 1e30f) ? 256.0f / ext : 0.0f;
+    }
+}
+
+
 #define UPLOAD_TRACE(msg)                                                                                              \
     if (getenv("RAYHIP_TRACE_UPLOAD")) {                                                                               \
         fprintf(stderr, "rayhip_scene_upload: %8.1f ms  %s\n",                                                         \
@@ -592,7 +690,18 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             rebuild = std::max(0, std::min(8, atoi(e)));
         }
         if (rebuild > 0 || refine > 0) {
-            rebuilt = rebuild > 0 ? rayhip_rebuild::rebuild_host(*d, uint32_t(rebuild)) : rayhip_rebuild::refine_host(*d, uint32_t(refine));
+            // the builder itself runs on the device (lbvh.hip.h); RAYHIP_BVH_BUILD_ON_HOST=1 runs the same element functions
+            // as host loops instead (A/B and debugging: the two produce identical arrays)
+            const bool on_host = getenv("RAYHIP_BVH_BUILD_ON_HOST") != nullptr && atoi(getenv("RAYHIP_BVH_BUILD_ON_HOST")) != 0;
+            auto build = [&](const rayhip_lbvh::Input &in, rayhip_lbvh::Output &out, std::string &why) {
+                if (on_host) {
+                    out = rayhip_lbvh::build_host(in);
+                    return true;
+                }
+                return rayhip_lbvh::build_device(c->stream, in, out, why);
+            };
+            rebuilt = rebuild > 0 ? rayhip_rebuild::rebuild_with(*d, uint32_t(rebuild), build) : rayhip_rebuild::refine_with(*d, uint32_t(refine), build);
+            UPLOAD_TRACE(rebuild > 0 ? "both levels rebuilt" : "leaves refined")
             if (!rebuilt.ok) {
                 return fail("acceleration-structure %s failed: %s", rebuild > 0 ? "rebuild" : "refinement", rebuilt.why.c_str());
             }
@@ -624,6 +733,14 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     }
     UPLOAD_TRACE(lay.applied ? "layout applied" : lay.why_not)
     uint32_t tlas_root = d->tlas_root;
+    { // room behind the nodes for top-level trees rebuilt on the device later (rayhip_scene_update_instances)
+        const size_t n_now = lay.applied ? lay.nodes.size() : size_t(d->nodes_count);
+        c->nodes_used = uint32_t(n_now);
+        c->nodes_reserved = uint32_t(std::max<size_t>(4096, 4 * size_t(d->mesh_instances_count)));
+        if (c->nodes.alloc((n_now + c->nodes_reserved) * sizeof(rayhip_bvh2_node))) {
+            return 1;
+        }
+    }
     if (lay.applied) {
         tlas_root = lay.tlas_root;
         if (upload(c, c->nodes, lay.nodes.data(), lay.nodes.size() * sizeof(rayhip_bvh2_node)) ||
@@ -641,6 +758,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     // 4-wide quantised BLAS trees (rt_bvh4.h) over the node order that was just uploaded; RAYHIP_NO_BVH4=1 keeps the
     // kernels on the reference's BVH2 (A/B measurements)
     bool have_wide = false;
+    std::vector<uint32_t> blas_root4;
     {
         const char *e = getenv("RAYHIP_NO_BVH4");
         if (!(e && e[0] == '1')) {
@@ -655,6 +773,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
                 }
                 HIP_TRY(hipStreamSynchronize(c->stream)); // b4 goes out of scope
                 have_wide = true;
+                blas_root4 = b4.blas_root4;
                 // "small": the BLAS working set (nodes + triangle records) fits one XCD's 4 MB L2 with room to spare
                 const size_t n_tris = lay.applied ? lay.tris.size() : size_t(d->tris_count);
                 c->small_scene = getenv("RAYHIP_NO_SMALL") == nullptr &&
@@ -663,107 +782,193 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         }
     }
     UPLOAD_TRACE(have_wide ? "bvh4 built" : "no bvh4")
+    { // the meshes in use, for rayhip_scene_update_instances: roots + object-space boxes of their trees as uploaded
+        const rayhip_bvh2_node *n2 = lay.applied ? lay.nodes.data() : d->nodes;
+        const uint32_t n2_count = lay.applied ? uint32_t(lay.nodes.size()) : d->nodes_count;
+        const rayhip_mesh_instance *mis = lay.applied ? lay.mesh_instances.data() : d->mesh_instances;
+        c->mesh_refs.clear();
+        std::vector<std::pair<uint32_t, uint32_t>> top;
+        if (tlas_root != 0xffffffffu && rayhip_rebuild::collect_leaf_ranges(n2, n2_count, tlas_root, top)) {
+            for (const auto &leaf : top) {
+                if (leaf.first < d->mesh_instances_count && mis[leaf.first].node_index < n2_count) {
+                    c->mesh_refs[mis[leaf.first].mesh_index] = rayhip_ctx::MeshRef{
+                        mis[leaf.first].node_index, have_wide ? blas_root4[leaf.first] : 0u, rayhip_rebuild::node_box(n2[mis[leaf.first].node_index])};
+                }
+            }
+        }
+    }
     UPLOAD_TRACE("bvh uploaded")
     UP(tri_materials)
     UP(materials)
     UP(vertices)
     UP(vtx_indices)
-    UP(lights)
-    UP(li_indices)
-    UP(light_cwnodes)
-    { // node-only half of the light-tree importance, evaluated once per scene (shade_lights.h: decode_light_child)
-        std::vector<float4> lc(size_t(d->light_cwnodes_count) * LIGHT_CHILDREN_STRIDE);
-        for (uint32_t n = 0; n < d->light_cwnodes_count; ++n) {
-            fill_light_children(d->light_cwnodes[n], &lc[size_t(n) * LIGHT_CHILDREN_STRIDE]);
-        }
-        if (upload(c, c->light_children, lc.data(), lc.size() * sizeof(float4))) {
+    { // vertices gathered per triangle (shade_point.h: fill_tri_verts), on the device from the arrays just uploaded
+        const uint32_t n_tris = d->vtx_indices_count / 3;
+        if (c->tri_verts.alloc(size_t(n_tris) * TRI_VERTS_STRIDE * sizeof(float4)) ||
+            c->tri_bitangents.alloc(size_t(n_tris) * TRI_BITANGENTS_STRIDE * sizeof(float4))) {
             return 1;
         }
-        UPLOAD_TRACE("light_children done")
-        { // vertices gathered per triangle (shade_point.h: fill_tri_verts)
-            const uint32_t n_tris = d->vtx_indices_count / 3;
-            std::vector<float4> tv(size_t(n_tris) * TRI_VERTS_STRIDE), tb(size_t(n_tris) * TRI_BITANGENTS_STRIDE);
-            for (uint32_t t = 0; t < n_tris; ++t) {
-                fill_tri_verts(d->vertices, d->vertices_count, d->vtx_indices, t, &tv[size_t(t) * TRI_VERTS_STRIDE], &tb[size_t(t) * TRI_BITANGENTS_STRIDE]);
-            }
-            if (upload(c, c->tri_verts, tv.data(), tv.size() * sizeof(float4)) || upload(c, c->tri_bitangents, tb.data(), tb.size() * sizeof(float4))) {
-                return 1;
-            }
-            HIP_TRY(hipStreamSynchronize(c->stream)); // `tv`, `tb` go out of scope
+        if (n_tris) {
+            k_fill_tri_verts<<<(n_tris + 255) / 256, 256, 0, c->stream>>>(c->vertices.as<rayhip_vertex>(), d->vertices_count,
+                                                                          c->vtx_indices.as<uint32_t>(), n_tris, c->tri_verts.as<float4>(),
+                                                                          c->tri_bitangents.as<float4>());
+            HIP_TRY(hipGetLastError());
         }
-        UPLOAD_TRACE("tri_verts done")
-        // world-space corners of the TRI lights (shade_lights.h: fill_light_tri_geom)
-        // (the light array is a sparse pool: only the slots li_indices[] names hold lights)
-        std::vector<float4> tg(size_t(d->lights_count) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-        for (uint32_t k = 0; k < d->li_indices_count; ++k) {
-            const uint32_t i = d->li_indices[k];
-            if (i >= d->lights_count) {
-                return fail("li_indices[%u] = %u is outside the light array", k, i);
-            }
-            const rayhip_light &l = d->lights[i];
-            if (light_type(l) == LIGHT_TYPE_TRI) {
-                const uint32_t tri = float_as_uint(l.params[0]), mi = float_as_uint(l.params[1]);
-                if (mi >= d->mesh_instances_count || size_t(tri) * 3 + 2 >= d->vtx_indices_count) {
-                    return fail("triangle light %u refers to triangle %u of instance %u: out of range", i, tri, mi);
-                }
-            }
-            fill_light_tri_geom(l, d->mesh_instances, d->vtx_indices, d->vertices, &tg[size_t(i) * 4]);
-        }
-        if (upload(c, c->light_tri_geom, tg.data(), tg.size() * sizeof(float4))) {
-            return 1;
-        }
-        HIP_TRY(hipStreamSynchronize(c->stream)); // `lc` goes out of scope
     }
+    UPLOAD_TRACE("tri_verts done")
+    if (upload_lights(c, d)) {
+        return 1;
+    }
+    UPLOAD_TRACE("lights done")
     UP(textures)
     UP(texels)
     UP(env_qtree)
 #undef UP
     HIP_TRY(hipStreamSynchronize(c->stream)); // host arrays may go away after this call
-    SceneView &v = c->sc;
-    v.nodes = c->nodes.as<rayhip_bvh2_node>(), v.tris = c->tris.as<rayhip_tri_accel>();
-    v.tri_indices = c->tri_indices.as<uint32_t>(), v.tri_materials = c->tri_materials.as<rayhip_tri_mat_data>();
-    v.materials = c->materials.as<rayhip_material>(), v.vertices = c->vertices.as<rayhip_vertex>();
-    v.vtx_indices = c->vtx_indices.as<uint32_t>(), v.mesh_instances = c->mesh_instances.as<rayhip_mesh_instance>();
-    v.lights = c->lights.as<rayhip_light>(), v.li_indices = c->li_indices.as<uint32_t>();
-    v.light_children = c->light_children.as<float4>();
-    v.light_tri_geom = c->light_tri_geom.as<float4>();
-    v.tri_verts = c->tri_verts.as<float4>();
-    v.tri_bitangents = c->tri_bitangents.as<float4>();
-    v.env_qtree = c->env_qtree.as<float4>();
-    for (int lod = 0, off = 0; lod < 16; ++lod) {
-        v.env_qtree_offset[lod] = uint32_t(off);
-        if (lod < d->env.qtree_levels) {
-            off += 1 << (2 * (d->env.qtree_levels - 1 - lod));
-        }
-    }
-    v.nodes4 = have_wide ? c->nodes4.as<Bvh4Node>() : nullptr;
-    v.blas_root4 = have_wide ? c->blas_root4.as<uint32_t>() : nullptr;
-    v.light_cwnodes = c->light_cwnodes.as<rayhip_light_cwbvh_node>(), v.textures = c->textures.as<rayhip_texture>();
-    v.texels = c->texels.as<uint32_t>();
-    memcpy(v.tex_table, d->tex_table, sizeof(v.tex_table));
-    v.li_indices_count = d->li_indices_count;
-    v.light_cwnodes_count = d->light_cwnodes_count;
-    v.visible_lights_count = d->visible_lights_count;
-    v.blocker_lights_count = d->blocker_lights_count;
-    v.tlas_root = tlas_root;
-    v.env = d->env;
-    memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
-    { // ray-sort grid: true bounds of the TLAS root (Scene::GetBounds takes fminf for the max corner, SceneCPU.cpp:1553)
-        float mn[3] = {d->bbox_min[0], d->bbox_min[1], d->bbox_min[2]}, mx[3] = {d->bbox_max[0], d->bbox_max[1], d->bbox_max[2]};
+    c->have_wide = have_wide;
+    memcpy(c->tex_table, d->tex_table, sizeof(c->tex_table));
+    c->textures_count = d->textures_count;
+    c->geometry = {d->vertices_count, d->vtx_indices_count, d->tri_materials_count, d->materials_count};
+    {
+        rayhip_lbvh::Box root_box = rayhip_lbvh::empty_box();
         if (d->tlas_root != 0xffffffffu && d->tlas_root < d->nodes_count) {
-            const rayhip_bvh2_node &r = d->nodes[d->tlas_root];
-            mn[0] = fminf(r.ch_data0[0], r.ch_data1[0]), mx[0] = fmaxf(r.ch_data0[1], r.ch_data1[1]);
-            mn[1] = fminf(r.ch_data0[2], r.ch_data1[2]), mx[1] = fmaxf(r.ch_data0[3], r.ch_data1[3]);
-            mn[2] = fminf(r.ch_data2[0], r.ch_data2[2]), mx[2] = fmaxf(r.ch_data2[1], r.ch_data2[3]);
+            root_box = rayhip_rebuild::node_box(d->nodes[d->tlas_root]);
         }
-        for (int i = 0; i < 3; ++i) {
-            const float ext = mx[i] - mn[i];
-            c->sort_grid.root_min[i] = mn[i];
-            c->sort_grid.inv_cell[i] = (ext > 0.0f && ext < 1e30f) ? 256.0f / ext : 0.0f;
-        }
+        refresh_scene_view(c, d, tlas_root, root_box);
     }
     c->have_scene = true;
     UPLOAD_TRACE("done")
+    return 0;
+}
+
+// ---- instance / light / environment update without a new upload of the geometry -----------------------------------------
+// What SceneBase::SetMeshInstanceTransform / AddMeshInstance / RemoveMeshInstance / AddLight / RemoveLight / SetEnvironment /
+// Finalize change (SceneCPU.cpp:1004-1094, 1103-1162 RebuildTLAS, 1411-1521 RebuildLightTree): the instance array, the
+// top-level tree, the light arrays and the environment.  The top level is rebuilt ON THE DEVICE by the linear builder
+// (lbvh.hip.h) from the instance transforms and the object-space boxes of the bottom-level trees kept from the last full
+// upload; the host's own top-level tree in `d` only says which instance slots are alive.
+// Returns 0, 1 = error, 2 = the scene needs rayhip_scene_upload (an instance of a mesh that is not on the device, geometry
+// arrays of another size, no room for the tree).
+int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->have_scene) {
+        (void)fail("rayhip_scene_update_instances before rayhip_scene_upload");
+        return 2;
+    }
+    const auto upload_t0 = std::chrono::steady_clock::now();
+    (void)upload_t0;
+    if (d->vertices_count != c->geometry.vertices || d->vtx_indices_count != c->geometry.vtx_indices ||
+        d->tri_materials_count != c->geometry.tri_materials || d->materials_count != c->geometry.materials) {
+        (void)fail("geometry arrays changed size since the last upload");
+        return 2;
+    }
+    if (d->env.qtree_levels < 0 || d->env.qtree_levels > 16) {
+        return fail("bad env-map quadtree depth %d", d->env.qtree_levels);
+    }
+    if (d->env.sky_map_spread_angle > 0.0f) {
+        return fail("the physical sky (environment_t::sky_map_spread_angle > 0) is not supported by the HIP backend");
+    }
+    {
+        size_t quads = 0;
+        for (int lod = 0; lod < d->env.qtree_levels; ++lod) {
+            quads += size_t(1) << (2 * (d->env.qtree_levels - 1 - lod));
+        }
+        if (size_t(d->env_qtree_count) != quads * 4) {
+            return fail("env_qtree holds %u floats, %d levels need %zu", d->env_qtree_count, d->env.qtree_levels, quads * 4);
+        }
+        for (const uint32_t handle : {d->env.env_map, d->env.back_map}) {
+            if (handle != 0xffffffffu && uint64_t(c->tex_table[handle >> 28]) + (handle & 0x00ffffffu) >= c->textures_count) {
+                return fail("environment map handle outside the texture table on the device");
+            }
+        }
+    }
+    // live instances: the leaves of the host's top level
+    std::vector<uint32_t> live;
+    if (d->tlas_root != 0xffffffffu) {
+        std::vector<std::pair<uint32_t, uint32_t>> leaves;
+        if (!rayhip_rebuild::collect_leaf_ranges(*d, d->tlas_root, leaves)) {
+            return fail("top-level tree is malformed");
+        }
+        for (const auto &l : leaves) {
+            if (l.first >= d->mesh_instances_count) {
+                return fail("top-level leaf names instance %u of %u", l.first, d->mesh_instances_count);
+            }
+            live.push_back(l.first);
+        }
+        std::sort(live.begin(), live.end());
+        live.erase(std::unique(live.begin(), live.end()), live.end());
+    }
+    // the instance array as the kernels follow it: tree roots of the meshes as laid out on the device
+    std::vector<rayhip_mesh_instance> mis(d->mesh_instances, d->mesh_instances + d->mesh_instances_count);
+    std::vector<uint32_t> root4(d->mesh_instances_count, 0);
+    std::vector<rayhip_lbvh::Box> boxes;
+    boxes.reserve(live.size());
+    for (const uint32_t mi : live) {
+        const auto it = c->mesh_refs.find(mis[mi].mesh_index);
+        if (it == c->mesh_refs.end()) {
+            (void)fail("instance %u uses mesh %u, which is not on the device", mi, mis[mi].mesh_index);
+            return 2;
+        }
+        mis[mi].node_index = it->second.node_index;
+        root4[mi] = it->second.root4;
+        boxes.push_back(rayhip_rebuild::transform_box(it->second.box, mis[mi].xform));
+    }
+    {
+        rayhip_scene_desc lights_only = *d;
+        lights_only.mesh_instances = mis.data();
+        std::string why;
+        if (!rayhip_validate::validate_lights(lights_only, why)) {
+            return fail("%s", why.c_str());
+        }
+    }
+    uint32_t tlas_root = 0xffffffffu;
+    rayhip_lbvh::Box root_box = rayhip_lbvh::empty_box();
+    if (!live.empty()) {
+        const std::vector<uint32_t> group(live.size(), 0);
+        rayhip_lbvh::Input ti;
+        ti.prim_box = boxes.data(), ti.prim_group = group.data(), ti.group_centroids = nullptr;
+        ti.n_prims = uint32_t(boxes.size()), ti.n_groups = 1, ti.leaf_max = 1, ti.leaf_is_primitive = true, ti.roots_are_nodes = true;
+        rayhip_lbvh::Output tlas;
+        std::string why;
+        if (!rayhip_lbvh::build_device(c->stream, ti, tlas, why)) {
+            return fail("top-level build failed: %s", why.c_str());
+        }
+        if (tlas.nodes.size() > c->nodes_reserved || tlas.group_root.empty() || tlas.group_root[0] == 0xffffffffu) {
+            (void)fail("no room for a top-level tree of %zu nodes", tlas.nodes.size());
+            return 2;
+        }
+        constexpr uint32_t COUNT_BITS = 7u << 29, INDEX_BITS = ~COUNT_BITS;
+        const uint32_t base = c->nodes_used;
+        for (rayhip_bvh2_node &n : tlas.nodes) {
+            for (uint32_t *link : {&n.left_child, &n.right_child}) {
+                *link = (*link & COUNT_BITS) == 0 ? *link + base : ((1u << 29) | live[*link & INDEX_BITS]);
+            }
+        }
+        tlas_root = base + tlas.group_root[0];
+        root_box = tlas.bounds;
+        UPLOAD_TRACE("top level built")
+        // pending passes read the old tree: the caller flushed (RendererHIP) or synchronises through the stream order here
+        HIP_TRY(hipMemcpyAsync(c->nodes.as<rayhip_bvh2_node>() + base, tlas.nodes.data(), tlas.nodes.size() * sizeof(rayhip_bvh2_node),
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream)); // `tlas` goes out of scope
+    }
+    if (upload(c, c->mesh_instances, mis.data(), mis.size() * sizeof(rayhip_mesh_instance)) ||
+        (c->have_wide && upload(c, c->blas_root4, root4.data(), root4.size() * sizeof(uint32_t)))) {
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        rayhip_scene_desc with_roots = *d; // triangle lights are placed by their instance's transform only
+        if (upload_lights(c, &with_roots) ||
+            upload(c, c->env_qtree, d->env_qtree, size_t(d->env_qtree_count) * sizeof(float))) {
+            return 1;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    refresh_scene_view(c, d, tlas_root, root_box);
+    UPLOAD_TRACE("instances updated")
     return 0;
 }
 
@@ -818,6 +1023,18 @@ int rayhip_scene_upload_blob(rayhip_ctx *c, const void *blob, size_t size, rayhi
         return 1;
     }
     return 0;
+}
+
+int rayhip_scene_update_instances_blob(rayhip_ctx *c, const void *blob, size_t size, rayhip_camera *out_cam) {
+    rayhip_scene_desc d;
+    const float *ft = nullptr;
+    int ftn = 0;
+    std::string err;
+    rayhip_blob::Extras extras;
+    if (!rayhip_blob::deserialize(blob, size, d, *out_cam, &ft, &ftn, err, &extras)) {
+        return fail("%s", err.c_str());
+    }
+    return rayhip_scene_update_instances(c, &d);
 }
 
 // do the allocated per-iteration pixel buffers and wavefront state hold a pass of `n` iterations over `rect`?

@@ -53,7 +53,13 @@ inline Box triangle_box(const rayhip_scene_desc &d, const uint32_t tri) {
 
 // leaf entry ranges of the tree under `root` (the host trees tell which tris[] entries a mesh owns when the scene carries
 // no mesh table)
+inline bool collect_leaf_ranges(const rayhip_bvh2_node *nodes, const uint32_t nodes_count, const uint32_t root,
+                                std::vector<std::pair<uint32_t, uint32_t>> &ranges);
 inline bool collect_leaf_ranges(const rayhip_scene_desc &d, const uint32_t root, std::vector<std::pair<uint32_t, uint32_t>> &ranges) {
+    return collect_leaf_ranges(d.nodes, d.nodes_count, root, ranges);
+}
+inline bool collect_leaf_ranges(const rayhip_bvh2_node *nodes, const uint32_t nodes_count, const uint32_t root,
+                                std::vector<std::pair<uint32_t, uint32_t>> &ranges) {
     std::vector<uint32_t> stack = {root};
     size_t visited = 0;
     while (!stack.empty()) {
@@ -63,11 +69,11 @@ inline bool collect_leaf_ranges(const rayhip_scene_desc &d, const uint32_t root,
             ranges.emplace_back(w & INDEX_BITS, ((w & COUNT_BITS) >> 29) + 1);
             continue;
         }
-        if (w >= d.nodes_count || ++visited > d.nodes_count) {
+        if (w >= nodes_count || ++visited > nodes_count) {
             return false;
         }
-        stack.push_back(d.nodes[w].left_child);
-        stack.push_back(d.nodes[w].right_child);
+        stack.push_back(nodes[w].left_child);
+        stack.push_back(nodes[w].right_child);
     }
     return true;
 }
@@ -190,7 +196,16 @@ inline void assemble(const rayhip_scene_desc &d, const Gathered &g, const rayhip
     out.tlas_root = tlas.group_root.empty() || tlas.group_root[0] == NONE ? NONE : base + tlas.group_root[0];
 }
 
-inline Rebuilt rebuild_host(const rayhip_scene_desc &d, const uint32_t leaf_max) {
+// `build`: the linear builder to run -- rayhip_lbvh::build_host, or the device driver of lbvh.hip.h (same element functions,
+// same trees); signature  bool(const rayhip_lbvh::Input &, rayhip_lbvh::Output &, std::string &why)
+struct HostBuilder {
+    bool operator()(const rayhip_lbvh::Input &in, rayhip_lbvh::Output &out, std::string &) const {
+        out = rayhip_lbvh::build_host(in);
+        return true;
+    }
+};
+
+template <class Build> inline Rebuilt rebuild_with(const rayhip_scene_desc &d, const uint32_t leaf_max, Build &&build) {
     Rebuilt out;
     Gathered g;
     if (!gather(d, g, out.why)) {
@@ -202,9 +217,12 @@ inline Rebuilt rebuild_host(const rayhip_scene_desc &d, const uint32_t leaf_max)
         return out;
     }
     rayhip_lbvh::Input bi;
-    bi.prim_box = g.prim_box.data(), bi.prim_group = g.prim_group.data();
+    bi.prim_box = g.prim_box.data(), bi.prim_group = g.prim_group.data(), bi.group_centroids = nullptr;
     bi.n_prims = uint32_t(g.prim_box.size()), bi.n_groups = g.n_groups, bi.leaf_max = leaf_max, bi.leaf_is_primitive = false, bi.roots_are_nodes = true;
-    const rayhip_lbvh::Output blas = rayhip_lbvh::build_host(bi);
+    rayhip_lbvh::Output blas;
+    if (!build(bi, blas, out.why)) {
+        return out;
+    }
     for (uint32_t grp = 0; grp < g.n_groups; ++grp) {
         if (blas.group_root[grp] == NONE) {
             out.why = "a mesh without triangles";
@@ -217,13 +235,17 @@ inline Rebuilt rebuild_host(const rayhip_scene_desc &d, const uint32_t leaf_max)
         ibox.push_back(transform_box(node_box(blas.nodes[blas.group_root[g.instance_group[k]]]), d.mesh_instances[g.instances[k]].xform));
     }
     rayhip_lbvh::Input ti;
-    ti.prim_box = ibox.data(), ti.prim_group = igroup.data();
+    ti.prim_box = ibox.data(), ti.prim_group = igroup.data(), ti.group_centroids = nullptr;
     ti.n_prims = uint32_t(ibox.size()), ti.n_groups = 1, ti.leaf_max = 1, ti.leaf_is_primitive = true, ti.roots_are_nodes = true;
-    const rayhip_lbvh::Output tlas = rayhip_lbvh::build_host(ti);
+    rayhip_lbvh::Output tlas;
+    if (!build(ti, tlas, out.why)) {
+        return out;
+    }
     assemble(d, g, blas, ibox, tlas, out);
     out.ok = true;
     return out;
 }
+inline Rebuilt rebuild_host(const rayhip_scene_desc &d, const uint32_t leaf_max) { return rebuild_with(d, leaf_max, HostBuilder()); }
 
 // ---- leaf refinement -------------------------------------------------------------------------------------------------------------
 // The reference's surface-area-heuristic trees are good trees with coarse leaves: up to 8 triangle slots each
@@ -232,7 +254,7 @@ inline Rebuilt rebuild_host(const rayhip_scene_desc &d, const uint32_t leaf_max)
 // the lanes busy), so a ray pays more for the ~15 triangle tests of a walk than for its last tree levels.  Refinement keeps
 // the tree and replaces every leaf that holds more than `leaf_max` triangles by a small subtree over them (the linear
 // builder, one group per leaf) -- same triangle records, same hits.
-inline Rebuilt refine_host(const rayhip_scene_desc &d, const uint32_t leaf_max) {
+template <class Build> inline Rebuilt refine_with(const rayhip_scene_desc &d, const uint32_t leaf_max, Build &&build) {
     Rebuilt out;
     Gathered g;
     if (d.tlas_root == NONE) {
@@ -311,10 +333,13 @@ inline Rebuilt refine_host(const rayhip_scene_desc &d, const uint32_t leaf_max) 
         }
     }
     rayhip_lbvh::Input bi;
-    bi.prim_box = g.prim_box.data(), bi.prim_group = g.prim_group.data();
+    bi.prim_box = g.prim_box.data(), bi.prim_group = g.prim_group.data(), bi.group_centroids = nullptr;
     bi.n_prims = uint32_t(g.prim_box.size()), bi.n_groups = g.n_groups, bi.leaf_max = leaf_max, bi.leaf_is_primitive = false,
     bi.roots_are_nodes = false;
-    const rayhip_lbvh::Output sub = rayhip_lbvh::build_host(bi);
+    rayhip_lbvh::Output sub;
+    if (!build(bi, sub, out.why)) {
+        return out;
+    }
     // splice: the old nodes keep their indices, the subtrees follow them
     out.nodes.assign(d.nodes, d.nodes + d.nodes_count);
     const uint32_t base = d.nodes_count;
@@ -348,5 +373,6 @@ inline Rebuilt refine_host(const rayhip_scene_desc &d, const uint32_t leaf_max) 
     out.ok = true;
     return out;
 }
+inline Rebuilt refine_host(const rayhip_scene_desc &d, const uint32_t leaf_max) { return refine_with(d, leaf_max, HostBuilder()); }
 
 } // namespace rayhip_rebuild

@@ -60,9 +60,11 @@ inline bool walk_tree(const rayhip_scene_desc &d, const uint32_t root, std::vect
     return true;
 }
 
+inline bool validate_lights(const rayhip_scene_desc &d, std::string &err);
+
 inline bool validate(const rayhip_scene_desc &d, std::string &err) {
     constexpr uint32_t COUNT_BITS = 7u << 29, INDEX_BITS = ~COUNT_BITS, NONE = 0xffffffffu;
-    constexpr uint32_t NODE_MIX = 4, NODE_PRINCIPLED = 6, LIGHT_LEAF_BIT = 1u << 31, LIGHT_TYPE_TRI = 5;
+    constexpr uint32_t NODE_MIX = 4, NODE_PRINCIPLED = 6;
     constexpr uint32_t MAT_INDEX_BITS = 16383;
     const uint32_t n_real_tris = d.vtx_indices_count / 3;
 
@@ -200,7 +202,13 @@ inline bool validate(const rayhip_scene_desc &d, std::string &err) {
             }
         }
     }
-    // ---- lights ----
+    return validate_lights(d, err);
+}
+
+// the part an instance / light update replaces (rayhip_scene_update_instances): lights, light tree, env light
+inline bool validate_lights(const rayhip_scene_desc &d, std::string &err) {
+    constexpr uint32_t NONE = 0xffffffffu, LIGHT_LEAF_BIT = 1u << 31, LIGHT_TYPE_TRI = 5;
+    const uint32_t n_real_tris = d.vtx_indices_count / 3;
     for (uint32_t k = 0; k < d.li_indices_count; ++k) {
         const uint32_t i = d.li_indices[k];
         if (i >= d.lights_count) {

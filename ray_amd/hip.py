@@ -76,7 +76,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 # every symbol include/rayhip.h declares (tests check that the built library exports all of them)
 ENTRY_POINTS = (
     "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
-    "scene_upload", "scene_upload_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
+    "scene_upload", "scene_upload_blob", "scene_update_instances", "scene_update_instances_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand", "k_shade",
     "comm_create", "comm_unique_id", "comm_create_rank", "comm_bind", "comm_reduce_framebuffers", "comm_destroy",
@@ -127,6 +127,7 @@ class Library:
         f("k_shade").argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int), vp,
                                  C.POINTER(C.c_int)]
         if prefix == "rayhip_":
+            f("scene_update_instances_blob").argtypes = [vp, vp, C.c_size_t, C.POINTER(Camera)]
             f("readback_device").argtypes = [vp, C.c_int, vp, C.c_int]
             f("set_raw_device").argtypes = [vp, vp, C.c_int, C.POINTER(Camera)]
             f("export_shard_device").argtypes = [vp, C.c_int, vp]
@@ -196,6 +197,18 @@ class Context:
         self.L.check(self.L.fn("scene_upload_blob")(self._ctx, self._blob.ctypes.data, self._blob.size, C.byref(cam)))
         self.cam = cam
         return cam
+
+    def update_instances(self, blob: bytes) -> int:
+        """instances / lights / environment of `blob` over the geometry that is on the device; the top level is rebuilt
+        there (rayhip_scene_update_instances).  Returns 0, or 2 if the change needs a full upload_scene()."""
+        self._blob2 = _aligned_copy(blob)
+        cam = Camera()
+        rc = self.L.fn("scene_update_instances_blob")(self._ctx, self._blob2.ctypes.data, self._blob2.size, C.byref(cam))
+        if rc == 2:
+            return 2
+        self.L.check(rc)
+        self.cam = cam
+        return 0
 
     def render(self, iteration: int, rect=None, cam: Camera = None, flags: int = 0, stats: Stats = None):
         rect = (0, 0, self.w, self.h) if rect is None else rect

@@ -46,13 +46,18 @@ inline uint64_t next_scene_version() {
 }
 
 class Scene final : public Cpu::Scene {
+    // `version_`: any change of an uploaded array.  `geometry_version_`: changes of what rayhip_scene_update_instances
+    // cannot replace (meshes, materials, textures); when only the first one moved, the renderer updates the instances,
+    // lights and environment on the device and rebuilds the top-level tree there instead of uploading the scene again.
     std::atomic<uint64_t> version_{next_scene_version()};
+    std::atomic<uint64_t> geometry_version_{version_.load()};
 
   public:
     Scene(ILog *log, const bool use_tex_compression)
         : Cpu::Scene(log, false /* use_wide_bvh */, use_tex_compression /* decoded at export, scene_export.h */, false) {}
 
     uint64_t version() const { return version_.load(); }
+    uint64_t geometry_version() const { return geometry_version_.load(); }
 
 // every mutator that changes an uploaded array bumps the version (cameras are passed per RenderScene call)
 #define BUMP(ret, name, params, args)                                                                                  \
@@ -60,14 +65,19 @@ class Scene final : public Cpu::Scene {
         version_ = next_scene_version();                                                                               \
         return Cpu::Scene::name args;                                                                                  \
     }
+#define BUMP_GEOMETRY(ret, name, params, args)                                                                         \
+    ret name params override {                                                                                        \
+        geometry_version_ = version_ = next_scene_version();                                                           \
+        return Cpu::Scene::name args;                                                                                  \
+    }
     BUMP(void, SetEnvironment, (const environment_desc_t &env), (env))
-    BUMP(TextureHandle, AddTexture, (const tex_desc_t &t), (t))
-    BUMP(void, RemoveTexture, (const TextureHandle t), (t))
-    BUMP(MaterialHandle, AddMaterial, (const shading_node_desc_t &m), (m))
-    BUMP(MaterialHandle, AddMaterial, (const principled_mat_desc_t &m), (m))
-    BUMP(void, RemoveMaterial, (const MaterialHandle m), (m))
-    BUMP(MeshHandle, AddMesh, (const mesh_desc_t &m), (m))
-    BUMP(void, RemoveMesh, (MeshHandle m), (m))
+    BUMP_GEOMETRY(TextureHandle, AddTexture, (const tex_desc_t &t), (t))
+    BUMP_GEOMETRY(void, RemoveTexture, (const TextureHandle t), (t))
+    BUMP_GEOMETRY(MaterialHandle, AddMaterial, (const shading_node_desc_t &m), (m))
+    BUMP_GEOMETRY(MaterialHandle, AddMaterial, (const principled_mat_desc_t &m), (m))
+    BUMP_GEOMETRY(void, RemoveMaterial, (const MaterialHandle m), (m))
+    BUMP_GEOMETRY(MeshHandle, AddMesh, (const mesh_desc_t &m), (m))
+    BUMP_GEOMETRY(void, RemoveMesh, (MeshHandle m), (m))
     BUMP(LightHandle, AddLight, (const directional_light_desc_t &l), (l))
     BUMP(LightHandle, AddLight, (const sphere_light_desc_t &l), (l))
     BUMP(LightHandle, AddLight, (const spot_light_desc_t &l), (l))
@@ -79,6 +89,7 @@ class Scene final : public Cpu::Scene {
     BUMP(void, SetMeshInstanceTransform, (MeshInstanceHandle mi, const float *xform), (mi, xform))
     BUMP(void, RemoveMeshInstance, (MeshInstanceHandle mi), (mi))
     BUMP(void, Finalize, (const std::function<void(int, int, ParallelForFunction &&)> &parallel_for), (parallel_for))
+#undef BUMP_GEOMETRY
 #undef BUMP
 };
 
@@ -89,7 +100,7 @@ class Renderer final : public RendererBase {
     int w_ = 0, h_ = 0;
 
     const Scene *uploaded_scene_ = nullptr;
-    uint64_t uploaded_version_ = 0;
+    uint64_t uploaded_version_ = 0, uploaded_geometry_version_ = 0;
 
     ePixelFilter filter_table_filter_ = ePixelFilter(-1);
     float filter_table_width_ = 0.0f;
@@ -254,20 +265,35 @@ class Renderer final : public RendererBase {
             Flush(); // pending iterations belong to the scene that is on the device now
             try {
                 FlatScene flat;
-                SceneAccess::Export(*s, flat);
-                if (rayhip_scene_upload(ctx_, &flat.desc) != 0) {
-                    // nothing usable is on the device: forget what was there, so that the next RenderScene tries again
-                    log_->Error("RendererHIP: rayhip_scene_upload failed: %s", rayhip_last_error());
-                    uploaded_scene_ = nullptr, uploaded_version_ = 0;
-                    return;
+                int rc = 2;
+                if (uploaded_scene_ == s && uploaded_geometry_version_ == s->geometry_version()) {
+                    // instances / lights / environment only: the top level is rebuilt on the device
+                    SceneAccess::Export(*s, flat, false /* with_textures */);
+                    rc = rayhip_scene_update_instances(ctx_, &flat.desc);
+                    if (rc == 1) {
+                        // the device state may be half replaced: nothing usable until a full upload succeeds
+                        log_->Error("RendererHIP: rayhip_scene_update_instances failed: %s", rayhip_last_error());
+                        uploaded_scene_ = nullptr, uploaded_version_ = uploaded_geometry_version_ = 0;
+                        return;
+                    }
+                }
+                if (rc == 2) {
+                    SceneAccess::Export(*s, flat);
+                    if (rayhip_scene_upload(ctx_, &flat.desc) != 0) {
+                        // nothing usable is on the device: forget what was there, so that the next RenderScene tries again
+                        log_->Error("RendererHIP: rayhip_scene_upload failed: %s", rayhip_last_error());
+                        uploaded_scene_ = nullptr, uploaded_version_ = uploaded_geometry_version_ = 0;
+                        return;
+                    }
                 }
             } catch (std::exception &e) {
                 log_->Error("RendererHIP: %s", e.what());
-                uploaded_scene_ = nullptr, uploaded_version_ = 0;
+                uploaded_scene_ = nullptr, uploaded_version_ = uploaded_geometry_version_ = 0;
                 return;
             }
             uploaded_scene_ = s;
             uploaded_version_ = s->version();
+            uploaded_geometry_version_ = s->geometry_version();
         }
 
         const camera_t &cam = SceneAccess::CurrentCamera(*s);

@@ -95,7 +95,8 @@ class SceneAccess : public Cpu::Scene {
     static std::shared_timed_mutex &Mutex(const Cpu::Scene &_s) { return static_cast<const SceneAccess &>(_s).mtx_; }
 
     // Caller must hold at least a shared lock on the scene.
-    static void Export(const Cpu::Scene &_s, FlatScene &out) {
+    // `with_textures` = false: everything but the (decoded) texture pool -- what rayhip_scene_update_instances reads
+    static void Export(const Cpu::Scene &_s, FlatScene &out, const bool with_textures = true) {
         // NOTE: the cast never touches SceneAccess-specific state (there is none); it only names the members
         const auto &s = static_cast<const SceneAccess &>(_s);
         if (s.use_wide_bvh_) {
@@ -121,28 +122,32 @@ class SceneAccess : public Cpu::Scene {
         d.light_cwnodes = reinterpret_cast<const rayhip_light_cwbvh_node *>(s.light_cwnodes_.data());
         d.light_cwnodes_count = uint32_t(s.light_cwnodes_.size());
 
-        out.textures.clear(), out.texels.clear();
-        d.tex_table[0] = uint32_t(out.textures.size());
-        export_storage<Cpu::TexStorageRGBA, 4>(s.tex_storage_rgba_, out);
-        d.tex_table[1] = uint32_t(out.textures.size());
-        export_storage<Cpu::TexStorageRGB, 3>(s.tex_storage_rgb_, out);
-        d.tex_table[2] = uint32_t(out.textures.size());
-        export_storage<Cpu::TexStorageRG, 2>(s.tex_storage_rg_, out);
-        d.tex_table[3] = uint32_t(out.textures.size());
-        export_storage<Cpu::TexStorageR, 1>(s.tex_storage_r_, out);
-        // Block-compressed storages (settings_t::use_tex_compression, the reference's default; eTextureFormat::BC1..BC5
-        // inputs): the device keeps every texture as linear RGBA8, so these are DECODED here, texel by texel, with the
-        // reference's own TexStorageBCn::Get (TextureStorageCPU.h:384-544) -- the values a CPU fetch returns, hence the
-        // same images as the reference renders from the compressed data.  (Memory: 4-8x the compressed size; a
-        // Bistro-class texture set stays far below 288 GB.  Decoding on the device is SURVEY section 8f, N4.)
-        d.tex_table[4] = uint32_t(out.textures.size());
-        export_storage<Cpu::TexStorageBCn<3>, 3>(s.tex_storage_bc1_, out);
-        d.tex_table[5] = uint32_t(out.textures.size());
-        export_storage<Cpu::TexStorageBCn<4>, 4>(s.tex_storage_bc3_, out);
-        d.tex_table[6] = uint32_t(out.textures.size());
-        export_storage<Cpu::TexStorageBCn<1>, 1>(s.tex_storage_bc4_, out);
-        d.tex_table[7] = uint32_t(out.textures.size());
-        export_storage<Cpu::TexStorageBCn<2>, 2>(s.tex_storage_bc5_, out);
+        if (with_textures) {
+            out.textures.clear(), out.texels.clear();
+            d.tex_table[0] = uint32_t(out.textures.size());
+            export_storage<Cpu::TexStorageRGBA, 4>(s.tex_storage_rgba_, out);
+            d.tex_table[1] = uint32_t(out.textures.size());
+            export_storage<Cpu::TexStorageRGB, 3>(s.tex_storage_rgb_, out);
+            d.tex_table[2] = uint32_t(out.textures.size());
+            export_storage<Cpu::TexStorageRG, 2>(s.tex_storage_rg_, out);
+            d.tex_table[3] = uint32_t(out.textures.size());
+            export_storage<Cpu::TexStorageR, 1>(s.tex_storage_r_, out);
+            // Block-compressed storages (settings_t::use_tex_compression, the reference's default; eTextureFormat::BC1..BC5
+            // inputs): the device keeps every texture as linear RGBA8, so these are DECODED here, texel by texel, with the
+            // reference's own TexStorageBCn::Get (TextureStorageCPU.h:384-544) -- the values a CPU fetch returns, hence the
+            // same images as the reference renders from the compressed data.  (Memory: 4-8x the compressed size; a
+            // Bistro-class texture set stays far below 288 GB.  Decoding on the device is SURVEY section 8f, N4.)
+            d.tex_table[4] = uint32_t(out.textures.size());
+            export_storage<Cpu::TexStorageBCn<3>, 3>(s.tex_storage_bc1_, out);
+            d.tex_table[5] = uint32_t(out.textures.size());
+            export_storage<Cpu::TexStorageBCn<4>, 4>(s.tex_storage_bc3_, out);
+            d.tex_table[6] = uint32_t(out.textures.size());
+            export_storage<Cpu::TexStorageBCn<1>, 1>(s.tex_storage_bc4_, out);
+            d.tex_table[7] = uint32_t(out.textures.size());
+            export_storage<Cpu::TexStorageBCn<2>, 2>(s.tex_storage_bc5_, out);
+        } else {
+            out.textures.clear(), out.texels.clear();
+        }
         d.textures = out.textures.data();
         d.textures_count = uint32_t(out.textures.size());
         d.texels = out.texels.data();

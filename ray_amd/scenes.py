@@ -855,3 +855,43 @@ SCENES = {
     "cornell_filmic": cornell_filmic,
     "cornell_instances": cornell_instances,
 }
+
+
+def instance_field(scene, count: int = 1000, seed: int = 0, moved: float = 0.0, **cam_overrides):
+    """`count` instances of two block meshes (one of them emissive: every instance brings its triangle lights) scattered over a
+    floor: the dynamic-scene case of SURVEY.md section 8f (N1).  The instance handles are kept on the scene object;
+    move_instance_field() gives every one of them a new transform."""
+    rs = np.random.RandomState(77000 + seed)
+    scene.SetEnvironment(env_col=(0.25, 0.3, 0.4), back_col=(0.25, 0.3, 0.4))
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.55, 0.55, 0.5)))
+    blue = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=(0.2, 0.3, 0.7), roughness=0.3))
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, base_color=(1.0, 0.7, 0.4), strength=6.0, importance_sample=True))
+    attrs, idx = cornell_mesh_arrays([_CORNELL_QUADS[0]])
+    floor = scene.AddMesh(attrs, idx, [(grey, None, 0, 6)])
+    scene.AddMeshInstance(floor, _xform(translate=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0)))
+    attrs, idx = cornell_mesh_arrays(_block_quads("short"))
+    block = scene.AddMesh(attrs, idx, [(blue, None, 0, 30)])
+    lamp = scene.AddMesh(attrs, idx, [(emit, None, 0, 30)])
+    scene._field = []
+    for k in range(count):
+        mesh = lamp if k % 64 == 0 else block
+        scene._field.append((scene.AddMeshInstance(mesh, _field_xform(rs, 0.0)), k))
+    scene.AddLight("sphere", color=(5.0, 5.0, 5.0), position=(-0.28, 0.5, -0.28), radius=0.03)
+    kw = dict(origin=(-0.278, 0.55, 0.25), fwd=(0.0, -0.9, -1.0), fov=55.0, max_total_depth=4)
+    kw.update(cam_overrides)
+    _cornell_camera(scene, **kw)
+    scene.Finalize()
+
+
+def _field_xform(rs, phase: float) -> np.ndarray:
+    s = float(rs.uniform(0.02, 0.06))
+    return _xform(translate=(float(rs.uniform(-0.55, 0.0)) - 0.1 * s, 0.02 * phase, float(rs.uniform(-0.55, 0.0))),
+                  rot_y_deg=float(rs.uniform(0.0, 360.0)) + 40.0 * phase, scale=(s, s * float(rs.uniform(0.5, 3.0)), s))
+
+
+def move_instance_field(scene, seed: int = 1):
+    """a new transform for every instance of instance_field(), then Finalize (the light tree follows the lamps)"""
+    rs = np.random.RandomState(78000 + seed)
+    for handle, _ in scene._field:
+        scene.SetMeshInstanceTransform(handle, _field_xform(rs, 1.0))
+    scene.Finalize()
