@@ -319,10 +319,10 @@ RAYHIP_API int rayhip_scene_upload(rayhip_ctx *ctx, const rayhip_scene_desc *des
 /* What SceneBase::SetMeshInstanceTransform / AddMeshInstance / RemoveMeshInstance / AddLight / RemoveLight /
  * SetEnvironment / Finalize change (SceneCPU.cpp:1004-1094; RebuildTLAS SceneCPU.cpp:1103-1162; RebuildLightTree
  * SceneCPU.cpp:1411-1521), without sending the geometry again: `desc` is the scene as after those calls -- its
- * mesh_instances, lights, li_indices, light_cwnodes, env, env_qtree, tlas_root (+ nodes: only the top level is read, to
- * learn which instance slots are alive), visible/blocker light counts and bounds are used, vertices / vtx_indices for
- * the corners of triangle lights; textures / texels may be null.  The top-level tree is rebuilt on the device from the
- * instance transforms (ray_amd/csrc/lbvh.hip.h).  Meshes, materials and textures must be the ones of the last
+ * mesh_instances, lights, li_indices, light_cwnodes, env, env_qtree, tlas_root (+ nodes: only the top level is read, for
+ * the live instance slots and their world-space boxes), visible/blocker light counts and bounds are used, vertices /
+ * vtx_indices for the corners of triangle lights; textures / texels may be null.  The top-level tree is rebuilt on the
+ * device over those boxes (ray_amd/csrc/lbvh.hip.h).  Meshes, materials and textures must be the ones of the last
  * rayhip_scene_upload.  Returns 0; 1 = error; 2 = this change needs rayhip_scene_upload (an instance of a mesh that was
  * not in use at the last upload, geometry arrays of another size) -- nothing on the device was touched. */
 RAYHIP_API int rayhip_scene_update_instances(rayhip_ctx *ctx, const rayhip_scene_desc *desc);

@@ -112,11 +112,10 @@ struct rayhip_ctx {
     DevBuf shard_stage;   // [4][h][w] float4: this rank's owned pixels of full / base colour / depth-normals / variance, zero elsewhere
                           // (what the multi-GPU frame reduce sums; rayhip_comm_reduce_framebuffers, rayhip_export_shard_device)
     // what rayhip_scene_update_instances needs of the last full upload: per mesh (key: mesh_instance_t::mesh_index) the roots
-    // of its bottom-level trees as uploaded and the object-space box of the tree; node slots reserved behind the uploaded
-    // nodes for top-level trees built later on the device
+    // of its bottom-level trees as uploaded; node slots reserved behind the uploaded nodes for top-level trees built later
+    // on the device
     struct MeshRef {
         uint32_t node_index, root4;
-        rayhip_lbvh::Box box;
     };
     std::unordered_map<uint32_t, MeshRef> mesh_refs;
     uint32_t nodes_used = 0, nodes_reserved = 0;
@@ -782,7 +781,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         }
     }
     UPLOAD_TRACE(have_wide ? "bvh4 built" : "no bvh4")
-    { // the meshes in use, for rayhip_scene_update_instances: roots + object-space boxes of their trees as uploaded
+    { // the meshes in use, for rayhip_scene_update_instances: the roots of their trees as uploaded
         const rayhip_bvh2_node *n2 = lay.applied ? lay.nodes.data() : d->nodes;
         const uint32_t n2_count = lay.applied ? uint32_t(lay.nodes.size()) : d->nodes_count;
         const rayhip_mesh_instance *mis = lay.applied ? lay.mesh_instances.data() : d->mesh_instances;
@@ -792,7 +791,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             for (const auto &leaf : top) {
                 if (leaf.first < d->mesh_instances_count && mis[leaf.first].node_index < n2_count) {
                     c->mesh_refs[mis[leaf.first].mesh_index] = rayhip_ctx::MeshRef{
-                        mis[leaf.first].node_index, have_wide ? blas_root4[leaf.first] : 0u, rayhip_rebuild::node_box(n2[mis[leaf.first].node_index])};
+                        mis[leaf.first].node_index, have_wide ? blas_root4[leaf.first] : 0u};
                 }
             }
         }
@@ -845,8 +844,8 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
 // What SceneBase::SetMeshInstanceTransform / AddMeshInstance / RemoveMeshInstance / AddLight / RemoveLight / SetEnvironment /
 // Finalize change (SceneCPU.cpp:1004-1094, 1103-1162 RebuildTLAS, 1411-1521 RebuildLightTree): the instance array, the
 // top-level tree, the light arrays and the environment.  The top level is rebuilt ON THE DEVICE by the linear builder
-// (lbvh.hip.h) from the instance transforms and the object-space boxes of the bottom-level trees kept from the last full
-// upload; the host's own top-level tree in `d` only says which instance slots are alive.
+// (lbvh.hip.h) over the instance boxes; the host's own top-level tree in `d` (node numbering of the host arrays, which the
+// device does not share after the layout pass) only tells which instance slots are alive and their world-space boxes.
 // Returns 0, 1 = error, 2 = the scene needs rayhip_scene_upload (an instance of a mesh that is not on the device, geometry
 // arrays of another size, no room for the tree).
 int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
@@ -884,27 +883,37 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
             }
         }
     }
-    // live instances: the leaves of the host's top level
+    // Live instances: the leaves of the host's top level, WITH the boxes the host gave them.  (Not recomputed from the
+    // transforms: after a RemoveMeshInstance the reference numbers its top-level leaves by the position of an instance among
+    // the live ones, not by its slot (SceneCPU.cpp:945-951 walks the sparse array, :1000-1008 writes that position into the
+    // leaf), so a leaf may name another slot than the one its box was made from.  The reference's renderers follow the leaf
+    // as written; so do we -- taking slot and box as a pair from the host tree keeps every frame identical to theirs.)
     std::vector<uint32_t> live;
+    std::vector<rayhip_lbvh::Box> boxes;
     if (d->tlas_root != 0xffffffffu) {
-        std::vector<std::pair<uint32_t, uint32_t>> leaves;
-        if (!rayhip_rebuild::collect_leaf_ranges(*d, d->tlas_root, leaves)) {
+        std::vector<std::pair<uint32_t, rayhip_lbvh::Box>> leaves;
+        if (!rayhip_rebuild::collect_leaf_boxes(*d, d->tlas_root, leaves)) {
             return fail("top-level tree is malformed");
         }
+        std::sort(leaves.begin(), leaves.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
         for (const auto &l : leaves) {
             if (l.first >= d->mesh_instances_count) {
                 return fail("top-level leaf names instance %u of %u", l.first, d->mesh_instances_count);
             }
-            live.push_back(l.first);
+            const bool real = l.second.lo[0] <= l.second.hi[0] && l.second.lo[1] <= l.second.hi[1] && l.second.lo[2] <= l.second.hi[2];
+            if (!live.empty() && live.back() == l.first) {
+                if (real) {
+                    rayhip_lbvh::grow(boxes.back(), l.second); // (a lone instance is stored as both children of the root)
+                }
+            } else {
+                live.push_back(l.first);
+                boxes.push_back(real ? l.second : rayhip_lbvh::empty_box());
+            }
         }
-        std::sort(live.begin(), live.end());
-        live.erase(std::unique(live.begin(), live.end()), live.end());
     }
     // the instance array as the kernels follow it: tree roots of the meshes as laid out on the device
     std::vector<rayhip_mesh_instance> mis(d->mesh_instances, d->mesh_instances + d->mesh_instances_count);
     std::vector<uint32_t> root4(d->mesh_instances_count, 0);
-    std::vector<rayhip_lbvh::Box> boxes;
-    boxes.reserve(live.size());
     for (const uint32_t mi : live) {
         const auto it = c->mesh_refs.find(mis[mi].mesh_index);
         if (it == c->mesh_refs.end()) {
@@ -913,7 +922,6 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
         }
         mis[mi].node_index = it->second.node_index;
         root4[mi] = it->second.root4;
-        boxes.push_back(rayhip_rebuild::transform_box(it->second.box, mis[mi].xform));
     }
     {
         rayhip_scene_desc lights_only = *d;

@@ -78,6 +78,35 @@ inline bool collect_leaf_ranges(const rayhip_bvh2_node *nodes, const uint32_t no
     return true;
 }
 
+// the leaves of the host's top-level tree with the boxes they are stored with: (instance slot, box)
+inline bool collect_leaf_boxes(const rayhip_scene_desc &d, const uint32_t root, std::vector<std::pair<uint32_t, Box>> &leaves) {
+    std::vector<uint32_t> stack = {root};
+    size_t visited = 0;
+    while (!stack.empty()) {
+        const uint32_t w = stack.back();
+        stack.pop_back();
+        if (w >= d.nodes_count || ++visited > d.nodes_count) {
+            return false;
+        }
+        const rayhip_bvh2_node &n = d.nodes[w];
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t link = k ? n.right_child : n.left_child;
+            if (link & COUNT_BITS) {
+                Box b;
+                if (k == 0) {
+                    b = Box{{n.ch_data0[0], n.ch_data0[2], n.ch_data2[0]}, {n.ch_data0[1], n.ch_data0[3], n.ch_data2[1]}};
+                } else {
+                    b = Box{{n.ch_data1[0], n.ch_data1[2], n.ch_data2[2]}, {n.ch_data1[1], n.ch_data1[3], n.ch_data2[3]}};
+                }
+                leaves.emplace_back(link & INDEX_BITS, b);
+            } else {
+                stack.push_back(link);
+            }
+        }
+    }
+    return true;
+}
+
 inline bool gather(const rayhip_scene_desc &d, Gathered &g, std::string &why) {
     if (d.tlas_root == NONE) {
         return true;

@@ -18,6 +18,13 @@ from ray_amd import api, hip, scenes
 pytestmark = [pytest.mark.gpu]
 
 
+@pytest.fixture(scope="module")
+def gpu_lib():
+    lib = hip.Library()
+    assert lib.device_count() > 0, "no HIP device: the product has no CPU path, -m gpu tests cannot run here"
+    return lib
+
+
 def _need_host_lib():
     if not os.path.exists(api.HIP_HOST_LIB):
         pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
