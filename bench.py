@@ -50,6 +50,9 @@ import numpy as np  # noqa: E402
 WORKLOADS = {
     "bistro": dict(kind="atrium", detail=4.3, w=1920, h=1080, label="synthetic Bistro-class atrium"),
     "sponza": dict(kind="atrium", detail=0.36, w=1920, h=1080, label="synthetic Sponza-class atrium"),
+    # the same geometry with a texture set (11 mip-mapped 1024^2 maps: base colour on every large surface, a normal map and
+    # roughness maps): not a BASELINE.json config -- the material -> texture gathers a textured asset set adds to the shade stage
+    "bistro_tex": dict(kind="atrium", detail=4.3, textured=True, w=1920, h=1080, label="synthetic Bistro-class atrium, textured"),
     "cornell": dict(kind="cornell_basic", w=1024, h=1024, label="samples/00_basic Cornell box"),
     "principled": dict(kind="cornell_principled", w=2048, h=2048, label="samples/03_principled Cornell box"),
 }
@@ -60,7 +63,7 @@ TILE = 64
 def build_scene(scene, wl):
     from ray_amd import scenes
     if wl["kind"] == "atrium":
-        return scenes.atrium(scene, wl["detail"])
+        return scenes.atrium(scene, wl["detail"], textured=wl.get("textured", False))
     scenes.SCENES[wl["kind"]](scene)
     return scene.triangle_count()
 

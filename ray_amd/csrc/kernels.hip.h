@@ -333,15 +333,18 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 // One stack per lane for both levels: the top lives in a register (`tos`, rt_bvh4.h); entering an instance saves the
 // TLAS `tos` below a sentinel, so the pop that ends the BLAS walk restores it.
 //
-// RESULT (MI355X, Bistro-class 1080p, 32-iteration passes): lanes busy in a node visit 48 % -> 65 %, in a triangle test
-// 21 % -> 40 %, wave-level node visits -24 %, triangle tests -46 % -- and the kernel takes 2.92 ms instead of 2.87.
-// The closest-hit kernel is therefore NOT bound by SIMT utilisation / instruction issue alone: the per-LANE work is
-// unchanged, and that is what the memory pipeline (texture addresser + L2 + random 64-byte HBM reads) sees.  At 59 G
-// node fetches/s + 35 G triangle fetches/s with a third of them missing L2 the kernel sits at ~75 % of what
-// tools/gather_bench.hip reaches for pure random 64-byte gathers of that hit/miss mix.  Kept for the day the node
-// format shrinks (then instruction issue becomes the larger term again).
+// RESULTS (MI355X, Bistro-class 1080p).  Round 1, 32-iteration passes, one block per resident wave slot, every bounce:
+// lanes busy in a node visit 48 % -> 65 %, in a triangle test 21 % -> 40 %, wave-level node visits -24 %, triangle tests
+// -46 % -- and 2.92 ms instead of 2.87: the per-LANE work is unchanged, and that is what the memory pipeline (texture
+// addresser + L2 + random 64-byte HBM reads) sees.  Round 2, after the cheaper node test and the leaf refinement made
+// instruction issue the larger term (64-iteration passes): the coherent primary rays lose (0.52 vs 0.35 ms: every lane of
+// a primary wavefront is busy to the end anyway, the refill only adds its service loop), the secondary bounces gain, and
+// a grid of 16 blocks per wave slot instead of 1 removes the tail of the launch: 1.90 -> 1.74 ms per iteration for the
+// secondary bounces (K2 2.25 -> 2.05 ms), bit-identical frames.  That is the default now (rayhip.hip: RAYHIP_REFILL=2).
+// RT_REFILL_MIN (lanes waiting before the wavefront leaves the BLAS loop to serve them): 16: 2.15, 24: 2.06, 32: 2.07,
+// 40: 2.04 ms.
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 24
+#define RT_REFILL_MIN 40
 #endif
 #ifndef RT_REFILL_MIN_WAVES
 #define RT_REFILL_MIN_WAVES 5 // 96 VGPRs, no scratch (6 waves: 80 VGPRs with spills in the loop, slower)

@@ -93,6 +93,7 @@ struct rayhip_ctx {
     int grid_waves = 0; // resident-ish grid for the wave-per-block kernels
     bool small_scene = false; // BLAS nodes + triangles fit one XCD's L2: traversal kernels with the smaller register footprint
     int refill_waves = 0; // exactly-resident grid of the persistent closest-hit kernel; 0 = kernel switched off
+    bool refill_secondary_only = false; // RAYHIP_REFILL=2: primary rays (coherent, every lane busy to the end) keep the plain kernel
 
     DevBuf pmj, filter_table;
     // scene
@@ -417,18 +418,27 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
         c->shade_split = atoi(e) & 3;
     }
-    // the persistent ray-refill form of the closest-hit kernel (opt-in, RAYHIP_REFILL=1: measured equal or slower, see
-    // kernels.hip.h) runs one block per resident wave slot
-    if (getenv("RAYHIP_REFILL") != nullptr && atoi(getenv("RAYHIP_REFILL")) != 0) {
-        int per_cu_refill = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_refill, k_trace_closest_refill, WAVE, 0) != hipSuccess || per_cu_refill <= 0) {
-            per_cu_refill = per_cu;
+    // The persistent ray-refill form of the closest-hit kernel (kernels.hip.h): lanes whose ray is finished fetch the next one
+    // instead of idling until the longest walk of their wavefront ends.  RAYHIP_REFILL: 2 (default) = for the secondary
+    // bounces (incoherent rays, 45 % of the lane slots of the plain kernel belong to finished rays: K2 2.25 -> 2.05 ms per
+    // iteration on the Bistro-class scene), the coherent primary rays keep the plain kernel (refill: 0.52 vs 0.35 ms);
+    // 1 = every bounce; 0 = off.  The grid is RAYHIP_REFILL_MULT (default 16) blocks per resident wave slot: with exactly
+    // one block per slot the launch ends on its slowest wavefront (1x: 1.84, 4x: 1.79, 16x: 1.74 ms; 64x the same).
+    // Scenes that fit L2 gain too (03_principled 2048^2: 965 -> 994 Msamples/s, Cornell 1024^2: 1056 -> 1064).
+    {
+        const int mode = getenv("RAYHIP_REFILL") != nullptr ? atoi(getenv("RAYHIP_REFILL")) : 2;
+        if (mode != 0) {
+            int per_cu_refill = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_refill, k_trace_closest_refill, WAVE, 0) != hipSuccess || per_cu_refill <= 0) {
+                per_cu_refill = per_cu;
+            }
+            int refill_mult = 16;
+            if (const char *e = getenv("RAYHIP_REFILL_MULT")) {
+                refill_mult = std::max(1, std::min(64, atoi(e)));
+            }
+            c->refill_waves = std::min(c->grid_waves, c->props.multiProcessorCount * per_cu_refill * refill_mult);
+            c->refill_secondary_only = mode == 2;
         }
-        int refill_mult = 1;
-        if (const char *e = getenv("RAYHIP_REFILL_MULT")) {
-            refill_mult = std::max(1, std::min(64, atoi(e)));
-        }
-        c->refill_waves = std::min(c->grid_waves, c->props.multiProcessorCount * per_cu_refill * refill_mult);
     }
     if (c->stack_spill.alloc(size_t(c->grid_waves) * STACK_SPILL_DEPTH * WAVE * sizeof(uint32_t))) {
         delete c;
@@ -1143,7 +1153,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             k_trace_closest<true, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else if (count) {
             k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
-        } else if (c->sc.nodes4 && c->refill_waves) {
+        } else if (c->sc.nodes4 && c->refill_waves && !(c->refill_secondary_only && !init_hits)) {
             k_trace_closest_refill<<<std::min(gtrace, c->refill_waves), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
         } else if (c->sc.nodes4 && c->small_scene) {
             k_trace_closest<false, true, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);

@@ -531,18 +531,59 @@ class _MeshBuilder:
         return np.concatenate(self.attrs), np.concatenate(self.idx), self.groups
 
 
-def atrium(scene, detail: float = 1.0, cam_overrides=None):
-    """Synthetic atrium, 30 x 12 x 18 (SURVEY.md section 8d input 3/4).  Triangle count ~ 250k * detail."""
+def _procedural_texture(res: int, seed: int, kind: str) -> np.ndarray:
+    """tileable RGBA8 pattern from sines and value noise: "albedo" (mottled, mid-grey mean so that a base colour still tints
+    it), "rough" (one channel repeated) or "normal" (tangent-space bumps)"""
+    y, x = np.meshgrid(np.arange(res) / res, np.arange(res) / res, indexing="ij")
+    two_pi = 2.0 * math.pi
+    f = np.zeros((res, res))
+    for k, (fx, fy) in enumerate(((3, 5), (7, 2), (13, 11), (29, 17), (61, 47))):
+        f += np.sin(two_pi * (fx * x + fy * y) + seed * (k + 1.3)) * np.cos(two_pi * (fy * x - fx * y) + seed * 0.7 * k) / (k + 1.5)
+    f = (f - f.min()) / (f.max() - f.min())
+    grain = _noise(np.stack([x * res, y * res, x * 0 + seed], -1), seed)
+    if kind == "albedo":
+        v = 0.55 + 0.35 * (f - 0.5) + 0.12 * (grain - 0.5)
+        rgb = np.stack([v * (1.0 + 0.08 * np.sin(seed)), v, v * (1.0 - 0.08 * np.cos(seed))], -1)
+    elif kind == "rough":
+        v = 0.35 + 0.5 * f + 0.1 * (grain - 0.5)
+        rgb = np.stack([v, v, v], -1)
+    else:
+        gy, gx = np.gradient(f + 0.05 * grain)
+        nrm = _normalize(np.stack([-gx * res * 0.02, -gy * res * 0.02, np.ones_like(f)], -1))
+        rgb = nrm * 0.5 + 0.5
+    out = np.empty((res, res, 4), dtype=np.uint8)
+    out[..., :3] = np.clip(rgb * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    out[..., 3] = 255
+    return out
+
+
+def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = False, tex_res: int = 1024):
+    """Synthetic atrium, 30 x 12 x 18 (SURVEY.md section 8d input 3/4).  Triangle count ~ 250k * detail.
+    textured=True: every large surface gets its own mip-mapped base-colour map, the stone also a normal map, the floor a
+    roughness map (11 maps of tex_res^2: the material -> texture gathers a textured asset set causes in the shade stage)."""
     d = max(detail, 0.02)
     s = math.sqrt(d)
     scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
-    stone = scene.AddMaterial(PrincipledMat(base_color=(0.62, 0.58, 0.50), roughness=0.7, specular=0.3))
-    floor_m = scene.AddMaterial(PrincipledMat(base_color=(0.35, 0.33, 0.32), roughness=0.35, specular=0.5))
-    cloth_r = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.55, 0.08, 0.07), roughness=0.5))
-    cloth_g = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.10, 0.40, 0.12), roughness=0.5))
-    cloth_b = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.10, 0.15, 0.50), roughness=0.5))
-    metal = scene.AddMaterial(PrincipledMat(base_color=(0.90, 0.75, 0.40), metallic=1.0, roughness=0.25))
-    glossy = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=(0.8, 0.8, 0.85), roughness=0.15))
+    tex = {}
+    if textured:
+        for k, (name, kind, srgb, nm) in enumerate((("stone", "albedo", True, False), ("stone_n", "normal", False, True),
+                                                     ("floor", "albedo", True, False), ("floor_r", "rough", False, False),
+                                                     ("cloth_r", "albedo", True, False), ("cloth_g", "albedo", True, False),
+                                                     ("cloth_b", "albedo", True, False), ("metal", "albedo", True, False),
+                                                     ("metal_r", "rough", False, False), ("glossy", "albedo", True, False),
+                                                     ("stone_r", "rough", False, False))):
+            tex[name] = scene.AddTexture(_procedural_texture(tex_res, 3 + k, kind), is_srgb=srgb, is_normalmap=nm, generate_mipmaps=True)
+    t = lambda name: tex.get(name)  # noqa: E731
+    stone = scene.AddMaterial(PrincipledMat(base_color=(0.62, 0.58, 0.50), roughness=0.7, specular=0.3, base_texture=t("stone"),
+                                            normal_map=t("stone_n"), roughness_texture=t("stone_r")))
+    floor_m = scene.AddMaterial(PrincipledMat(base_color=(0.35, 0.33, 0.32), roughness=0.35, specular=0.5, base_texture=t("floor"),
+                                              roughness_texture=t("floor_r")))
+    cloth_r = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.55, 0.08, 0.07), roughness=0.5, base_texture=t("cloth_r")))
+    cloth_g = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.10, 0.40, 0.12), roughness=0.5, base_texture=t("cloth_g")))
+    cloth_b = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.10, 0.15, 0.50), roughness=0.5, base_texture=t("cloth_b")))
+    metal = scene.AddMaterial(PrincipledMat(base_color=(0.90, 0.75, 0.40), metallic=1.0, roughness=0.25, base_texture=t("metal"),
+                                            roughness_texture=t("metal_r")))
+    glossy = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=(0.8, 0.8, 0.85), roughness=0.15, base_texture=t("glossy")))
     emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=18.0, base_color=(1.0, 0.95, 0.85),
                                          importance_sample=True))
     X, Y, Z = 30.0, 12.0, 18.0

@@ -81,9 +81,10 @@ def _check(img, ref, min_psnr, what):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= min_psnr and m["alpha_equal"], (what, m)
 
 
-@pytest.mark.parametrize("name", ["sponza", "bistro"])
+@pytest.mark.parametrize("name", ["sponza", "bistro", "bistro_tex"])
 def test_atrium_1080p_against_renderer_ref(name):
-    """configs 3 and 4 at 1920 x 1080: iteration 1, then 20 iterations in one 20-layer pass (the shape bench.py times)"""
+    """configs 3 and 4 at 1920 x 1080: iteration 1, then 20 iterations in one 20-layer pass (the shape bench.py times);
+    bistro_tex: config 4 with a texture set (mip-mapped base-colour / normal / roughness maps on every large surface)"""
     wk = Workload(name)
     wk.ctx.render(1)
     _check(wk.ctx.readback(hip.BUF_RAW), wk.ref_frame(1), util.MIN_PSNR_1SPP, f"{name} 1080p 1 spp")

@@ -1,67 +1,137 @@
 #!/usr/bin/env python3
-"""rocprofv3 counter CSVs -> profiles/<round>/k2_traffic.json: HBM-side bytes per launch of the closest-hit kernel.
+"""rocprofv3 counter CSVs -> profiles/<round>/k2_traffic.json (HBM-side bytes per launch of the closest-hit kernel) and a
+per-kernel HBM table of the whole timed region.
 
-    python tools/k2_traffic.py <out.json> <workload> <steps> <warmup> <iterations_per_pass> <fetch_dir> <write_dir> [<stats_csv>]
+    python tools/k2_traffic.py <out.json> <workload> <steps> <warmup> <iterations_per_pass> <fetch_dir> <write_dir> [<table.txt>]
 
 fetch_dir / write_dir: output directories of two `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of
-`bench.py --steps <steps> --warmup <warmup> --no-cpu-baseline` (separate passes: the two counters do not fit one).  Only
-launches of the timed shape count: the warm-up passes (different iteration count per pass) and the instrumented kernels that
-bench.py runs after the timed region are told apart by name / by being the largest launches.  Unit of both counters: KiB.
-Appends / replaces the entry for this (workload, steps, iterations_per_pass)."""
-import csv, glob, json, os, sys
+`bench.py --steps <steps> --warmup <warmup> --no-cpu-baseline` (separate passes: the two counters do not fit one).
 
-KERNEL = "k_trace_closest<false, true, 6>"
+The closest-hit kernel K2 has two forms (rayhip.hip): k_trace_closest<false,true,N> for the primary rays and
+k_trace_closest_refill for the secondary bounces; "a K2 launch" is a launch of either.  Which launches belong to the timed
+region: bench.py runs, in this order, one priming pass of the timed shape, the warm-up passes, the timed passes and then the
+instrumented passes (other kernels: k_trace_closest<true,...>); every product pass has the same number of K2 launches
+(primary + one per bounce), so the timed ones are the LAST ceil(steps / ipp) x launches_per_pass product launches.
+Unit of both counters: KiB.  Appends / replaces the entry for this (workload, steps, iterations_per_pass)."""
+import csv, glob, json, os, re, sys
+
+K2_FORMS = ("k_trace_closest<false, true", "k_trace_closest_refill")
 
 
-def per_launch(d, counter):
+def short(name):
+    name = name.split("(")[0].replace("void ", "").replace("rt::", "")
+    return re.sub(r"\s+", " ", name).strip()
+
+
+def counters(d, counter):
+    """[(dispatch id, kernel, bytes)] in dispatch order"""
     vals = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if KERNEL in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-                    vals.append((int(row.get("Dispatch_Id", 0)), float(row["Counter_Value"]) * 1024.0))
+                if row.get("Counter_Name") == counter:
+                    vals.append((int(row.get("Dispatch_Id", 0)), short(row.get("Kernel_Name", "")), float(row["Counter_Value"]) * 1024.0))
     vals.sort()
-    return [v for _, v in vals]
+    return vals
+
+
+def durations(d):
+    """[(start, kernel, ms)] in start order"""
+    out = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                out.append((int(row["Start_Timestamp"]), short(row.get("Kernel_Name", "")), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6))
+    out.sort()
+    return out
+
+
+def is_k2(kernel):
+    return any(kernel.startswith(k) for k in K2_FORMS)
 
 
 def main():
     out, workload, steps, warmup, ipp, fetch_dir, write_dir = sys.argv[1:8]
+    table_path = sys.argv[8] if len(sys.argv) > 8 else None
     steps, warmup, ipp = int(steps), int(warmup), int(ipp)
-    fetch, write = per_launch(fetch_dir, "FETCH_SIZE"), per_launch(write_dir, "WRITE_SIZE")
-    # launches per pass: primary + one per bounce; the timed passes are the LAST ceil(steps / ipp) passes of the product kernel
+    fetch_all, write_all, dur_all = counters(fetch_dir, "FETCH_SIZE"), counters(write_dir, "WRITE_SIZE"), durations(fetch_dir)
+    fetch = [(i, k, v) for i, k, v in fetch_all if is_k2(k)]
+    write = [(i, k, v) for i, k, v in write_all if is_k2(k)]
+    durs = [(t, k, v) for t, k, v in dur_all if is_k2(k)]
     passes = -(-steps // ipp)
     warm_passes = -(-warmup // ipp) if warmup else 0
-    per_pass = len(fetch) // max(passes + warm_passes, 1)
+    per_pass = len(fetch) // max(passes + warm_passes + 1, 1)  # (+1: the priming pass)
     take = per_pass * passes
-    f, w = fetch[-take:], write[-take:]
+    f, w, dd = fetch[-take:], write[-take:], durs[-take:]
+    fsum, wsum = sum(v for _, _, v in f), sum(v for _, _, v in w)
     entry = {"workload": workload, "steps": steps, "warmup": warmup, "iterations_per_pass": ipp,
+             "kernels": sorted({k for _, k, _ in f}),
              "launches_sampled": len(f), "launches_per_pass": per_pass,
-             "fetch_bytes_per_launch": sum(f) / max(len(f), 1), "write_bytes_per_launch": sum(w) / max(len(w), 1),
+             "fetch_bytes_per_launch": fsum / max(len(f), 1), "write_bytes_per_launch": wsum / max(len(w), 1),
              "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) -- python bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline"}
-    # launch durations of the same launches, from the kernel trace the FETCH_SIZE pass wrote (under the profiler; bench.py
-    # measures its own with HIP events in the unprofiled run)
-    durs = []
-    for f in glob.glob(os.path.join(fetch_dir, "**", "*kernel_trace.csv"), recursive=True):
-        with open(f) as fh:
-            for row in csv.DictReader(fh):
-                if KERNEL in row.get("Kernel_Name", ""):
-                    durs.append((int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6))
-    durs = [d for _, d in sorted(durs)][-take:]
-    if durs:
-        entry["avg_launch_ms"] = sum(durs) / len(durs)
+    if dd:
+        entry["avg_launch_ms"] = sum(v for _, _, v in dd) / len(dd)
         entry["hbm_GBps_under_profiler"] = (entry["fetch_bytes_per_launch"] + entry["write_bytes_per_launch"]) / 1e9 / (entry["avg_launch_ms"] / 1e3)
-    table = {"_comment": "HBM-side traffic of k_trace_closest<false,true,6> per launch of the timed passes; unit bytes (counters are KiB). "
+    table = {"_comment": "HBM-side traffic of the closest-hit kernel (k_trace_closest<false,true,N> for primary rays, k_trace_closest_refill for "
+                         "the secondary bounces) per launch of the timed passes; unit bytes (counters are KiB). "
                          "FETCH_SIZE on this access pattern (random 64-byte gathers) was calibrated at 0.96-0.98 x the missed bytes "
                          "(profiles/r01/gather_bench.txt), so no x2 correction is applied; Infinity-Cache hits are included in both counters "
                          "(MI355X_MICROARCH.md), i.e. this is an upper bound of what reached HBM.", "runs": []}
     if os.path.exists(out):
         with open(out) as fh:
             table = json.load(fh)
+        table["_comment"] = table.get("_comment", "")
     table["runs"] = [e for e in table.get("runs", []) if not (e["workload"] == workload and e["steps"] == steps and e["iterations_per_pass"] == ipp)]
     table["runs"].append(entry)
     with open(out, "w") as fh:
         json.dump(table, fh, indent=1)
     print(json.dumps(entry))
+
+    if table_path:
+        # every kernel of the timed region: the dispatches after the first timed K2 launch and before the first instrumented kernel
+        first_id = f[0][0] if f else 0
+        last_id = max(i for i, _, _ in f) if f else 0
+        # (the stages that follow the last K2 launch of the pass -- shade, shadow, accumulate -- belong to it too: take every
+        # product dispatch up to the first instrumented / counting kernel after last_id)
+        end_id = None
+        for i, k, _ in fetch_all:
+            if i > last_id and k.startswith("k_trace_closest<true"):
+                end_id = i
+                break
+        fb, wb, n = {}, {}, {}
+        for i, k, v in fetch_all:
+            if i >= first_id and (end_id is None or i < end_id):
+                fb[k] = fb.get(k, 0.0) + v
+                n[k] = n.get(k, 0) + 1
+        for i, k, v in write_all:
+            if i >= first_id and (end_id is None or i < end_id):
+                wb[k] = wb.get(k, 0.0) + v
+        # durations of the same kernels: the last n[k] launches of each kernel before the instrumented ones cannot be told
+        # apart by id in the trace, so take time per kernel over the same count of launches counted back from the end of the
+        # product launches
+        t_first = dd[0][0] if dd else 0
+        t_end = None
+        for t, k, _ in dur_all:
+            if dd and t > dd[-1][0] and k.startswith("k_trace_closest<true"):
+                t_end = t
+                break
+        ms = {}
+        for t, k, v in dur_all:
+            if t >= t_first and (t_end is None or t < t_end):
+                ms[k] = ms.get(k, 0.0) + v
+        total_ms = sum(ms.values())
+        with open(table_path, "w") as fh:
+            fh.write(f"# per-kernel HBM-side traffic of the timed passes: bench.py --workload {workload} --steps {steps} --warmup {warmup}\n"
+                     f"# (rocprofv3 --kernel-trace --pmc FETCH_SIZE, second run --pmc WRITE_SIZE; times from the FETCH_SIZE run, i.e. under the profiler)\n"
+                     f"# {'kernel':58s} {'launches':>8s} {'ms':>9s} {'% time':>7s} {'fetch GB':>9s} {'write GB':>9s} {'TB/s':>6s} {'% of 8 TB/s':>11s}\n")
+            for k in sorted(ms, key=lambda k: -ms[k]):
+                gb_f, gb_w = fb.get(k, 0.0) / 1e9, wb.get(k, 0.0) / 1e9
+                rate = (gb_f + gb_w) / ms[k] if ms[k] > 0 else 0.0  # GB / ms = TB/s
+                fh.write(f"  {k[:58]:58s} {n.get(k, 0):8d} {ms[k]:9.2f} {100 * ms[k] / total_ms:7.1f} {gb_f:9.2f} {gb_w:9.2f} {rate:6.2f} {100 * rate / 8.0:11.1f}\n")
+            tot_gb = (sum(fb.values()) + sum(wb.values())) / 1e9
+            fh.write(f"  {'all kernels':58s} {sum(n.values()):8d} {total_ms:9.2f} {100.0:7.1f} {sum(fb.values()) / 1e9:9.2f} {sum(wb.values()) / 1e9:9.2f} "
+                     f"{tot_gb / total_ms if total_ms else 0:6.2f} {100 * tot_gb / total_ms / 8.0 if total_ms else 0:11.1f}\n")
+        print(open(table_path).read())
 
 
 if __name__ == "__main__":

@@ -31,10 +31,12 @@ def build_one(name, flags):
     import __graft_entry__ as g
     out = os.path.join(VDIR, name)
     os.makedirs(out, exist_ok=True)
+    shade_only = [f[7:] for f in flags if f.startswith("+shade:")]  # "+shade:<flag>": for shade_kernels.hip only
+    trace_only = [f[7:] for f in flags if f.startswith("+trace:")]  # "+trace:<flag>": for rayhip.hip only
     flags = [f for f in flags if not f.startswith("+")]
     base = [f for f in g.HIPCC_FLAGS if not (f.startswith("-ffp-contract") and any(x.startswith("-ffp-contract") for x in flags))]
-    objs = {"rayhip": ("rayhip.hip", []),
-            "shade": ("shade_kernels.hip", [])}
+    objs = {"rayhip": ("rayhip.hip", trace_only),
+            "shade": ("shade_kernels.hip", shade_only)}
     class R:
         stderr = ""
         returncode = 0
