@@ -20,7 +20,8 @@ inside the timed region.  Total work is fixed -> "scaling": "strong".
 Timed region: barrier + stream sync | K iterations (+ the reduce at N>1) | stream sync + barrier; max over ranks.
 Inputs (scene, PMJ table) are resident in HBM before the region starts; nothing is copied to the host inside it.
 
-roofline (dominant kernel: k_trace_closest<false,true>, the closest-hit traversal K2).  Its launches are bracketed by HIP
+roofline (dominant kernel: the closest-hit traversal K2 -- k_trace_closest_refill for the secondary bounces,
+k_trace_closest<false,true> for the primary rays; "a launch" is a launch of either).  Its launches are bracketed by HIP
 events on the context stream during the timed region (RAYHIP_FLAG_TIME_STAGES, no synchronisation).  Three byte counts,
 all per launch:
   traffic      HBM bytes that actually moved: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE of this kernel, from a profiled run of
@@ -343,7 +344,7 @@ def main():
                        "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 RCCL reduce/frame)",
                        "iterations_per_pass": batch},
             "roofline": {
-                "bound": "hbm", "kernel": "k_trace_closest<false,true> (closest-hit traversal, K2)",
+                "bound": "hbm", "kernel": "K2 closest-hit traversal: k_trace_closest_refill (secondary bounces) + k_trace_closest<false,true> (primary rays)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "achieved_is": ("HBM traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE of a profiled run of this command) / launch time"
                                 if hbm_gbs is not None else

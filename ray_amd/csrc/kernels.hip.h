@@ -675,13 +675,13 @@ __global__ void __launch_bounds__(WAVE) k_shadow_blockers(const SceneView sc, co
 // ---- K6 / K8: ray sort ----------------------------------------------------------------------------------------
 // K6: one sort key per live secondary ray (slots >= the live count get the DEAD key so a fixed-size sort works)
 __global__ void __launch_bounds__(256) k_ray_keys(const RaySoA rays, const uint32_t *__restrict__ ray_count, const uint32_t cap,
-                                                 const SortGrid grid, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+                                                 const SortGrid grid, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx, const int mode) {
     const uint32_t n = *ray_count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
-        uint32_t key = SORT_KEY_DEAD >> (32 - SORT_KEY_BITS);
+        uint32_t key = SORT_KEY_DEAD >> (32 - ray_sort_key_bits(mode));
         if (i < n) {
             const float4 o = rays.o_pdf[i], d = rays.d_cw[i];
-            key = ray_sort_key(grid, f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z});
+            key = ray_sort_key(grid, f3{o.x, o.y, o.z}, f3{d.x, d.y, d.z}, mode);
         }
         keys[i] = key;
         idx[i] = i;

@@ -93,6 +93,8 @@ struct rayhip_ctx {
     int grid_waves = 0; // resident-ish grid for the wave-per-block kernels
     bool small_scene = false; // BLAS nodes + triangles fit one XCD's L2: traversal kernels with the smaller register footprint
     int refill_waves = 0; // exactly-resident grid of the persistent closest-hit kernel; 0 = kernel switched off
+    int sort_key_mode = 0; // RAYHIP_SORT_KEY (tuning, rt_sort.h)
+    int tune_primary_waves = 0, tune_shadow_waves = 0; // RAYHIP_PRIMARY_WAVES / RAYHIP_SHADOW_WAVES (tuning): register footprint of K2 (primary) / K3
     bool refill_secondary_only = false; // RAYHIP_REFILL=2: primary rays (coherent, every lane busy to the end) keep the plain kernel
 
     DevBuf pmj, filter_table;
@@ -415,6 +417,15 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         }
     }
     c->grid_waves = c->props.multiProcessorCount * per_cu * grid_mult;
+    if (const char *e = getenv("RAYHIP_PRIMARY_WAVES")) {
+        c->tune_primary_waves = atoi(e);
+    }
+    if (const char *e = getenv("RAYHIP_SHADOW_WAVES")) {
+        c->tune_shadow_waves = atoi(e);
+    }
+    if (const char *e = getenv("RAYHIP_SORT_KEY")) {
+        c->sort_key_mode = std::max(0, std::min(3, atoi(e)));
+    }
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
         c->shade_split = atoi(e) & 3;
     }
@@ -1155,7 +1166,9 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else if (c->sc.nodes4 && c->refill_waves && !(c->refill_secondary_only && !init_hits)) {
             k_trace_closest_refill<<<std::min(gtrace, c->refill_waves), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
-        } else if (c->sc.nodes4 && c->small_scene) {
+        } else if (c->sc.nodes4 && c->tune_primary_waves == 4) { // (tuning)
+            k_trace_closest<false, true, 4><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
+        } else if (c->sc.nodes4 && (c->small_scene || c->tune_primary_waves == 5)) {
             k_trace_closest<false, true, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else if (c->sc.nodes4) {
             k_trace_closest<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
@@ -1194,10 +1207,10 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
                     return 1;
                 }
                 k_ray_keys<<<grid_for(c, npix, 256), 256, 0, s>>>(c->rays[cur], c->ray_count(bounce), uint32_t(npix), c->sort_grid,
-                                                                  c->sort_keys[0].as<uint32_t>(), c->sort_idx[0].as<uint32_t>());
+                                                                  c->sort_keys[0].as<uint32_t>(), c->sort_idx[0].as<uint32_t>(), c->sort_key_mode);
                 HIP_TRY(sort_pairs(c->sort_temp.p, c->sort_temp.bytes, c->sort_keys[0].as<uint32_t>(),
                                    c->sort_keys[1].as<uint32_t>(), c->sort_idx[0].as<uint32_t>(), c->sort_idx[1].as<uint32_t>(),
-                                   npix, SORT_KEY_BITS, s));
+                                   npix, ray_sort_key_bits(c->sort_key_mode), s));
                 k_reorder_rays<<<grid_for(c, npix, 256), 256, 0, s>>>(c->rays[cur], c->rays[cur ^ 1], c->sort_idx[1].as<uint32_t>(),
                                                                       c->ray_count(bounce));
                 cur ^= 1;
@@ -1227,7 +1240,10 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         } else if (count) {
             k_trace_shadow<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
                                                                 vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
-        } else if (c->sc.nodes4 && c->small_scene) {
+        } else if (c->sc.nodes4 && c->tune_shadow_waves == 4) { // (tuning)
+            k_trace_shadow<false, true, 4><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes),
+                                                                   limit, vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
+        } else if (c->sc.nodes4 && (c->small_scene || c->tune_shadow_waves == 5)) {
             k_trace_shadow<false, true, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes),
                                                                                       limit, vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
         } else if (c->sc.nodes4) {

@@ -33,13 +33,25 @@ struct SortGrid {
     float inv_cell[3]; // 256 / extent
 };
 
-RT_HD uint32_t ray_sort_key(const SortGrid &g, const f3 o, const f3 d) {
+// `mode` (tuning, RAYHIP_SORT_KEY): 0 = the key above; 1 = direction octant only (3 bits: what binning at emission could do
+// without a sort pass); 2 = coarse cell, then octant (18 bits); 3 = octant, then coarse cell (18 bits)
+RT_HD uint32_t ray_sort_key_bits(const int mode) { return mode == 1 ? 3u : (mode == 2 || mode == 3) ? 18u : SORT_KEY_BITS; }
+RT_HD uint32_t ray_sort_key(const SortGrid &g, const f3 o, const f3 d, const int mode = 0) {
     const int x = clampi(int((o.x - g.root_min[0]) * g.inv_cell[0]), 0, 255);
     const int y = clampi(int((o.y - g.root_min[1]) * g.inv_cell[1]), 0, 255);
     const int z = clampi(int((o.z - g.root_min[2]) * g.inv_cell[2]), 0, 255);
     const uint32_t m = part1by2_8(uint32_t(x)) | (part1by2_8(uint32_t(y)) << 1) | (part1by2_8(uint32_t(z)) << 2); // 24 b
     const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
     const uint32_t coarse = m >> 9, fine = m & 0x1ffu;
+    if (mode == 1) {
+        return oct;
+    }
+    if (mode == 2) {
+        return (coarse << 3) | oct;
+    }
+    if (mode == 3) {
+        return (oct << 15) | coarse;
+    }
     return (coarse << 12) | (oct << 9) | fine;
 }
 
