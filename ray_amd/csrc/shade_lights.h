@@ -280,56 +280,40 @@ RT_HD float sin_of_clamped_difference(float sin_a, float cos_a, float sin_b, flo
 }
 // importance of one child as seen from P: flux * cos(max(theta_w - theta_o - theta_b, 0)) / max(d^2, half_diag), zero outside
 // the emission cone widened by theta_e (CoreRef.cpp:1024-1066)
+// (written without an early exit: an empty or box-less child yields its flux through the final select, the arithmetic above it
+// runs on the zero rows of its table entry and is discarded.  That keeps the eight evaluations of a node free of control
+// flow, so the compiler can issue the table loads of all children before the first use -- with the branch the descent
+// paid one memory round trip per child, 8 in a row per level, and k_light_pick sat 75 % of its time in s_waitcnt.)
 RT_HD float light_child_importance(const LightChild &c, const f3 P) {
-    float importance = c.cosines.w;
-    if (c.centre_valid.w != 0.0f && importance != 0.0f) {
-        const float half_diag = c.axis_extent.w;
-        float w[3] = {P.x - c.centre_valid.x, P.y - c.centre_valid.y, P.z - c.centre_valid.z};
-        const float d2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-        const float d = steer_sqrt(d2);
-        w[0] = steer_div(w[0], d), w[1] = steer_div(w[1], d), w[2] = steer_div(w[2], d);
-        const float falloff_d2 = sse_max(d2, half_diag);
-        const float cos_w = c.axis_extent.x * w[0] + c.axis_extent.y * w[1] + c.axis_extent.z * w[2];
-        const float sin_w = steer_sqrt(sse_max(1.0f - cos_w * cos_w, 0.0f));
-        // angle under which the box is seen (inside the bounding sphere: everything)
-        float cos_b = steer_sqrt(sse_max(1.0f - steer_div(half_diag * half_diag, d2), 0.0f));
-        if (d2 < half_diag * half_diag) {
-            cos_b = -1.0f;
-        }
-        const float sin_b = steer_sqrt(1.0f - cos_b * cos_b);
-        const float cos_o = c.cosines.x, sin_o = c.cosines.y, cos_e = c.cosines.z;
-        const float cos_x = cos_of_clamped_difference(sin_w, cos_w, sin_o, cos_o);
-        const float sin_x = sin_of_clamped_difference(sin_w, cos_w, sin_o, cos_o);
-        const float cos_min = cos_of_clamped_difference(sin_x, cos_x, sin_b, cos_b);
-        float geometric = 0.0f;
-        if (cos_min > cos_e) {
-            geometric = steer_div(cos_min, falloff_d2);
-        }
-        importance = importance * geometric;
-    }
-    return importance;
+    const float flux = c.cosines.w;
+    const float half_diag = c.axis_extent.w;
+    float w[3] = {P.x - c.centre_valid.x, P.y - c.centre_valid.y, P.z - c.centre_valid.z};
+    const float d2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const float d = steer_sqrt(d2);
+    w[0] = steer_div(w[0], d), w[1] = steer_div(w[1], d), w[2] = steer_div(w[2], d);
+    const float falloff_d2 = sse_max(d2, half_diag);
+    const float cos_w = c.axis_extent.x * w[0] + c.axis_extent.y * w[1] + c.axis_extent.z * w[2];
+    const float sin_w = steer_sqrt(sse_max(1.0f - cos_w * cos_w, 0.0f));
+    // angle under which the box is seen (inside the bounding sphere: everything)
+    float cos_b = steer_sqrt(sse_max(1.0f - steer_div(half_diag * half_diag, d2), 0.0f));
+    cos_b = (d2 < half_diag * half_diag) ? -1.0f : cos_b;
+    const float sin_b = steer_sqrt(1.0f - cos_b * cos_b);
+    const float cos_o = c.cosines.x, sin_o = c.cosines.y, cos_e = c.cosines.z;
+    const float cos_x = cos_of_clamped_difference(sin_w, cos_w, sin_o, cos_o);
+    const float sin_x = sin_of_clamped_difference(sin_w, cos_w, sin_o, cos_o);
+    const float cos_min = cos_of_clamped_difference(sin_x, cos_x, sin_b, cos_b);
+    const float geometric = (cos_min > cos_e) ? steer_div(cos_min, falloff_d2) : 0.0f;
+    return (c.centre_valid.w != 0.0f && flux != 0.0f) ? flux * geometric : flux;
 }
-// the eight importances of a node, and their sum in the oracle's SSE association order
-RT_HD void light_node_importances(const SceneView &sc, uint32_t node, const f3 P, float imp[8]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // Near the root every lane of a wavefront sits at the same node.  When that is the case the node index is made
-    // wave-uniform for the compiler (readfirstlane), which turns the 26 per-lane 16-byte gathers of the node's table rows into
-    // scalar loads through the constant cache: same values, a fraction of the memory-pipeline work.
-    const uint32_t first = uint32_t(__builtin_amdgcn_readfirstlane(int(node)));
-    if (__builtin_amdgcn_ballot_w64(node != first) == 0ull) {
-        node = first;
-    }
-#endif
-    const float4 *t = sc.light_children + size_t(node) * LIGHT_CHILDREN_STRIDE;
-    const float4 f0 = t[0], f1 = t[1];
-    const float flux[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+// the eight importances of a node (their sum is taken in the oracle's SSE association order, sum8_sse_order)
+RT_HD void light_node_importances(const SceneView &sc, const uint32_t node, const f3 P, float imp[8]) {
+    const float4 *t = sc.light_children + size_t(node) * LIGHT_CHILDREN_STRIDE + 2; // (rows 0-1: the fluxes again, for host-side tools)
+    LightChild c[8];
     for (int i = 0; i < 8; ++i) {
-        imp[i] = flux[i];
-        if (flux[i] != 0.0f) {
-            LightChild c;
-            c.axis_extent = t[2 + 3 * i + 0], c.centre_valid = t[2 + 3 * i + 1], c.cosines = t[2 + 3 * i + 2];
-            imp[i] = light_child_importance(c, P);
-        }
+        c[i].axis_extent = t[3 * i + 0], c[i].centre_valid = t[3 * i + 1], c[i].cosines = t[3 * i + 2];
+    }
+    for (int i = 0; i < 8; ++i) {
+        imp[i] = light_child_importance(c[i], P);
     }
 }
 RT_HD float sum8_sse_order(const float v[8]) { return (((v[0] + v[4]) + (v[1] + v[5])) + (v[2] + v[6])) + (v[3] + v[7]); }
