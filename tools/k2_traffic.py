@@ -90,6 +90,9 @@ def main():
     if table_path:
         # every kernel of the timed region: the dispatches after the first timed K2 launch and before the first instrumented kernel
         first_id = f[0][0] if f else 0
+        # (the pass starts with its ray generation, just before the first K2 launch)
+        gen = [i for i, k, _ in fetch_all if k.startswith("k_raygen") and i < first_id]
+        first_id = max(gen) if gen else first_id
         last_id = max(i for i, _, _ in f) if f else 0
         # (the stages that follow the last K2 launch of the pass -- shade, shadow, accumulate -- belong to it too: take every
         # product dispatch up to the first instrumented / counting kernel after last_id)
@@ -110,6 +113,8 @@ def main():
         # apart by id in the trace, so take time per kernel over the same count of launches counted back from the end of the
         # product launches
         t_first = dd[0][0] if dd else 0
+        gen_t = [t for t, k, _ in dur_all if k.startswith("k_raygen") and t < t_first]
+        t_first = max(gen_t) if gen_t else t_first
         t_end = None
         for t, k, _ in dur_all:
             if dd and t > dd[-1][0] and k.startswith("k_trace_closest<true"):
