@@ -214,7 +214,15 @@ typedef struct rayhip_scene_desc {
     uint32_t visible_lights_count;
     uint32_t blocker_lights_count;
     float bbox_min[3], bbox_max[3]; /* Scene::GetBounds (SceneCPU.cpp:1523), feeds the ray-sort grid only */
+    uint32_t texture_flags;         /* RAYHIP_TEX_* */
 } rayhip_scene_desc;
+
+/* rayhip_scene_desc::texture_flags.  RAW_BC: the textures of the four block-compressed storages (tex_table[4..7]: BC1,
+ * BC3, BC4, BC5 -- reference TexStorageBCn<3|4|1|2>, TextureStorageCPU.h:364-617) are handed over as the reference keeps
+ * them, 4x4 blocks of 8 / 16 / 8 / 16 bytes in row-major tile order, and decoded per fetch on the device (rt_texture.h);
+ * rayhip_texture::offset[] of such a texture counts 32-bit words of `texels` like everywhere else, width / height are
+ * the mip's size in texels.  Without the flag every texture is row-major RGBA8. */
+#define RAYHIP_TEX_RAW_BC 1u
 
 /* == RendererBase::stats_t (reference RendererBase.h:230-244), microseconds */
 typedef struct rayhip_stats {

@@ -101,6 +101,7 @@ class TexDesc(C.Structure):  # ray_tex_desc
         ("force_no_compression", C.c_int32),
         ("generate_mipmaps", C.c_int32),
         ("reconstruct_z", C.c_int32),
+        ("mips_count", C.c_int32),
     ]
 
 

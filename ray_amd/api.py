@@ -48,6 +48,10 @@ class eTextureFormat(IntEnum):  # SceneBase.h:151
     RGB888 = 2
     RG88 = 3
     R8 = 4
+    BC1 = 5  # block-compressed inputs: `data` holds the 4x4 blocks of `mips_count` levels, width / height are given
+    BC3 = 6
+    BC4 = 7
+    BC5 = 8
 
 
 class ePixelFilter(IntEnum):  # Types.h:60
@@ -145,10 +149,12 @@ class SceneBase:
 
     # -- textures / materials ----------------------------------------------------------------------------------
     def AddTexture(self, data: np.ndarray, fmt=eTextureFormat.RGBA8888, is_srgb=True, is_normalmap=False,
-                   generate_mipmaps=False, reconstruct_z=False, force_no_compression=True) -> int:
+                   generate_mipmaps=False, reconstruct_z=False, force_no_compression=True, size=None, mips_count=1,
+                   is_YCoCg=False) -> int:
         data = np.ascontiguousarray(data, dtype=np.uint8)
-        h, w = data.shape[0], data.shape[1]
+        h, w = (size[1], size[0]) if size is not None else (data.shape[0], data.shape[1])  # size = (w, h): block-compressed data
         d = _capi.TexDesc()
+        d.mips_count, d.is_YCoCg = int(mips_count), int(is_YCoCg)
         d.format = int(fmt)
         d.data = data.ctypes.data_as(C.POINTER(C.c_uint8))
         d.data_size = data.size

@@ -123,7 +123,7 @@ struct rayhip_ctx {
     std::unordered_map<uint32_t, MeshRef> mesh_refs;
     uint32_t nodes_used = 0, nodes_reserved = 0;
     bool have_wide = false;
-    uint32_t tex_table[8] = {}, textures_count = 0;
+    uint32_t tex_table[8] = {}, textures_count = 0, tex_flags = 0;
     struct { uint32_t vertices, vtx_indices, tri_materials, materials; } geometry = {};
     bool adaptive_dirty = false; // a pass ran with variance_threshold != 0 since the last Clear / Resize: required_samples may
                                  // lie below the next iteration, so passes are not batched (rayhip_render_batch)
@@ -638,6 +638,7 @@ static void refresh_scene_view(rayhip_ctx *c, const rayhip_scene_desc *d, const 
     v.light_cwnodes = c->light_cwnodes.as<rayhip_light_cwbvh_node>(), v.textures = c->textures.as<rayhip_texture>();
     v.texels = c->texels.as<uint32_t>();
     memcpy(v.tex_table, c->tex_table, sizeof(v.tex_table));
+    v.tex_flags = c->tex_flags;
     v.li_indices_count = d->li_indices_count;
     v.light_cwnodes_count = d->light_cwnodes_count;
     v.visible_lights_count = d->visible_lights_count;
@@ -848,6 +849,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     c->have_wide = have_wide;
     memcpy(c->tex_table, d->tex_table, sizeof(c->tex_table));
     c->textures_count = d->textures_count;
+    c->tex_flags = d->texture_flags;
     c->geometry = {d->vertices_count, d->vtx_indices_count, d->tri_materials_count, d->materials_count};
     {
         rayhip_lbvh::Box root_box = rayhip_lbvh::empty_box();

@@ -43,6 +43,7 @@ struct SceneView {
     uint32_t env_qtree_offset[16]; // first quad of each lod
     const uint32_t *pmj; // 32 dims x 4096 samples x 2 (u32), reference Core.h:363-368
     uint32_t tex_table[8];
+    uint32_t tex_flags; // rayhip_scene_desc::texture_flags
     uint32_t li_indices_count;
     uint32_t light_cwnodes_count;
     uint32_t visible_lights_count;

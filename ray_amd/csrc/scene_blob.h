@@ -35,7 +35,7 @@ struct Section {
 struct Scalars {
     uint32_t tex_table[8];
     rayhip_environment env;
-    uint32_t tlas_root, visible_lights_count, blocker_lights_count, _pad;
+    uint32_t tlas_root, visible_lights_count, blocker_lights_count, texture_flags; // (the last one: padding, i.e. 0, in blobs of round 1)
     float bbox_min[3], bbox_max[3];
 };
 
@@ -81,6 +81,7 @@ inline std::vector<uint8_t> serialize(const rayhip_scene_desc &d, const rayhip_c
     sc.env = d.env;
     sc.tlas_root = d.tlas_root, sc.visible_lights_count = d.visible_lights_count;
     sc.blocker_lights_count = d.blocker_lights_count;
+    sc.texture_flags = d.texture_flags;
     memcpy(sc.bbox_min, d.bbox_min, 12), memcpy(sc.bbox_max, d.bbox_max, 12);
     add_section(secs, payload, "scalars", &sc, sizeof(sc));
     add_section(secs, payload, "camera", &cam, sizeof(cam));
@@ -190,6 +191,7 @@ inline bool deserialize(const void *blob, size_t size, rayhip_scene_desc &d, ray
             d.env = sc.env;
             d.tlas_root = sc.tlas_root, d.visible_lights_count = sc.visible_lights_count;
             d.blocker_lights_count = sc.blocker_lights_count;
+            d.texture_flags = sc.texture_flags;
             memcpy(d.bbox_min, sc.bbox_min, 12), memcpy(d.bbox_max, sc.bbox_max, 12);
             have_scalars = true;
         } else if (name == "camera" && s.size == sizeof(rayhip_camera)) {

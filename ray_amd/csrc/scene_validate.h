@@ -195,8 +195,19 @@ inline bool validate(const rayhip_scene_desc &d, std::string &err) {
         if (!tex_used[t]) {
             continue;
         }
+        // the storage a table entry belongs to: the last one whose first entry is not behind it (block-compressed storages
+        // handed over as blocks occupy 2 or 4 words per 4x4 tile, everything else one word per texel)
+        uint32_t storage = 0;
+        for (uint32_t k = 0; k < 8; ++k) {
+            if (d.tex_table[k] <= t) {
+                storage = k;
+            }
+        }
+        const bool blocks = storage >= 4 && (d.texture_flags & RAYHIP_TEX_RAW_BC) != 0u;
+        const uint64_t words_per_block = (storage == 5 || storage == 7) ? 4 : 2;
         for (int l = 0; l < 12; ++l) {
-            const uint64_t end = uint64_t(d.textures[t].offset[l]) + uint64_t(d.textures[t].width[l]) * d.textures[t].height[l];
+            const uint64_t w = d.textures[t].width[l], h = d.textures[t].height[l];
+            const uint64_t end = uint64_t(d.textures[t].offset[l]) + (blocks ? ((w + 3) / 4) * ((h + 3) / 4) * words_per_block : w * h);
             if (end > d.texels_count) {
                 return fail(err, "texture mip end", t, end, uint64_t(d.texels_count) + 1);
             }

@@ -307,6 +307,7 @@ ray_handle ray_scene_add_texture(ray_scene *s, const ray_tex_desc *d) {
     t.is_srgb = d->is_srgb != 0, t.is_normalmap = d->is_normalmap != 0, t.is_YCoCg = d->is_YCoCg != 0;
     t.force_no_compression = d->force_no_compression != 0, t.generate_mipmaps = d->generate_mipmaps != 0;
     t.reconstruct_z = d->reconstruct_z != 0;
+    t.mips_count = d->mips_count > 0 ? d->mips_count : 1;
     return from_handle(s->s->AddTexture(t));
 }
 

@@ -103,6 +103,7 @@ typedef struct ray_tex_desc { /* Ray::tex_desc_t, SceneBase.h:172-187 */
     uint64_t data_size;
     int32_t w, h;
     int32_t is_srgb, is_normalmap, is_YCoCg, force_no_compression, generate_mipmaps, reconstruct_z;
+    int32_t mips_count;         /* levels present in `data` (block-compressed formats; 0 = 1) */
 } ray_tex_desc;
 
 typedef struct ray_light_desc { /* union of the six light descriptors, SceneBase.h:189-262 */

@@ -10,6 +10,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <vector>
@@ -38,6 +39,22 @@ static_assert(offsetof(rayhip_camera, pass_settings) == offsetof(camera_t, pass_
 static_assert(offsetof(rayhip_camera, origin) == offsetof(camera_t, origin), "layout");
 static_assert(sizeof(rayhip_pass_settings) == sizeof(pass_settings_t), "layout");
 static_assert(sizeof(rayhip_stats) == sizeof(RendererBase::stats_t), "layout");
+
+// ---- the block-compressed storages as they are kept ----------------------------------------------------
+// TexStorageBCn<N> (TextureStorageCPU.h:364-617) keeps its images -- 4x4 blocks per mip -- in a private member and offers
+// texel-wise Get only.  The explicit instantiation below hands out a pointer to that member (explicit instantiations may name
+// private members, [temp.spec]/6); a maintainer integrating this backend would add a `const ImgData &image(int) const`
+// accessor instead.
+template <int N> struct BcImagesTag {
+    friend auto bc_images_member(BcImagesTag); // defined by the instantiation of BcImagesGrant below
+};
+template <class Tag, auto Member> struct BcImagesGrant {
+    friend auto bc_images_member(Tag) { return Member; }
+};
+template struct BcImagesGrant<BcImagesTag<1>, &Cpu::TexStorageBCn<1>::images_>;
+template struct BcImagesGrant<BcImagesTag<2>, &Cpu::TexStorageBCn<2>::images_>;
+template struct BcImagesGrant<BcImagesTag<3>, &Cpu::TexStorageBCn<3>::images_>;
+template struct BcImagesGrant<BcImagesTag<4>, &Cpu::TexStorageBCn<4>::images_>;
 
 // Owns the converted texture pool; every other pointer in `desc` aliases the scene's own storage and stays
 // valid until the next scene mutation.
@@ -87,6 +104,28 @@ class SceneAccess : public Cpu::Scene {
         }
     }
 
+    // a block-compressed storage as it is: the 4x4 blocks of every mip, copied word for word (RAYHIP_TEX_RAW_BC)
+    template <int N> static void export_blocks(const Cpu::TexStorageBCn<N> &st, FlatScene &out) {
+        const auto &images = st.*bc_images_member(BcImagesTag<N>{});
+        const int block_bytes = (N == 4 || N == 2) ? 16 : 8;
+        for (int i = 0; i < st.img_count(); ++i) {
+            const auto &img = images[size_t(i)];
+            rayhip_texture t = {};
+            for (int lod = 0; lod < NUM_MIP_LEVELS; ++lod) {
+                t.width[lod] = uint32_t(img.res[lod][0]), t.height[lod] = uint32_t(img.res[lod][1]);
+                if (lod && img.lod_offsets[lod] == img.lod_offsets[lod - 1]) {
+                    t.offset[lod] = t.offset[lod - 1]; // a missing level aliases the last real one (TextureStorageCPU.cpp:349-353)
+                    continue;
+                }
+                const size_t bytes = size_t(img.res_in_tiles[lod][0]) * size_t(img.res_in_tiles[lod][1]) * size_t(block_bytes);
+                t.offset[lod] = uint32_t(out.texels.size());
+                out.texels.resize(out.texels.size() + bytes / 4);
+                memcpy(&out.texels[t.offset[lod]], &img.pixels[size_t(img.lod_offsets[lod])], bytes);
+            }
+            out.textures.push_back(t);
+        }
+    }
+
   public:
     static const camera_t &CurrentCamera(const Cpu::Scene &_s) {
         const auto &s = static_cast<const SceneAccess &>(_s);
@@ -96,7 +135,14 @@ class SceneAccess : public Cpu::Scene {
 
     // Caller must hold at least a shared lock on the scene.
     // `with_textures` = false: everything but the (decoded) texture pool -- what rayhip_scene_update_instances reads
-    static void Export(const Cpu::Scene &_s, FlatScene &out, const bool with_textures = true) {
+    // `raw_blocks`: the block-compressed storages are handed over as blocks and decoded per fetch on the device (a quarter to
+    // an eighth of the footprint); false = decoded here, texel by texel, with the reference's own TexStorageBCn::Get
+    // (RAY_HIP_DECODE_BC=1 selects the second form: A/B measurements and tests)
+    static bool RawBlocksByDefault() {
+        const char *e = getenv("RAY_HIP_DECODE_BC");
+        return !(e && e[0] == '1');
+    }
+    static void Export(const Cpu::Scene &_s, FlatScene &out, const bool with_textures = true, const bool raw_blocks = RawBlocksByDefault()) {
         // NOTE: the cast never touches SceneAccess-specific state (there is none); it only names the members
         const auto &s = static_cast<const SceneAccess &>(_s);
         if (s.use_wide_bvh_) {
@@ -133,18 +179,18 @@ class SceneAccess : public Cpu::Scene {
             d.tex_table[3] = uint32_t(out.textures.size());
             export_storage<Cpu::TexStorageR, 1>(s.tex_storage_r_, out);
             // Block-compressed storages (settings_t::use_tex_compression, the reference's default; eTextureFormat::BC1..BC5
-            // inputs): the device keeps every texture as linear RGBA8, so these are DECODED here, texel by texel, with the
-            // reference's own TexStorageBCn::Get (TextureStorageCPU.h:384-544) -- the values a CPU fetch returns, hence the
-            // same images as the reference renders from the compressed data.  (Memory: 4-8x the compressed size; a
-            // Bistro-class texture set stays far below 288 GB.  Decoding on the device is SURVEY section 8f, N4.)
+            // inputs): kept as blocks (RAYHIP_TEX_RAW_BC; the device decodes the texel it fetches, rt_texture.h), or --
+            // raw_blocks = false -- decoded here with the reference's own TexStorageBCn::Get (TextureStorageCPU.h:384-544).
+            // Either way the values a CPU fetch returns, hence the same images as the reference renders from the compressed data.
             d.tex_table[4] = uint32_t(out.textures.size());
-            export_storage<Cpu::TexStorageBCn<3>, 3>(s.tex_storage_bc1_, out);
+            raw_blocks ? export_blocks<3>(s.tex_storage_bc1_, out) : export_storage<Cpu::TexStorageBCn<3>, 3>(s.tex_storage_bc1_, out);
             d.tex_table[5] = uint32_t(out.textures.size());
-            export_storage<Cpu::TexStorageBCn<4>, 4>(s.tex_storage_bc3_, out);
+            raw_blocks ? export_blocks<4>(s.tex_storage_bc3_, out) : export_storage<Cpu::TexStorageBCn<4>, 4>(s.tex_storage_bc3_, out);
             d.tex_table[6] = uint32_t(out.textures.size());
-            export_storage<Cpu::TexStorageBCn<1>, 1>(s.tex_storage_bc4_, out);
+            raw_blocks ? export_blocks<1>(s.tex_storage_bc4_, out) : export_storage<Cpu::TexStorageBCn<1>, 1>(s.tex_storage_bc4_, out);
             d.tex_table[7] = uint32_t(out.textures.size());
-            export_storage<Cpu::TexStorageBCn<2>, 2>(s.tex_storage_bc5_, out);
+            raw_blocks ? export_blocks<2>(s.tex_storage_bc5_, out) : export_storage<Cpu::TexStorageBCn<2>, 2>(s.tex_storage_bc5_, out);
+            d.texture_flags = raw_blocks ? RAYHIP_TEX_RAW_BC : 0u;
         } else {
             out.textures.clear(), out.texels.clear();
         }

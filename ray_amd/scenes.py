@@ -433,6 +433,42 @@ def cornell_textures(scene, **cam_overrides):
     scene.Finalize()
 
 
+def random_blocks(fmt: eTextureFormat, w: int, h: int, mips: int, seed: int) -> np.ndarray:
+    """`mips` levels of 4x4 blocks with random bytes: every bit pattern is a valid BC1 / BC3 / BC4 / BC5 block, so this walks
+    all selector values, both end-point orders and the tile padding of sizes that are not multiples of four"""
+    rs = np.random.RandomState(4200 + seed)
+    block = 16 if fmt in (eTextureFormat.BC3, eTextureFormat.BC5) else 8
+    out = []
+    for _ in range(mips):
+        out.append(rs.randint(0, 256, size=((w + 3) // 4) * ((h + 3) // 4) * block, dtype=np.uint8))
+        w, h = max(w // 2, 1), max(h // 2, 1)
+    return np.concatenate(out)
+
+
+def cornell_block_textures(scene, **cam_overrides):
+    """Cornell box textured from pre-compressed inputs (eTextureFormat::BC1 / BC3 / BC4 / BC5 -> the four block storages,
+    SceneCPU.cpp:160-178): base colour maps in BC1 and BC3, a roughness map in BC4, a two-channel normal map in BC5
+    (z reconstructed), with mip levels and odd sizes"""
+    scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
+    F = eTextureFormat
+    t_bc1 = scene.AddTexture(random_blocks(F.BC1, 24, 20, 3, 1), fmt=F.BC1, size=(24, 20), mips_count=3, is_srgb=True)
+    t_bc3 = scene.AddTexture(random_blocks(F.BC3, 18, 30, 2, 2), fmt=F.BC3, size=(18, 30), mips_count=2, is_srgb=True)
+    t_bc4 = scene.AddTexture(random_blocks(F.BC4, 32, 32, 4, 3), fmt=F.BC4, size=(32, 32), mips_count=4, is_srgb=False)
+    t_bc5 = scene.AddTexture(random_blocks(F.BC5, 16, 16, 1, 4), fmt=F.BC5, size=(16, 16), mips_count=1, is_srgb=False, is_normalmap=True)
+    m1 = scene.AddMaterial(PrincipledMat(base_texture=t_bc1, roughness=1.0, roughness_texture=t_bc4, specular=0.5))
+    m3 = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_texture=t_bc3, normal_map=t_bc5, normal_map_intensity=0.6))
+    m4 = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_texture=t_bc1, roughness=0.8, roughness_texture=t_bc4))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.0, 0.0)))
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=100.0, importance_sample=True))
+    attrs, idx = cornell_mesh_arrays()
+    groups = [(m1, None, 0, 6), (m3, None, 6, 6), (m3, None, 12, 6), (red, None, 19, 6), (m4, None, 25, 6),
+              (emit, 0xFFFFFFFF, 31, 6), (m1, None, 37, 30), (m4, None, 67, 30)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
 def _xform(translate=(0.0, 0.0, 0.0), rot_y_deg=0.0, rot_z_deg=0.0, scale=(1.0, 1.0, 1.0)) -> np.ndarray:
     """4x4 T * Ry * Rz * S in the layout the reference takes (column vectors, translation in elements 12..14)"""
     cy, sy = np.cos(np.radians(rot_y_deg)), np.sin(np.radians(rot_y_deg))

@@ -235,6 +235,7 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     v.li_indices = s.li_indices.data(), v.light_cwnodes = s.light_cwnodes.data(), v.textures = s.textures.data();
     v.texels = s.texels.data();
     memcpy(v.tex_table, d->tex_table, sizeof(v.tex_table));
+    v.tex_flags = d->texture_flags;
     v.li_indices_count = d->li_indices_count;
     v.light_cwnodes_count = d->light_cwnodes_count;
     v.visible_lights_count = d->visible_lights_count;

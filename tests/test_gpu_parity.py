@@ -529,6 +529,33 @@ def test_compressed_textures_through_the_ray_api(gpu_lib, hostsim_lib):
     assert not np.array_equal(imgs[1], imgs[2]), "compression did not change a texel: not exercised"
 
 
+def test_block_textures_are_decoded_on_the_device(gpu_lib, hostsim_lib):
+    """the four block-compressed storages cross the boundary as blocks (RAYHIP_TEX_RAW_BC) and a fetch decodes its texel on
+    the device: random BC1 / BC3 / BC4 / BC5 blocks (host build of the same decoder: bit-exact against the reference's
+    TexStorageBCn::Get, test_hostsim_parity.py); the base-colour image of the first hits must match the host build's to
+    rounding, the frame within tolerance"""
+    import os
+    from ray_amd import api, scenes
+    if not os.path.exists(api.HIP_HOST_LIB):
+        pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
+    w, h, spp = 96, 96, 4
+    s = api.CreateSceneHIP()
+    scenes.cornell_block_textures(s)
+    blob = api.export_scene_blob(s)
+    imgs, base = [], []
+    for lib in (gpu_lib, hostsim_lib):
+        ctx = hip.Context(0, lib)
+        ctx.upload_static(util.pmj())
+        ctx.resize(w, h)
+        ctx.upload_scene_blob(blob)
+        imgs.append(util.render_frames(ctx, spp))
+        base.append(ctx.readback(hip.BUF_BASE_COLOR))
+    m = util.frame_metrics(imgs[0], imgs[1])
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
+    # base colour: texel values through srgb_to_linear (device powf): tight, not exact
+    assert np.abs(base[0] - base[1]).max() <= 2e-6, np.abs(base[0] - base[1]).max()
+
+
 def test_renderer_hip_reuploads_a_mutated_scene(gpu_lib, hostsim_lib):
     """scene mutators between RenderScene calls (with iterations still pending): RendererHIP must flush, notice the new
     scene version and upload the mutated arrays -- sparse pools with freed slots, rebuilt TLAS / light tree"""

@@ -352,11 +352,14 @@ def test_sky_portals_against_live_reference(lib):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
-def test_compressed_textures_against_live_reference(lib):
+@pytest.mark.parametrize("decode_at_export", ["0", "1"], ids=["blocks", "decoded"])
+def test_compressed_textures_against_live_reference(lib, decode_at_export, monkeypatch):
     """settings_t::use_tex_compression (the reference's default): RGBA/RGB/R inputs and normal maps land in the BC3
-    (YCoCg) / BC4 / BC5 storages; the exporter decodes them with the reference's own block decoder, so the frames must
-    equal the reference's rendered from the compressed data"""
+    (YCoCg) / BC4 / BC5 storages.  They cross the boundary as the reference keeps them -- 4x4 blocks, decoded per fetch by
+    rt_texture.h (RAYHIP_TEX_RAW_BC) -- or decoded at export with the reference's own block decoder; either way the frames
+    must equal the reference's rendered from the compressed data"""
     from ray_amd import api, scenes
+    monkeypatch.setenv("RAY_HIP_DECODE_BC", decode_at_export)
 
     w, h, spp = 64, 64, 4
     r, s = O.render_ref(scenes.cornell_textures, w, h, spp, use_tex_compression=True)
@@ -369,6 +372,25 @@ def test_compressed_textures_against_live_reference(lib):
     assert np.array_equal(img, r.get_raw_pixels_ref())
     assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
     assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
+
+
+@pytest.mark.parametrize("decode_at_export", ["0", "1"], ids=["blocks", "decoded"])
+def test_block_compressed_inputs_against_live_reference(lib, decode_at_export, monkeypatch):
+    """pre-compressed inputs (eTextureFormat::BC1 / BC3 / BC4 / BC5 -> TexStorageBCn<3|4|1|2>::AllocateRaw) made of random
+    bytes -- every selector, both end-point orders, mip levels, sizes that are not multiples of four: the per-fetch block
+    decoder of rt_texture.h against TexStorageBCn::Get (TextureStorageCPU.h:381-541), through whole frames"""
+    from ray_amd import api, scenes
+    monkeypatch.setenv("RAY_HIP_DECODE_BC", decode_at_export)
+    w, h, spp = 64, 64, 4
+    r, s = O.render_ref(scenes.cornell_block_textures, w, h, spp)
+    blob = O.export_scene(s)
+    ctx = O.hostsim_context(w, h, blob)
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
+    if decode_at_export == "0":  # blocks are a quarter (BC1, BC4) / half... of one byte per texel and channel: 8 or 16 bytes per 16 texels
+        monkeypatch.setenv("RAY_HIP_DECODE_BC", "1")
+        assert len(blob) < len(O.export_scene(s))
 
 
 @pytest.mark.parametrize("name", SCENES)
