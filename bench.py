@@ -54,6 +54,10 @@ WORKLOADS = {
     # the same geometry with a texture set (11 mip-mapped 1024^2 maps: base colour on every large surface, a normal map and
     # roughness maps): not a BASELINE.json config -- the material -> texture gathers a textured asset set adds to the shade stage
     "bistro_tex": dict(kind="atrium", detail=4.3, textured=True, w=1920, h=1080, label="synthetic Bistro-class atrium, textured"),
+    # ... and with settings_t::use_tex_compression (the reference's default): the maps live in the BC3 / BC4 / BC5 storages and
+    # stay compressed on the device (RAYHIP_TEX_RAW_BC; RAY_HIP_DECODE_BC=1 expands them at export instead)
+    "bistro_texc": dict(kind="atrium", detail=4.3, textured=True, compressed=True, w=1920, h=1080,
+                        label="synthetic Bistro-class atrium, textured, block-compressed"),
     "cornell": dict(kind="cornell_basic", w=1024, h=1024, label="samples/00_basic Cornell box"),
     "principled": dict(kind="cornell_principled", w=2048, h=2048, label="samples/03_principled Cornell box"),
 }
@@ -64,7 +68,7 @@ TILE = 64
 def build_scene(scene, wl):
     from ray_amd import scenes
     if wl["kind"] == "atrium":
-        return scenes.atrium(scene, wl["detail"], textured=wl.get("textured", False))
+        return scenes.atrium(scene, wl["detail"], textured=wl.get("textured", False), compress=wl.get("compressed", False))
     scenes.SCENES[wl["kind"]](scene)
     return scene.triangle_count()
 
@@ -74,11 +78,11 @@ def get_scene_blob(name, wl, rank, world, barrier):
     from ray_amd import api
     cache_dir = os.environ.get("RAY_AMD_CACHE", "/tmp/ray_amd_cache")
     os.makedirs(cache_dir, exist_ok=True)
-    path = os.path.join(cache_dir, f"{name}_{wl.get('detail', 0)}.rayscene")
+    path = os.path.join(cache_dir, f"{name}_{wl.get('detail', 0)}{'_decoded' if os.environ.get('RAY_HIP_DECODE_BC') == '1' else ''}.rayscene")
     meta = path + ".json"
     t0 = time.time()
     if rank == 0 and not (os.path.exists(path) and os.path.exists(meta)):
-        s = api.CreateSceneHIP()
+        s = api.CreateSceneHIP(use_tex_compression=wl.get("compressed", False))
         ntris = build_scene(s, wl)
         blob = api.export_scene_blob(s)
         with open(path + ".tmp", "wb") as f:
@@ -224,6 +228,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
+    # torch initialises its device context lazily, on the first call that needs it -- which would be the
+    # torch.cuda.synchronize() that opens the timed region: the first timed pass of a process then started 15-30 ms late
+    # (measured: 350 instead of 478 Msamples/s at --steps 20, repeats of the same region in the same process unaffected).
+    # Do it here, with everything else that is set-up.
+    torch.zeros(1, device=f"cuda:{local_rank}").add_(1.0)
+    torch.cuda.synchronize()
     dist = None
     # RAY_AMD_FORCE_DIST=1: run the N > 1 code path (process group, frame reduce over RCCL, re-tonemap) with one rank
     force_dist = world == 1 and os.environ.get("RAY_AMD_FORCE_DIST") == "1"
@@ -249,7 +259,6 @@ def main():
     ctx.upload_static(api.pmj_table())
     ctx.resize(W, H)
     cam = ctx.upload_scene_blob(blob)
-    del blob
     ctx.set_shard(TILE, world, rank)
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") if dist is not None else None
 
@@ -275,6 +284,16 @@ def main():
     ctx.trav_timing(reset=True)
     ctx.stage_times(reset=True)
 
+    # Host memory the HIP runtime pinned for a copy (the scene blob, the PMJ table, a read-back frame) must not be unmapped
+    # while the GPU works: the kernel driver answers the unmap by stopping and restarting this process's GPU queues, and the
+    # kernels running at that moment stand still for 15-30 ms (measured: 350 instead of 478 Msamples/s at --steps 20 whenever
+    # a large numpy array happened to be freed around the start of the timed region).  So: the frame buffer of the read-back
+    # exists -- and is touched -- before the region, the blob stays referenced until after it, and the garbage collector
+    # rests.  (A C++ host has the same rule: allocate the read-back buffer once.)
+    import gc
+    host_frame = np.zeros((H, W, 4), dtype=np.float32) if dist is None else None
+    gc.collect()
+    gc.disable()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -283,11 +302,13 @@ def main():
                             flags=hip.FLAG_TIME_STAGES, tile=TILE, batch=batch)
     it += K
     if dist is None:  # what the reduce is at N > 1: the finished frame leaves the GPU once per image
-        host_frame = ctx.readback(hip.BUF_RAW)
+        ctx.readback(hip.BUF_RAW, out=host_frame)
     ctx.sync()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    del blob
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -295,6 +316,23 @@ def main():
 
     (k2_ms, k2_launches), (k3_ms, k3_launches) = ctx.trav_timing(reset=True)
     stages = ctx.stage_times(reset=True)
+    for rep in range(int(os.environ.get("RAY_AMD_BENCH_REPEAT", "0"))):  # diagnostics: the same warm-up + timed sequence again
+        if Wm > 0:
+            ctx.render_batch(it + 1, min(batch, Wm))
+            it += min(batch, Wm)
+        ctx.sync()
+        ctx.stage_times(reset=True)
+        torch.cuda.synchronize()
+        t_rep = time.perf_counter()
+        multigpu.render_sharded(ctx, range(it + 1, it + 1 + K), rank, world, dist=None, frame=None, flags=hip.FLAG_TIME_STAGES, tile=TILE, batch=batch)
+        it += K
+        ctx.readback(hip.BUF_RAW, out=host_frame)
+        ctx.sync()
+        st_rep = ctx.stage_times(reset=True)
+        ctx.trav_timing(reset=True)
+        print(f"repeat {rep}: {W * H * K / (time.perf_counter() - t_rep) / 1e6:.1f} Msamples/s, ray gen {st_rep['primary_ray_gen'] / K:.0f} us/step, "
+              f"primary trace {st_rep['primary_trace'] / K:.0f} us/step (first timed region of this process: {W * H * K / dt / 1e6:.1f}, "
+              f"ray gen {stages['primary_ray_gen'] / K:.0f}, primary trace {stages['primary_trace'] / K:.0f})", file=sys.stderr)
 
     # algorithmic bytes of the traversal kernels: instrumented variants on the next iterations of the same workload --
     # first the product kernels with counters (their own bytes), then the reference's BVH2 walk on the same rays

@@ -404,6 +404,8 @@ def _hip_lib():
         vp = C.c_void_p
         lib.ray_hip_create_scene.restype = vp
         lib.ray_hip_create_scene.argtypes = [C.c_int]
+        lib.ray_hip_create_scene_ex.restype = vp
+        lib.ray_hip_create_scene_ex.argtypes = [C.c_int, C.c_int]
         lib.ray_hip_export_scene.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
         lib.ray_hip_free.argtypes = [vp]
         lib.ray_hip_free.restype = None
@@ -413,10 +415,11 @@ def _hip_lib():
     return lib
 
 
-def CreateSceneHIP(verbose: bool = False) -> SceneBase:
-    """A SceneHIP without a renderer: scene construction (BVH, light tree) is host work and needs no GPU."""
+def CreateSceneHIP(verbose: bool = False, use_tex_compression: bool = False) -> SceneBase:
+    """A SceneHIP without a renderer: scene construction (BVH, light tree) is host work and needs no GPU.
+    use_tex_compression: settings_t::use_tex_compression for the textures added without force_no_compression."""
     lib = _hip_lib()
-    return SceneBase(lib, lib.ray_hip_create_scene(int(verbose)))
+    return SceneBase(lib, lib.ray_hip_create_scene_ex(int(verbose), int(use_tex_compression)))
 
 
 def export_scene_blob(scene: SceneBase) -> bytes:

@@ -1189,13 +1189,22 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const float mix_factor = 1.0f / float(iteration);
 
+    const bool trace_launch = getenv("RAYHIP_TRACE_LAUNCH") != nullptr; // (diagnostics: host time of the first calls of a pass)
+    const auto h0 = std::chrono::steady_clock::now();
     if (tm.mark(ST_GEN, -1)) {
         return 1;
     }
+    const auto h1 = std::chrono::steady_clock::now();
     k_raygen<<<grid_for(c, nslots, 256), 256, 0, s>>>(rg, c->sc.pmj, c->filter_table.as<float>(), c->px.required_samples,
                                                       c->rays[0], c->hits, c->ray_queue(0, nslots, stripes), layers, tiling);
+    const auto h2 = std::chrono::steady_clock::now();
     if (tm.mark(ST_PTRACE, 0)) {
         return 1;
+    }
+    if (trace_launch) {
+        const auto h3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "rayhip pass start (host): event record %.0f us, k_raygen launch %.0f us, event record %.0f us\n", us(h0, h1), us(h1, h2), us(h2, h3));
     }
     if (c->sc.tlas_root != 0xffffffffu) {
         launch_closest(c->rays[0], c->ray_queue(0, nslots, stripes), 0);

@@ -248,8 +248,13 @@ class Context:
         """allocate the buffers passes of `count` iterations need (under the current shard) ahead of time"""
         self.L.check(self.L.fn("reserve_batch")(self._ctx, count))
 
-    def readback(self, which: int = BUF_RAW) -> np.ndarray:
-        out = np.empty((self.h, self.w, 4), dtype=np.float32)
+    def readback(self, which: int = BUF_RAW, out: np.ndarray = None) -> np.ndarray:
+        """`out`: a [h, w, 4] float32 array to fill (a caller that reads frames repeatedly should reuse one: the HIP runtime
+        pins the destination pages for the copy, and unmapping pinned pages -- numpy freeing a large array -- makes the kernel
+        driver stop and restart the process's GPU queues, 15-30 ms during which running kernels stand still)"""
+        if out is None:
+            out = np.empty((self.h, self.w, 4), dtype=np.float32)
+        assert out.shape == (self.h, self.w, 4) and out.dtype == np.float32 and out.flags["C_CONTIGUOUS"]
         self.L.check(self.L.fn("readback")(self._ctx, which, out.ctypes.data, self.w))
         return out
 

@@ -386,7 +386,7 @@ class Renderer final : public RendererBase {
 
 RendererBase *CreateRenderer(const settings_t &s, ILog *log) { return new Renderer(s, log); }
 
-SceneBase *CreateScene(ILog *log) { return new Scene(log, false); }
+SceneBase *CreateScene(ILog *log, const bool use_tex_compression) { return new Scene(log, use_tex_compression); }
 
 std::vector<uint8_t> ExportSceneBlob(const SceneBase &scene) {
     const auto *s = dynamic_cast<const Cpu::Scene *>(&scene);

@@ -26,7 +26,7 @@ RendererBase *CreateRenderer(const settings_t &s, ILog *log);
 
 // SceneHIP without a renderer (scene construction is host-only work) and its flat serialisation
 // (ray_amd/csrc/scene_blob.h): what rayhip_scene_upload_blob consumes.
-SceneBase *CreateScene(ILog *log);
+SceneBase *CreateScene(ILog *log, bool use_tex_compression = false);
 std::vector<uint8_t> ExportSceneBlob(const SceneBase &scene);
 } // namespace Hip
 } // namespace Ray

@@ -482,12 +482,13 @@ uint32_t ray_scene_triangle_count(ray_scene *s) { return s->s->triangle_count();
 uint32_t ray_scene_node_count(ray_scene *s) { return s->s->node_count(); }
 
 #ifdef RAY_CAPI_WITH_HIP
-ray_scene *ray_hip_create_scene(int verbose) {
+ray_scene *ray_hip_create_scene_ex(int verbose, int use_tex_compression) {
     static CollectLog quiet(false), loud(true);
     auto out = std::make_unique<ray_scene>();
-    out->s.reset(Ray::Hip::CreateScene(verbose ? &loud : &quiet));
+    out->s.reset(Ray::Hip::CreateScene(verbose ? &loud : &quiet, use_tex_compression != 0));
     return out.release();
 }
+ray_scene *ray_hip_create_scene(int verbose) { return ray_hip_create_scene_ex(verbose, 0); }
 int ray_hip_export_scene(ray_scene *s, void **out_blob, uint64_t *out_size) {
     try {
         const std::vector<uint8_t> blob = Ray::Hip::ExportSceneBlob(*s->s);

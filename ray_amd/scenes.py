@@ -593,7 +593,7 @@ def _procedural_texture(res: int, seed: int, kind: str) -> np.ndarray:
     return out
 
 
-def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = False, tex_res: int = 1024):
+def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = False, tex_res: int = 1024, compress: bool = False):
     """Synthetic atrium, 30 x 12 x 18 (SURVEY.md section 8d input 3/4).  Triangle count ~ 250k * detail.
     textured=True: every large surface gets its own mip-mapped base-colour map, the stone also a normal map, the floor a
     roughness map (11 maps of tex_res^2: the material -> texture gathers a textured asset set causes in the shade stage)."""
@@ -608,7 +608,12 @@ def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = Fals
                                                      ("cloth_b", "albedo", True, False), ("metal", "albedo", True, False),
                                                      ("metal_r", "rough", False, False), ("glossy", "albedo", True, False),
                                                      ("stone_r", "rough", False, False))):
-            tex[name] = scene.AddTexture(_procedural_texture(tex_res, 3 + k, kind), is_srgb=srgb, is_normalmap=nm, generate_mipmaps=True)
+            # compress: leave the choice to settings_t::use_tex_compression (BC3 / BC4 / BC5 storages when the scene has it on)
+            # (RGB888 / R8 inputs: with compression on they land in the BC3 (YCoCg) / BC5 / BC4 storages, SceneCPU.cpp:90-160;
+            # an RGBA8888 colour map is never compressed)
+            img = _procedural_texture(tex_res, 3 + k, kind)
+            img, fmt = (img[..., :1], eTextureFormat.R8) if kind == "rough" else (img[..., :3], eTextureFormat.RGB888)
+            tex[name] = scene.AddTexture(img, fmt=fmt, is_srgb=srgb, is_normalmap=nm, generate_mipmaps=True, force_no_compression=not compress)
     t = lambda name: tex.get(name)  # noqa: E731
     stone = scene.AddMaterial(PrincipledMat(base_color=(0.62, 0.58, 0.50), roughness=0.7, specular=0.3, base_texture=t("stone"),
                                             normal_map=t("stone_n"), roughness_texture=t("stone_r")))
