@@ -264,6 +264,16 @@ def main():
 
     batch = int(os.environ.get("RAY_AMD_BATCH", "0")) or multigpu.batch_size(W * H // world, ctx.max_batch(), K)
     ctx.reserve_batch(batch)  # (the shard is set: a rank's buffers are sized for its share of the frame)
+    # Host memory the HIP runtime pinned for a copy (the scene blob, the PMJ table, a read-back frame) must not be unmapped
+    # while the GPU works: the kernel driver answers the unmap by stopping and restarting this process's GPU queues, and the
+    # kernels running at that moment stand still for 15-30 ms (measured: 350 instead of 478 Msamples/s at --steps 20 whenever
+    # a large numpy array happened to be freed around the start of the timed region).  So: the frame buffer of the read-back
+    # exists -- and is touched -- before the first pass, the blob stays referenced until after it, and the garbage collector
+    # rests.  (A C++ host has the same rule: allocate the read-back buffer once.)
+    import gc
+    host_frame = np.zeros((H, W, 4), dtype=np.float32) if dist is None else None
+    gc.collect()
+    gc.disable()
     it = 0
     # set-up, not warm-up: one pass of exactly the shape and flags of the timed passes, so that nothing in the timed region
     # is the first of its kind in this process (measured: the first timed pass of the first process on a fresh box spent
@@ -284,16 +294,6 @@ def main():
     ctx.trav_timing(reset=True)
     ctx.stage_times(reset=True)
 
-    # Host memory the HIP runtime pinned for a copy (the scene blob, the PMJ table, a read-back frame) must not be unmapped
-    # while the GPU works: the kernel driver answers the unmap by stopping and restarting this process's GPU queues, and the
-    # kernels running at that moment stand still for 15-30 ms (measured: 350 instead of 478 Msamples/s at --steps 20 whenever
-    # a large numpy array happened to be freed around the start of the timed region).  So: the frame buffer of the read-back
-    # exists -- and is touched -- before the region, the blob stays referenced until after it, and the garbage collector
-    # rests.  (A C++ host has the same rule: allocate the read-back buffer once.)
-    import gc
-    host_frame = np.zeros((H, W, 4), dtype=np.float32) if dist is None else None
-    gc.collect()
-    gc.disable()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
