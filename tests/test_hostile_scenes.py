@@ -1,0 +1,136 @@
+"""A scene that does not hold together must be refused at the boundary, with a message, before any kernel follows an index
+out of its array (ray_amd/csrc/scene_blob.h: section bounds, alignment, element sizes; ray_amd/csrc/scene_validate.h: every
+index a kernel dereferences without a bound of its own, by reachability from the top-level tree).  The checks are shared
+source between librayhip and the host build, so they are exercised here without a GPU."""
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import util
+from ray_amd import hip
+
+pytestmark = pytest.mark.skipif(not O.have_hostsim(), reason="tests/hostsim not built")
+
+HEADER, SECTION = 16, 40  # scene_blob.h: Header {magic[8], count, pad}, Section {name[24], offset u64, size u64}
+
+
+def sections(blob: bytes) -> dict:
+    count = struct.unpack_from("<I", blob, 8)[0]
+    out = {}
+    for i in range(count):
+        name, off, size = struct.unpack_from("<24sQQ", blob, HEADER + i * SECTION)
+        out[name.rstrip(b"\0").decode()] = (i, off, size)
+    return out
+
+
+def upload(blob: bytes):
+    ctx = hip.Context(0, hip.Library(O.HOSTSIM_LIB, prefix="hostsim_"))
+    ctx.upload_static(util.pmj())
+    ctx.resize(32, 32)
+    ctx.upload_scene_blob(blob)
+    return ctx
+
+
+def patched(blob: bytes, section: str, byte_offset: int, fmt: str, value) -> bytes:
+    _, off, size = sections(blob)[section]
+    assert byte_offset + struct.calcsize(fmt) <= size
+    b = bytearray(blob)
+    struct.pack_into(fmt, b, off + byte_offset, value)
+    return bytes(b)
+
+
+def first_leaf_entry(blob: bytes) -> int:
+    """index into tris[] / tri_indices[] of a triangle entry that a bottom-level leaf reaches (the arrays are sparse pools)"""
+    _, off, size = sections(blob)["nodes"]
+    nodes = np.frombuffer(blob, dtype=np.uint32, count=size // 4, offset=off).reshape(-1, 16)
+    _, moff, msize = sections(blob)["mesh_instances"]
+    node_index = struct.unpack_from("<I", blob, moff + 4)[0]
+    stack = [int(node_index)]
+    while stack:
+        w = stack.pop()
+        if w & (7 << 29):
+            return w & ~(7 << 29)
+        stack += [int(nodes[w, 12]), int(nodes[w, 13])]
+    raise AssertionError("no leaf")
+
+
+def test_the_untouched_scene_uploads():
+    upload(util.golden_scene("cornell_lights")).render(1)
+
+
+@pytest.mark.parametrize("what", ["tri_indices", "vtx_indices", "node_link", "leaf_range", "li_indices", "light_tree_link", "material",
+                                  "instance_root", "tlas_root", "env_light"])
+def test_an_index_out_of_its_array_is_refused(what):
+    blob = util.golden_scene("cornell_lights")
+    s = sections(blob)
+    if what == "tri_indices":
+        bad = patched(blob, "tri_indices", 4 * first_leaf_entry(blob), "<I", 0x0fffffff)
+    elif what == "vtx_indices":
+        _, off, _ = s["tri_indices"]
+        tri = struct.unpack_from("<I", blob, off + 4 * first_leaf_entry(blob))[0]
+        bad = patched(blob, "vtx_indices", 12 * tri, "<I", 0x0fffffff)
+    elif what == "node_link":
+        _, moff, _ = s["mesh_instances"]
+        root = struct.unpack_from("<I", blob, moff + 4)[0]
+        bad = patched(blob, "nodes", 64 * root + 48, "<I", 0x00ffffff)  # left_child of a bottom-level root: far outside
+    elif what == "leaf_range":
+        _, moff, _ = s["mesh_instances"]
+        root = struct.unpack_from("<I", blob, moff + 4)[0]
+        bad = patched(blob, "nodes", 64 * root + 48, "<I", (7 << 29) | 0x0ffffff0)  # a leaf of 8 entries beyond tris[]
+    elif what == "li_indices":
+        bad = patched(blob, "li_indices", 0, "<I", 0x00ffffff)
+    elif what == "light_tree_link":
+        bad = patched(blob, "light_cwnodes", 80, "<I", 0x00ffffff)  # child[0] of the root (after two boxes and 48 quantised bytes): no such node
+    elif what == "material":
+        _, off, _ = s["tri_indices"]
+        tri = struct.unpack_from("<I", blob, off + 4 * first_leaf_entry(blob))[0]
+        bad = patched(blob, "tri_materials", 4 * tri, "<H", 0x3fff)  # front material index 16383
+    elif what == "instance_root":
+        bad = patched(blob, "mesh_instances", 4, "<I", 0x00ffffff)
+    elif what == "tlas_root":
+        bad = patched(blob, "scalars", 32 + 64, "<I", 0x00ffffff)  # Scalars: tex_table[8], environment (64 B), tlas_root
+    else:
+        bad = patched(blob, "scalars", 32 + 40, "<I", 0x00ffffff)  # environment.light_index
+    with pytest.raises(RuntimeError) as e:
+        upload(bad)
+    print(what, "->", e.value)
+    assert len(str(e.value)) > 20
+
+
+def test_malformed_containers_are_refused():
+    blob = util.golden_scene("cornell_basic")
+    s = sections(blob)
+    cases = {}
+    i, off, size = s["tris"]
+    b = bytearray(blob)
+    struct.pack_into("<QQ", b, HEADER + i * SECTION + 24, 2 ** 64 - 8, 16)  # offset + size wraps around
+    cases["wrapping section"] = bytes(b)
+    b = bytearray(blob)
+    struct.pack_into("<QQ", b, HEADER + i * SECTION + 24, off + 4, size - 16)  # not 16-byte aligned
+    cases["misaligned section"] = bytes(b)
+    b = bytearray(blob)
+    struct.pack_into("<QQ", b, HEADER + i * SECTION + 24, off, size - 8)  # not a whole number of 48-byte records
+    cases["ragged section"] = bytes(b)
+    b = bytearray(blob)
+    struct.pack_into("<QQ", b, HEADER + i * SECTION + 24, off, len(blob))  # runs past the end
+    cases["section past the end"] = bytes(b)
+    cases["truncated"] = blob[:HEADER + 3 * SECTION]
+    cases["bad magic"] = b"NOTASCENE" + blob[9:]
+    b = bytearray(blob)
+    struct.pack_into("<I", b, 8, 0x7fffffff)  # section count
+    cases["absurd section count"] = bytes(b)
+    for name, bad in cases.items():
+        with pytest.raises(RuntimeError) as e:
+            upload(bad)
+        print(name, "->", e.value)
+
+
+def test_a_texture_outside_the_texel_pool_is_refused():
+    blob = util.golden_scene("cornell_principled")
+    _, off, size = sections(blob)["textures"]
+    assert size >= 144  # rayhip_texture: width[12], height[12], offset[12]
+    bad = patched(blob, "textures", 96, "<I", 0x7ffffff0)  # offset[0] of the first texture
+    with pytest.raises(RuntimeError):
+        upload(bad)
