@@ -92,7 +92,8 @@ struct rayhip_ctx {
     hipDeviceProp_t props = {};
     int grid_waves = 0; // resident-ish grid for the wave-per-block kernels
     bool small_scene = false; // BLAS nodes + triangles fit one XCD's L2: traversal kernels with the smaller register footprint
-    int refill_waves = 0; // exactly-resident grid of the persistent closest-hit kernel; 0 = kernel switched off
+    int refill_waves = 0; // largest grid of the persistent closest-hit kernel (blocks); 0 = kernel switched off
+    int refill_resident = 0; // ... and the number of its blocks the device holds at once
     int sort_key_mode = 0; // RAYHIP_SORT_KEY (tuning, rt_sort.h)
     int tune_primary_waves = 0, tune_shadow_waves = 0; // RAYHIP_PRIMARY_WAVES / RAYHIP_SHADOW_WAVES (tuning): register footprint of K2 (primary) / K3
     bool refill_secondary_only = false; // RAYHIP_REFILL=2: primary rays (coherent, every lane busy to the end) keep the plain kernel
@@ -447,7 +448,8 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
             if (const char *e = getenv("RAYHIP_REFILL_MULT")) {
                 refill_mult = std::max(1, std::min(64, atoi(e)));
             }
-            c->refill_waves = std::min(c->grid_waves, c->props.multiProcessorCount * per_cu_refill * refill_mult);
+            c->refill_resident = c->props.multiProcessorCount * per_cu_refill;
+            c->refill_waves = std::min(c->grid_waves, c->refill_resident * refill_mult);
             c->refill_secondary_only = mode == 2;
         }
     }
@@ -1167,7 +1169,11 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         } else if (count) {
             k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else if (c->sc.nodes4 && c->refill_waves && !(c->refill_secondary_only && !init_hits)) {
-            k_trace_closest_refill<<<std::min(gtrace, c->refill_waves), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
+            // blocks: enough to even out the end of the launch (16 per wave slot on a full-size pass), but never so many that a
+            // block gets fewer than ~8 chunks of 64 rays -- below that the kernel degenerates into the plain one with extra
+            // set-up per block (a rank of 8 at 20 spp: 5.2 M rays per pass; 16 blocks per slot 6.6 ms, 4: 5.97, plain 5.98)
+            const int want = int(std::min<size_t>(size_t(c->refill_waves), std::max<size_t>(size_t(c->refill_resident), nslots / WAVE / 8)));
+            k_trace_closest_refill<<<std::min(gtrace, want), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
         } else if (c->sc.nodes4 && c->tune_primary_waves == 4) { // (tuning)
             k_trace_closest<false, true, 4><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
         } else if (c->sc.nodes4 && (c->small_scene || c->tune_primary_waves == 5)) {

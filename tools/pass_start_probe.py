@@ -19,7 +19,7 @@ ctx.resize(wl["w"], wl["h"])
 ctx.upload_scene_blob(blob)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 if os.environ.get("PROBE_SHARD"):
-    ctx.set_shard(bench.TILE, 1, 0)
+    ctx.set_shard(bench.TILE, int(os.environ["PROBE_SHARD"]), 0)
 ctx.reserve_batch(B)
 it = 0
 use_torch = len(sys.argv) > 3 and sys.argv[3] == "torch"
@@ -51,3 +51,4 @@ for k in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     slow += st["primary_ray_gen"] / 1e3 > 2.0 * n / 20.0
     print(f"pass {k:2d} ({n} it): primary trace {st['primary_trace'] / 1e3:6.2f} ms  submit {1e3 * (t1 - t0):7.2f} ms  total {1e3 * (t2 - t0):7.2f} ms  ray gen stage {st['primary_ray_gen'] / 1e3:7.2f} ms", file=sys.stderr, flush=True)
 print(f"passes with a slow start: {slow}", file=sys.stderr)
+print("last pass, ms per stage:", {k: round(v / 1e3, 2) for k, v in st.items() if v}, file=sys.stderr)
