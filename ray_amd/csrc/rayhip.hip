@@ -25,6 +25,7 @@
 #include "lbvh.hip.h"
 #include "scene_blob.h"
 #include "scene_rebuild.h"
+#include "scene_update.h"
 #include "scene_validate.h"
 #include "sort.h"
 
@@ -118,10 +119,7 @@ struct rayhip_ctx {
     // what rayhip_scene_update_instances needs of the last full upload: per mesh (key: mesh_instance_t::mesh_index) the roots
     // of its bottom-level trees as uploaded; node slots reserved behind the uploaded nodes for top-level trees built later
     // on the device
-    struct MeshRef {
-        uint32_t node_index, root4;
-    };
-    std::unordered_map<uint32_t, MeshRef> mesh_refs;
+    rayhip_update::MeshRefs mesh_refs;
     uint32_t nodes_used = 0, nodes_reserved = 0;
     bool have_wide = false;
     uint32_t tex_table[8] = {}, textures_count = 0, tex_flags = 0;
@@ -809,16 +807,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         const rayhip_bvh2_node *n2 = lay.applied ? lay.nodes.data() : d->nodes;
         const uint32_t n2_count = lay.applied ? uint32_t(lay.nodes.size()) : d->nodes_count;
         const rayhip_mesh_instance *mis = lay.applied ? lay.mesh_instances.data() : d->mesh_instances;
-        c->mesh_refs.clear();
-        std::vector<std::pair<uint32_t, uint32_t>> top;
-        if (tlas_root != 0xffffffffu && rayhip_rebuild::collect_leaf_ranges(n2, n2_count, tlas_root, top)) {
-            for (const auto &leaf : top) {
-                if (leaf.first < d->mesh_instances_count && mis[leaf.first].node_index < n2_count) {
-                    c->mesh_refs[mis[leaf.first].mesh_index] = rayhip_ctx::MeshRef{
-                        mis[leaf.first].node_index, have_wide ? blas_root4[leaf.first] : 0u};
-                }
-            }
-        }
+        rayhip_update::collect_mesh_refs(n2, n2_count, mis, d->mesh_instances_count, tlas_root, have_wide ? blas_root4.data() : nullptr, c->mesh_refs);
     }
     UPLOAD_TRACE("bvh uploaded")
     UP(tri_materials)
@@ -908,46 +897,18 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
             }
         }
     }
-    // Live instances: the leaves of the host's top level, WITH the boxes the host gave them.  (Not recomputed from the
-    // transforms: after a RemoveMeshInstance the reference numbers its top-level leaves by the position of an instance among
-    // the live ones, not by its slot (SceneCPU.cpp:945-951 walks the sparse array, :1000-1008 writes that position into the
-    // leaf), so a leaf may name another slot than the one its box was made from.  The reference's renderers follow the leaf
-    // as written; so do we -- taking slot and box as a pair from the host tree keeps every frame identical to theirs.)
-    std::vector<uint32_t> live;
-    std::vector<rayhip_lbvh::Box> boxes;
-    if (d->tlas_root != 0xffffffffu) {
-        std::vector<std::pair<uint32_t, rayhip_lbvh::Box>> leaves;
-        if (!rayhip_rebuild::collect_leaf_boxes(*d, d->tlas_root, leaves)) {
-            return fail("top-level tree is malformed");
-        }
-        std::sort(leaves.begin(), leaves.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
-        for (const auto &l : leaves) {
-            if (l.first >= d->mesh_instances_count) {
-                return fail("top-level leaf names instance %u of %u", l.first, d->mesh_instances_count);
-            }
-            const bool real = l.second.lo[0] <= l.second.hi[0] && l.second.lo[1] <= l.second.hi[1] && l.second.lo[2] <= l.second.hi[2];
-            if (!live.empty() && live.back() == l.first) {
-                if (real) {
-                    rayhip_lbvh::grow(boxes.back(), l.second); // (a lone instance is stored as both children of the root)
-                }
-            } else {
-                live.push_back(l.first);
-                boxes.push_back(real ? l.second : rayhip_lbvh::empty_box());
-            }
+    rayhip_update::Plan up;
+    {
+        std::string why;
+        const int rc = rayhip_update::plan(*d, c->mesh_refs, up, why);
+        if (rc) {
+            (void)fail("%s", why.c_str());
+            return rc;
         }
     }
-    // the instance array as the kernels follow it: tree roots of the meshes as laid out on the device
-    std::vector<rayhip_mesh_instance> mis(d->mesh_instances, d->mesh_instances + d->mesh_instances_count);
-    std::vector<uint32_t> root4(d->mesh_instances_count, 0);
-    for (const uint32_t mi : live) {
-        const auto it = c->mesh_refs.find(mis[mi].mesh_index);
-        if (it == c->mesh_refs.end()) {
-            (void)fail("instance %u uses mesh %u, which is not on the device", mi, mis[mi].mesh_index);
-            return 2;
-        }
-        mis[mi].node_index = it->second.node_index;
-        root4[mi] = it->second.root4;
-    }
+    const std::vector<uint32_t> &live = up.live;
+    std::vector<rayhip_mesh_instance> &mis = up.instances;
+    std::vector<uint32_t> &root4 = up.root4;
     {
         rayhip_scene_desc lights_only = *d;
         lights_only.mesh_instances = mis.data();
@@ -960,9 +921,7 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
     rayhip_lbvh::Box root_box = rayhip_lbvh::empty_box();
     if (!live.empty()) {
         const std::vector<uint32_t> group(live.size(), 0);
-        rayhip_lbvh::Input ti;
-        ti.prim_box = boxes.data(), ti.prim_group = group.data(), ti.group_centroids = nullptr;
-        ti.n_prims = uint32_t(boxes.size()), ti.n_groups = 1, ti.leaf_max = 1, ti.leaf_is_primitive = true, ti.roots_are_nodes = true;
+        const rayhip_lbvh::Input ti = rayhip_update::top_level_input(up, group);
         rayhip_lbvh::Output tlas;
         std::string why;
         if (!rayhip_lbvh::build_device(c->stream, ti, tlas, why)) {
@@ -972,14 +931,8 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
             (void)fail("no room for a top-level tree of %zu nodes", tlas.nodes.size());
             return 2;
         }
-        constexpr uint32_t COUNT_BITS = 7u << 29, INDEX_BITS = ~COUNT_BITS;
         const uint32_t base = c->nodes_used;
-        for (rayhip_bvh2_node &n : tlas.nodes) {
-            for (uint32_t *link : {&n.left_child, &n.right_child}) {
-                *link = (*link & COUNT_BITS) == 0 ? *link + base : ((1u << 29) | live[*link & INDEX_BITS]);
-            }
-        }
-        tlas_root = base + tlas.group_root[0];
+        tlas_root = rayhip_update::relocate_top_level(tlas, up, base);
         root_box = tlas.bounds;
         UPLOAD_TRACE("top level built")
         // pending passes read the old tree: the caller flushed (RendererHIP) or synchronises through the stream order here

@@ -126,8 +126,8 @@ class Library:
         f("k_scrambled_rand").argtypes = [vp, vp, vp, vp, C.c_int, vp]
         f("k_shade").argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int), vp,
                                  C.POINTER(C.c_int)]
+        f("scene_update_instances_blob").argtypes = [vp, vp, C.c_size_t, C.POINTER(Camera)]
         if prefix == "rayhip_":
-            f("scene_update_instances_blob").argtypes = [vp, vp, C.c_size_t, C.POINTER(Camera)]
             f("readback_device").argtypes = [vp, C.c_int, vp, C.c_int]
             f("set_raw_device").argtypes = [vp, vp, C.c_int, C.POINTER(Camera)]
             f("export_shard_device").argtypes = [vp, C.c_int, vp]
