@@ -4,7 +4,7 @@
 //   K1  primary_ray_gen.comp.glsl            -> k_raygen
 //   K2  intersect_scene.comp.glsl            -> k_trace_closest<COUNT, WIDE> (the roofline kernel; product form WIDE: the
 //                                               4-wide quantised BLAS of rt_bvh4.h, majority-scheduled; COUNT: the
-//                                               reference's BVH2 with visit counters), k_trace_closest_refill (opt-in)
+//                                               reference's BVH2 with visit counters), k_trace_closest_refill (the secondary bounces)
 //   K3  intersect_scene_shadow.comp.glsl     -> k_trace_shadow
 //   K4  intersect_area_lights.comp.glsl      -> k_intersect_area_lights (+ k_shadow_blockers for the shadow-ray form)
 //   K5  shade.comp.glsl (PRIMARY/SECONDARY)  -> shade_kernels.hip: k_surface / k_light_pick / k_scatter / k_shade_emissive
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 #endif
 }
 
-// ---- K2, experimental form (opt-in: RAYHIP_REFILL=1): persistent wavefronts with ray refill ---------------------------
+// ---- K2, persistent form (the secondary bounces by default, rayhip.hip: RAYHIP_REFILL): wavefronts with ray refill ------------
 // With one ray per lane traced to completion (k_trace_closest above) a wavefront is as slow as its longest ray: measured
 // on the Bistro-class scene inside the majority-scheduled BLAS loop, 45 % of the lane slots belong to rays that are
 // already finished.  Here a wavefront is persistent and a lane that finishes its ray takes the next one from the queue
