@@ -343,21 +343,27 @@ def test_iteration_batching_is_bit_identical(gpu_lib, name):
 
 
 def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
-    """RAYHIP_REFILL=1: the persistent ray-refill form of the closest-hit kernel (kernels.hip.h) performs the same node
-    visits and triangle tests per ray, only interleaved differently between lanes -- hits and frames must be the same
-    bits, transparency rounds (cornell_principled), analytic lights (cornell_lights) and a TLAS with seven instances and
-    visibility masks (cornell_instances) included"""
+    """the persistent ray-refill form of the closest-hit kernel (kernels.hip.h) performs the same node visits and triangle
+    tests per ray, only interleaved differently between lanes -- hits and frames must be the same bits whether no bounce
+    (RAYHIP_REFILL=0), every bounce (1) or the secondary bounces (2, the default) go through it: transparency rounds
+    (cornell_principled), analytic lights (cornell_lights) and a TLAS with seven instances and visibility masks
+    (cornell_instances) included"""
     for name in ("cornell_principled", "cornell_lights", "cornell_instances"):
         g = util.golden_ref(name)
-        base = util.make_context(gpu_lib, name)
-        monkeypatch.setenv("RAYHIP_REFILL", "1")
-        ref = util.make_context(gpu_lib, name)
+        ctxs = {}
+        for mode in ("0", "1", "2"):
+            monkeypatch.setenv("RAYHIP_REFILL", mode)
+            ctxs[mode] = util.make_context(gpu_lib, name)
         monkeypatch.delenv("RAYHIP_REFILL")
-        _, h0, _ = base.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
-        _, h1, _ = ref.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
-        assert h0.tobytes() == h1.tobytes()
-        base.render_batch(1, 6), ref.render_batch(1, 6)
-        assert np.array_equal(base.readback(hip.BUF_RAW), ref.readback(hip.BUF_RAW))
+        ctxs["default"] = util.make_context(gpu_lib, name)
+        hits, frames = {}, {}
+        for mode, ctx in ctxs.items():
+            _, hits[mode], _ = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
+            ctx.render_batch(1, 6)
+            frames[mode] = ctx.readback(hip.BUF_RAW)
+        for mode in ("1", "2", "default"):
+            assert hits[mode].tobytes() == hits["0"].tobytes(), (name, mode)
+            assert np.array_equal(frames[mode], frames["0"]), (name, mode)
 
 
 def test_maximal_batch_and_row_limit_split(gpu_lib):
