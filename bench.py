@@ -26,7 +26,9 @@ events on the context stream during the timed region (RAYHIP_FLAG_TIME_STAGES, n
 all per launch:
   traffic      HBM bytes that actually moved: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE of this kernel, from a profiled run of
                THIS command line (profiles/r02/k2_traffic.json, keyed by workload / steps / iterations per pass; written by
-               tools/k2_traffic.py from the rocprofv3 output); null when this configuration was not profiled
+               tools/k2_traffic.py from the rocprofv3 output); for another pass size or N > 1 the profiled run of the same
+               workload with the nearest pass size, scaled by rays per launch (traffic_detail.exact = false says so); null
+               when the workload was never profiled
   achieved     = traffic / launch time when traffic is known (the north star's figure: "achieved HBM GB/s from rocprof
                against the chip's memory roofline"), else the kernel's own algorithmic rate; frac = achieved / 8 TB/s
   algorithmic  the kernel's OWN algorithmic bytes: 72+20+4 per ray + 64 per TLAS node + 64 per 4-wide node + 48 per
@@ -99,19 +101,31 @@ def get_scene_blob(name, wl, rank, world, barrier):
     return blob, info
 
 
-def measured_traffic(workload, steps, batch):
-    """HBM bytes per K2 launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 PMC passes of this very command line
-    (profiles/r02/k2_traffic.json, written by tools/k2_traffic.py); None when this configuration was not profiled"""
+def measured_traffic(workload, steps, batch, world=1):
+    """HBM bytes per K2 launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 PMC passes (profiles/r02/k2_traffic.json,
+    written by tools/k2_traffic.py).  Exact when this very command line was profiled (same workload, steps, iterations per
+    pass, one GPU); otherwise SCALED from the profiled run of the same workload with the nearest pass size -- K2's traffic
+    per launch is proportional to the rays of the launch, i.e. to iterations per pass / ranks (64 vs 20 iterations per pass:
+    0.5636 vs 0.5610 GB per iteration) -- and marked as such; None when the workload was never profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "r02", "k2_traffic.json")) as f:
             table = json.load(f)
-        for e in table.get("runs", []):
-            if e["workload"] == workload and e["steps"] == steps and e["iterations_per_pass"] == batch:
-                return {"bytes_per_launch": float(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]),
-                        "fetch_bytes_per_launch": float(e["fetch_bytes_per_launch"]),
-                        "write_bytes_per_launch": float(e["write_bytes_per_launch"]),
-                        "profiled_avg_launch_ms": e.get("avg_launch_ms"), "source": e.get("source")}
-    except (OSError, ValueError, KeyError):
+        runs = [e for e in table.get("runs", []) if e["workload"] == workload]
+        if not runs:
+            return None
+        exact = [e for e in runs if world == 1 and e["steps"] == steps and e["iterations_per_pass"] == batch]
+        e = exact[0] if exact else min(runs, key=lambda r: abs(r["iterations_per_pass"] - batch))
+        k = 1.0 if exact else (batch / e["iterations_per_pass"]) / world
+        out = {"bytes_per_launch": float(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]) * k,
+               "fetch_bytes_per_launch": float(e["fetch_bytes_per_launch"]) * k,
+               "write_bytes_per_launch": float(e["write_bytes_per_launch"]) * k,
+               "profiled_avg_launch_ms": e.get("avg_launch_ms") if exact else None, "source": e.get("source"),
+               "exact": bool(exact)}
+        if not exact:
+            out["scaled_by"] = k
+            out["scaled_from"] = {"steps": e["steps"], "iterations_per_pass": e["iterations_per_pass"], "n_gpus": 1}
+        return out
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
         pass
     return None
 
@@ -360,7 +374,7 @@ def main():
         launches = max(k2_launches, 1)
         k2_s = k2_ms / 1e3
         alg_gbs = (k2_bytes / 1e9) / k2_s if k2_s > 0 else 0.0          # the kernel's own algorithmic bytes per second
-        traffic = measured_traffic(args.workload, K, batch) if world == 1 else None
+        traffic = measured_traffic(args.workload, K, batch, world)
         hbm_gbs = (traffic["bytes_per_launch"] * launches / 1e9) / k2_s if (traffic and k2_s > 0) else None
         achieved = hbm_gbs if hbm_gbs is not None else alg_gbs
         out = {
@@ -384,9 +398,13 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "K2 closest-hit traversal: k_trace_closest_refill (secondary bounces) + k_trace_closest<false,true> (primary rays)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "achieved_is": ("HBM traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE of a profiled run of this command) / launch time"
+                "achieved_is": (("HBM traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE of a profiled run of this command) / launch time"
+                                 if traffic.get("exact") else
+                                 "HBM traffic scaled from the profiled run of this workload with the nearest pass size (traffic is proportional "
+                                 "to the rays of a launch) / launch time of rank 0")
                                 if hbm_gbs is not None else
-                                "the kernel's own algorithmic bytes / launch time (no PMC profile of this configuration is committed)"),
+                                "the kernel's own algorithmic bytes / launch time (no PMC profile of this workload is committed): an upper "
+                                "bound of the HBM rate, every visit counted as a miss"),
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
                 "traffic_detail": traffic,
                 "avg_launch_ms": k2_ms / launches, "launches": k2_launches,
