@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
     }
 #endif
     const uint32_t n_live_chunks = queue.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
@@ -379,8 +380,8 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
     Hit h = make_hit();
     float t_val = 0.0f;
     // wavefront state (uniform): the chunk being handed out, the next chunk index of this wavefront
-    uint32_t pool_slot = 0, pool_left = 0, next_chunk = blockIdx.x;
-    const uint32_t total_chunks = queue.live_chunks();
+    uint32_t pool_slot = 0, pool_left = 0;
+    ChunkWalk walk(queue.live_chunks());
 
     auto begin_round = [&]() { // IntersectScene loop head + walk prologue at TLAS level
         t_val = h.t;
@@ -489,10 +490,10 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                 }
                 if (pool_left == 0) {
                     int found = 0;
-                    while (next_chunk < total_chunks && !found) { // (uniform)
+                    uint32_t next_chunk;
+                    while (!found && walk.next(next_chunk)) { // (uniform)
                         uint32_t stripe, slot0, n_live;
                         found = __builtin_amdgcn_readfirstlane(int(queue.chunk(next_chunk, stripe, slot0, n_live)));
-                        next_chunk += gridDim.x;
                         if (found) {
                             pool_slot = uint32_t(__builtin_amdgcn_readfirstlane(int(slot0)));
                             pool_left = uint32_t(__builtin_amdgcn_readfirstlane(int(n_live)));
@@ -595,7 +596,8 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_shadow(const SceneView sc,
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t lane = threadIdx.x;
     const uint32_t n_live_chunks = queue.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
@@ -633,7 +635,8 @@ __global__ void __launch_bounds__(WAVE) k_intersect_area_lights(const SceneView 
                                                                const RayQueue queue) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_live_chunks = queue.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
@@ -657,7 +660,8 @@ __global__ void __launch_bounds__(WAVE) k_intersect_area_lights(const SceneView 
 __global__ void __launch_bounds__(WAVE) k_shadow_blockers(const SceneView sc, const ShadowSoA shadow, const RayQueue queue) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_live_chunks = queue.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;

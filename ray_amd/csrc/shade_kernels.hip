@@ -88,7 +88,8 @@ __global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const Sc
                                                                        const PixelBuffers px, const int img_w, const float mix_factor,
                                                                        const Layering layers) {
     const uint32_t n_live_chunks = in.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
         if (!in.chunk(c, stripe, slot0, n_live)) {
             continue;
@@ -149,7 +150,8 @@ __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick(const Sc
                                                                        const PointSoA points, const RayQueue queue, const Layering layers) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_live_chunks = queue.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;
@@ -169,7 +171,8 @@ __global__ void __launch_bounds__(WAVE, RT_SCATTER_MIN_WAVES) k_scatter(const Sc
                                                                        const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
                                                                        const PixelBuffers px, const int img_w, const Layering layers) {
     const uint32_t n_live_chunks = in.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
         if (!in.chunk(c, stripe, slot0, n_live)) {
             continue;
@@ -232,7 +235,8 @@ __global__ void __launch_bounds__(WAVE) k_shade_emissive(const SceneView sc, con
                                                         const int img_w) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_live_chunks = queue.live_chunks();
-    for (uint32_t c = blockIdx.x; c < n_live_chunks; c += gridDim.x) {
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
         if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
             continue;

@@ -76,6 +76,48 @@ struct RayQueue {
     }
 };
 
+// Which chunks a block takes.  Plain striding (c = blockIdx, += gridDim) hands consecutive chunks -- neighbouring 8x8 pixel
+// tiles at the primary level, their survivors later -- to consecutive blocks, and consecutive blocks sit on different XCDs
+// (block b runs on XCD b % 8: observed placement, MI355X_MICROARCH.md; used for speed only, any placement is correct), so
+// each of the eight L2s sees rays from everywhere.  With RT_XCD_CHUNKS=1 every sweep of gridDim chunks is cut into eight
+// contiguous parts and the blocks of one XCD take one part: an XCD's L2 then serves a compact piece of the frame (the
+// sub-trees, triangle rows and materials behind it) instead of an eighth of every piece.
+// MEASURED (MI355X, all traversal and shade kernels, bit-identical frames): no gain -- Bistro-class 64 spp 508.6 vs 507.9
+// Msamples/s, 20 spp 488.9 vs 485.6, Sponza-class 567.5 vs 561.6 (plain vs XCD-aware; profiles/r02/experiments/
+// variants_xcd.txt).  The per-XCD L2 hit rate is not what limits these kernels (the 256 MB last-level cache behind the
+// L2s holds the whole tree either way); the plain order stays the default.
+#ifndef RT_XCD_CHUNKS
+#define RT_XCD_CHUNKS 0
+#endif
+struct ChunkWalk {
+    uint32_t base, n, grid, x, local;
+    __device__ __forceinline__ explicit ChunkWalk(const uint32_t n_chunks) : base(0), n(n_chunks) {
+        const bool remap = RT_XCD_CHUNKS != 0 && gridDim.x >= 8u;
+        grid = remap ? (gridDim.x & ~7u) : gridDim.x; // (up to seven surplus blocks of a grid that is not a multiple of 8 idle)
+        x = remap ? (blockIdx.x & 7u) : 0u;
+        local = remap ? (blockIdx.x >> 3) : blockIdx.x;
+        if (remap && blockIdx.x >= grid) {
+            base = n;
+        }
+        parts = remap ? 8u : 1u;
+    }
+    uint32_t parts;
+    // the next chunk of this block (wave-uniform); false when there is none left
+    __device__ __forceinline__ bool next(uint32_t &c) {
+        while (base < n) {
+            const uint32_t width = min(grid, n - base), per = (width + parts - 1u) / parts;
+            const uint32_t off = x * per + local;
+            const bool mine = local < per && off < width;
+            c = base + off;
+            base += grid;
+            if (mine) {
+                return true;
+            }
+        }
+        return false;
+    }
+};
+
 // hits of importance-sampled emitters whose MIS weight is evaluated by k_shade_emissive
 struct DeferredSoA {
     float4 *a; // ray slot, tri_index, material index (bits), mix_weight
