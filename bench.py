@@ -58,6 +58,8 @@ WORKLOADS = {
     "bistro_tex": dict(kind="atrium", detail=4.3, textured=True, w=1920, h=1080, label="synthetic Bistro-class atrium, textured"),
     # ... and with settings_t::use_tex_compression (the reference's default): the maps live in the BC3 / BC4 / BC5 storages and
     # stay compressed on the device (RAYHIP_TEX_RAW_BC; RAY_HIP_DECODE_BC=1 expands them at export instead)
+    # tuning experiment only: every surface Principled (what does material-type divergence inside a wavefront cost?)
+    "bistro_1type": dict(kind="atrium", detail=4.3, one_material_type=True, w=1920, h=1080, label="synthetic Bistro-class atrium, one material type"),
     "bistro_texc": dict(kind="atrium", detail=4.3, textured=True, compressed=True, w=1920, h=1080,
                         label="synthetic Bistro-class atrium, textured, block-compressed"),
     "cornell": dict(kind="cornell_basic", w=1024, h=1024, label="samples/00_basic Cornell box"),
@@ -70,7 +72,8 @@ TILE = 64
 def build_scene(scene, wl):
     from ray_amd import scenes
     if wl["kind"] == "atrium":
-        return scenes.atrium(scene, wl["detail"], textured=wl.get("textured", False), compress=wl.get("compressed", False))
+        return scenes.atrium(scene, wl["detail"], textured=wl.get("textured", False), compress=wl.get("compressed", False),
+                             one_material_type=wl.get("one_material_type", False))
     scenes.SCENES[wl["kind"]](scene)
     return scene.triangle_count()
 

@@ -593,7 +593,8 @@ def _procedural_texture(res: int, seed: int, kind: str) -> np.ndarray:
     return out
 
 
-def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = False, tex_res: int = 1024, compress: bool = False):
+def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = False, tex_res: int = 1024, compress: bool = False,
+           one_material_type: bool = False):
     """Synthetic atrium, 30 x 12 x 18 (SURVEY.md section 8d input 3/4).  Triangle count ~ 250k * detail.
     textured=True: every large surface gets its own mip-mapped base-colour map, the stone also a normal map, the floor a
     roughness map (11 maps of tex_res^2: the material -> texture gathers a textured asset set causes in the shade stage)."""
@@ -625,6 +626,11 @@ def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = Fals
     metal = scene.AddMaterial(PrincipledMat(base_color=(0.90, 0.75, 0.40), metallic=1.0, roughness=0.25, base_texture=t("metal"),
                                             roughness_texture=t("metal_r")))
     glossy = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=(0.8, 0.8, 0.85), roughness=0.15, base_texture=t("glossy")))
+    if one_material_type:  # tuning experiment (how much does material-type divergence inside a wavefront cost?): Principled everywhere
+        cloth_r = scene.AddMaterial(PrincipledMat(base_color=(0.55, 0.08, 0.07), roughness=0.5, specular=0.0))
+        cloth_g = scene.AddMaterial(PrincipledMat(base_color=(0.10, 0.40, 0.12), roughness=0.5, specular=0.0))
+        cloth_b = scene.AddMaterial(PrincipledMat(base_color=(0.10, 0.15, 0.50), roughness=0.5, specular=0.0))
+        glossy = scene.AddMaterial(PrincipledMat(base_color=(0.8, 0.8, 0.85), metallic=1.0, roughness=0.15))
     emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=18.0, base_color=(1.0, 0.95, 0.85),
                                          importance_sample=True))
     X, Y, Z = 30.0, 12.0, 18.0
