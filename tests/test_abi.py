@@ -4,6 +4,7 @@ no CPU path to fall back on)."""
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -61,3 +62,21 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert r.returncode != 0
     assert r.stdout.strip() == ""
     assert "needs a GPU" in r.stderr
+
+
+def test_bench_roofline_traffic_lookup():
+    """roofline.traffic comes from the committed rocprofv3 counter runs: exact for the profiled command lines, scaled by rays
+    per launch for other pass sizes / rank counts of a profiled workload, absent for a workload that was never profiled"""
+    sys.path.insert(0, ROOT)
+    import bench
+    exact = bench.measured_traffic("bistro", 20, 20, 1)
+    assert exact and exact["exact"] and exact["profiled_avg_launch_ms"] > 0
+    assert exact["bytes_per_launch"] == exact["fetch_bytes_per_launch"] + exact["write_bytes_per_launch"]
+    # the north star's figure can be recomputed from the file: HBM bytes / launch time / 8 TB/s, a fraction
+    frac = exact["bytes_per_launch"] / (exact["profiled_avg_launch_ms"] * 1e-3) / 8e12
+    assert 0.05 < frac < 1.0
+    big = bench.measured_traffic("bistro", 480, 120, 1)
+    assert big and not big["exact"] and abs(big["scaled_by"] - 120 / 64) < 1e-9 and big["scaled_from"]["iterations_per_pass"] == 64
+    rank = bench.measured_traffic("bistro", 20, 20, 8)
+    assert rank and not rank["exact"] and abs(rank["bytes_per_launch"] * 8 - exact["bytes_per_launch"]) < 1.0
+    assert bench.measured_traffic("no_such_workload", 20, 20, 1) is None
