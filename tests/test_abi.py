@@ -80,3 +80,28 @@ def test_bench_roofline_traffic_lookup():
     rank = bench.measured_traffic("bistro", 20, 20, 8)
     assert rank and not rank["exact"] and abs(rank["bytes_per_launch"] * 8 - exact["bytes_per_launch"]) < 1.0
     assert bench.measured_traffic("no_such_workload", 20, 20, 1) is None
+
+
+def build_c_host(tmp_path):
+    """examples/c_abi_render.c compiled as C99 against include/rayhip.h and linked with the product library"""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "c_abi_render")
+    build_dir = os.path.dirname(hip.RAYHIP_LIB)
+    cmd = ["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200112L", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_abi_render.c"), "-L", build_dir, "-lrayhip", f"-Wl,-rpath,{build_dir}", "-lm", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_the_header_is_plain_c_and_a_c_host_links(lib, tmp_path):
+    """the boundary is a C ABI: include/rayhip.h must compile as C99 without warnings, a host written in C must link against
+    librayhip.so -- and, here, be told that there is no device instead of getting a picture from some CPU path"""
+    import subprocess
+    if lib.device_count() > 0:
+        pytest.skip("a GPU is present: the C host is run by tests/test_gpu_parity.py")
+    exe = build_c_host(tmp_path)
+    golden = os.path.join(ROOT, "tests", "golden")
+    r = subprocess.run([exe, os.path.join(golden, "cornell_basic.rayscene"), os.path.join(golden, "pmj02_samples.npy"), "32", "32", "1",
+                        os.path.join(str(tmp_path), "o.ppm")], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr
+    assert not os.path.exists(os.path.join(str(tmp_path), "o.ppm"))

@@ -7,6 +7,8 @@ Every test goes through include/rayhip.h entry points (ctypes, ray_amd/hip.py); 
     compaction, SoA memory layout.
 Bar: integer/index results exact; fp32 images within the stated tolerance (tests/util.py).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -533,6 +535,28 @@ def test_compressed_textures_through_the_ray_api(gpu_lib, hostsim_lib):
     m = util.frame_metrics(imgs[1], imgs[0])
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
     assert not np.array_equal(imgs[1], imgs[2]), "compression did not change a texel: not exercised"
+
+
+def test_a_host_written_in_c(gpu_lib, tmp_path):
+    """examples/c_abi_render.c: blob -> rayhip_* calls -> PPM, compiled as C99 (no Python, no C++ in the host): the picture
+    must be the tone-mapped frame the ctypes path reads back"""
+    import subprocess
+    import test_abi
+    exe = test_abi.build_c_host(tmp_path)
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    w, h, spp = 96, 64, 6
+    out = os.path.join(str(tmp_path), "o.ppm")
+    r = subprocess.run([exe, os.path.join(golden, "cornell_lights.rayscene"), os.path.join(golden, "pmj02_samples.npy"), str(w), str(h), str(spp), out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    print(r.stdout.strip())
+    with open(out, "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == f"{w} {h}\n".encode() and f.readline() == b"255\n"
+        ppm = np.frombuffer(f.read(), dtype=np.uint8).reshape(h, w, 3)
+    ctx = util.make_context(gpu_lib, "cornell_lights", w, h)
+    ctx.render_batch(1, spp)
+    final = np.clip(ctx.readback(hip.BUF_FINAL)[..., :3], 0.0, 1.0)
+    assert np.array_equal(ppm, (final * 255.0 + 0.5).astype(np.uint8))
 
 
 def test_block_textures_are_decoded_on_the_device(gpu_lib, hostsim_lib):
