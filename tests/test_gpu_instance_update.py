@@ -147,3 +147,35 @@ def test_renderer_hip_takes_the_update_path(gpu_lib, capfd, monkeypatch):
     r.RenderScene(s, region)
     r.get_raw_pixels_ref()
     assert "bvh uploaded" in capfd.readouterr().err
+
+
+def test_single_instance_moved_removed_and_added_again(gpu_lib):
+    """the smallest top level (one instance: the builder's root gets a far-away point box as second child), an empty one,
+    and one instance again -- each through the update path, each equal to a full upload of the same scene"""
+    _need_host_lib()
+    w, h, spp = 64, 48, 3
+    s = api.CreateSceneHIP()
+    s.SetEnvironment(env_col=(0.2, 0.25, 0.3), back_col=(0.2, 0.25, 0.3))
+    grey = s.AddMaterial(api.ShadingNode(type=api.eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    attrs, idx = scenes.cornell_mesh_arrays(scenes._block_quads("tall"))
+    mesh = s.AddMesh(attrs, idx, [(grey, None, 0, 30)])
+    mi = s.AddMeshInstance(mesh)
+    s.AddLight("sphere", color=(4.0, 4.0, 4.0), position=(-0.1, 0.5, 0.1), radius=0.03)
+    scenes._cornell_camera(s)
+    s.Finalize()
+    ctx = _context(gpu_lib, w, h, api.export_scene_blob(s))
+    frames = [util.render_frames(ctx, spp)]
+    for step in ("move", "remove", "add"):
+        if step == "move":
+            s.SetMeshInstanceTransform(mi, scenes._xform(translate=(0.1, 0.05, -0.05), rot_y_deg=30.0, scale=(1.2, 0.8, 1.0)))
+        elif step == "remove":
+            s.RemoveMeshInstance(mi)
+        else:
+            mi = s.AddMeshInstance(mesh, scenes._xform(translate=(-0.1, 0.0, 0.1)))
+        s.Finalize()
+        blob = api.export_scene_blob(s)
+        assert ctx.update_instances(blob) == 0, step
+        ctx.clear()
+        frames.append(util.render_frames(ctx, spp))
+        assert np.array_equal(frames[-1], util.render_frames(_context(gpu_lib, w, h, blob), spp)), step
+        assert not np.array_equal(frames[-1], frames[-2]), step

@@ -204,6 +204,48 @@ def test_instance_update_against_live_reference(lib, wide, monkeypatch):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("wide", ["0", "1"], ids=["bvh2", "bvh4"])
+def test_instance_update_with_a_single_instance(lib, wide, monkeypatch):
+    """the smallest top level: ONE instance (the linear builder has nothing to split: its root gets a far-away point box as
+    second child), moved and rotated; then removed altogether (an empty scene with lights), then added again"""
+    from ray_amd import api, scenes
+    monkeypatch.setenv("HOSTSIM_BVH4", wide)
+    w, h, spp = 48, 48, 2
+    handle = {}
+
+    def one_instance(scene):
+        scene.SetEnvironment(env_col=(0.2, 0.25, 0.3), back_col=(0.2, 0.25, 0.3))
+        grey = scene.AddMaterial(api.ShadingNode(type=api.eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+        attrs, idx = scenes.cornell_mesh_arrays(scenes._block_quads("tall"))
+        mesh = scene.AddMesh(attrs, idx, [(grey, None, 0, 30)])
+        handle["mi"], handle["mesh"] = scene.AddMeshInstance(mesh), mesh
+        scene.AddLight("sphere", color=(4.0, 4.0, 4.0), position=(-0.1, 0.5, 0.1), radius=0.03)
+        scenes._cornell_camera(scene)
+        scene.Finalize()
+
+    r, s = O.render_ref(one_instance, w, h, spp)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+
+    def check(mutate):
+        mutate()
+        s.Finalize()
+        region = api.RegionContext((0, 0, w, h))
+        r.Clear()
+        for _ in range(spp):
+            r.RenderScene(s, region)
+        assert ctx.update_instances(O.export_scene(s)) == 0
+        ctx.clear()
+        assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+
+    check(lambda: s.SetMeshInstanceTransform(handle["mi"], scenes._xform(translate=(0.1, 0.05, -0.05), rot_y_deg=30.0, scale=(1.2, 0.8, 1.0))))
+    moved = r.get_raw_pixels_ref().copy()
+    check(lambda: s.RemoveMeshInstance(handle["mi"]))
+    assert not np.array_equal(moved, r.get_raw_pixels_ref())
+    check(lambda: handle.update(mi=s.AddMeshInstance(handle["mesh"], scenes._xform(translate=(-0.1, 0.0, 0.1)))))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_instance_update_of_a_field_of_instances(lib):
     """200 instances (every 64th a lamp: its triangle lights move along), all moved, Finalize: update path against the live
     reference; and a scene with other geometry is turned away with 2 (= upload it)"""
