@@ -234,6 +234,110 @@ struct HostBuilder {
     }
 };
 
+// A builder for SMALL groups (leaf refinement: a group is one leaf of the scene's trees, at most 8 triangles): instead of
+// the Morton order of the linear builder, every split is chosen by sweeping the surface-area heuristic over the three axes
+// -- exhaustive for so few primitives.  Cost of a side: area x triangle tests, where a leaf of one triangle counts as two
+// (the reference's leaf word cannot say "1": a lone triangle is stored, and tested, twice).  Same interface and output
+// conventions as rayhip_lbvh::build_host; `leaf_is_primitive` / `roots_are_nodes` inputs are not supported.
+// MEASURED against the linear builder as refinement builder (atrium, visit counters of the 4-wide walk over all bounces,
+// leaf_max 2): 19.52 vs 19.66 node visits and 4.84 vs 5.16 triangle tests per ray -- the leaves of a regular mesh are small
+// patches whose Morton order already is a good split order.  Not enough to move the refinement off the device builder; kept as
+// the comparison (tests/hostsim: HOSTSIM_REFINE_SAH=1).
+struct SmallSahBuilder {
+    bool operator()(const rayhip_lbvh::Input &in, rayhip_lbvh::Output &out, std::string &why) const {
+        using rayhip_lbvh::leaf_word;
+        if (in.leaf_is_primitive || in.roots_are_nodes) {
+            why = "SmallSahBuilder builds leaf refinements only";
+            return false;
+        }
+        out = rayhip_lbvh::Output();
+        out.group_root.assign(in.n_groups, NONE);
+        out.bounds = rayhip_lbvh::empty_box();
+        std::vector<std::vector<uint32_t>> members(in.n_groups);
+        for (uint32_t p = 0; p < in.n_prims; ++p) {
+            members[in.prim_group[p]].push_back(p);
+        }
+        auto half_area = [](const Box &b) {
+            const float e[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]};
+            return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+        };
+        auto tests = [&](const size_t m) { return m == 1 ? 2.0f : float(m); };
+        struct Task {
+            std::vector<uint32_t> ids;
+            uint32_t node, side; // where the link goes (node == NONE: the group root)
+            uint32_t group;
+        };
+        for (uint32_t grp = 0; grp < in.n_groups; ++grp) {
+            if (members[grp].empty()) {
+                continue;
+            }
+            if (members[grp].size() > 16) {
+                why = "SmallSahBuilder: a group of " + std::to_string(members[grp].size()) + " primitives";
+                return false;
+            }
+            std::vector<Task> stack;
+            stack.push_back(Task{members[grp], NONE, 0, grp});
+            while (!stack.empty()) {
+                Task t = std::move(stack.back());
+                stack.pop_back();
+                Box box = rayhip_lbvh::empty_box();
+                for (const uint32_t p : t.ids) {
+                    rayhip_lbvh::grow(box, in.prim_box[p]);
+                }
+                uint32_t link;
+                if (t.ids.size() <= in.leaf_max) {
+                    const uint32_t first = uint32_t(out.entries.size());
+                    for (const uint32_t p : t.ids) {
+                        out.entries.push_back(p);
+                    }
+                    if (t.ids.size() == 1) {
+                        out.entries.push_back(t.ids[0]);
+                    }
+                    link = leaf_word(first, uint32_t(t.ids.size()));
+                } else {
+                    // best (axis, position) by area x tests of the two sides
+                    float best = 3.402823466e+38f;
+                    int best_axis = 0;
+                    size_t best_k = t.ids.size() / 2;
+                    std::vector<uint32_t> sorted[3];
+                    for (int a = 0; a < 3; ++a) {
+                        sorted[a] = t.ids;
+                        std::stable_sort(sorted[a].begin(), sorted[a].end(), [&](const uint32_t x, const uint32_t y) {
+                            return in.prim_box[x].lo[a] + in.prim_box[x].hi[a] < in.prim_box[y].lo[a] + in.prim_box[y].hi[a];
+                        });
+                        const size_t n = sorted[a].size();
+                        std::vector<Box> suffix(n + 1, rayhip_lbvh::empty_box());
+                        for (size_t k = n; k-- > 0;) {
+                            suffix[k] = suffix[k + 1];
+                            rayhip_lbvh::grow(suffix[k], in.prim_box[sorted[a][k]]);
+                        }
+                        Box prefix = rayhip_lbvh::empty_box();
+                        for (size_t k = 1; k < n; ++k) {
+                            rayhip_lbvh::grow(prefix, in.prim_box[sorted[a][k - 1]]);
+                            const float cost = half_area(prefix) * tests(k) + half_area(suffix[k]) * tests(n - k);
+                            if (cost < best) {
+                                best = cost, best_axis = a, best_k = k;
+                            }
+                        }
+                    }
+                    link = uint32_t(out.nodes.size());
+                    out.nodes.emplace_back();
+                    const std::vector<uint32_t> &srt = sorted[best_axis];
+                    stack.push_back(Task{std::vector<uint32_t>(srt.begin() + best_k, srt.end()), link, 1, grp});
+                    stack.push_back(Task{std::vector<uint32_t>(srt.begin(), srt.begin() + best_k), link, 0, grp});
+                }
+                if (t.node == NONE) {
+                    out.group_root[grp] = link;
+                } else {
+                    rayhip_lbvh::write_child(out.nodes[t.node], int(t.side), box, link);
+                }
+                rayhip_lbvh::grow(out.bounds, box);
+            }
+        }
+        return true;
+    }
+};
+
 template <class Build> inline Rebuilt rebuild_with(const rayhip_scene_desc &d, const uint32_t leaf_max, Build &&build) {
     Rebuilt out;
     Gathered g;
@@ -403,5 +507,6 @@ template <class Build> inline Rebuilt refine_with(const rayhip_scene_desc &d, co
     return out;
 }
 inline Rebuilt refine_host(const rayhip_scene_desc &d, const uint32_t leaf_max) { return refine_with(d, leaf_max, HostBuilder()); }
+inline Rebuilt refine_host_sah(const rayhip_scene_desc &d, const uint32_t leaf_max) { return refine_with(d, leaf_max, SmallSahBuilder()); }
 
 } // namespace rayhip_rebuild

@@ -137,7 +137,9 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
             rebuild = atoi(e);
         }
         if (rebuild > 0 || refine > 0) {
-            rebuilt = rebuild > 0 ? rayhip_rebuild::rebuild_host(aligned0.d, uint32_t(rebuild)) : rayhip_rebuild::refine_host(aligned0.d, uint32_t(refine));
+            const bool sah = getenv("HOSTSIM_REFINE_SAH") != nullptr && atoi(getenv("HOSTSIM_REFINE_SAH")) != 0; // (scene_rebuild.h: SmallSahBuilder)
+            rebuilt = rebuild > 0 ? rayhip_rebuild::rebuild_host(aligned0.d, uint32_t(rebuild))
+                                  : (sah ? rayhip_rebuild::refine_host_sah(aligned0.d, uint32_t(refine)) : rayhip_rebuild::refine_host(aligned0.d, uint32_t(refine)));
             if (!rebuilt.ok) {
                 g_err = "scene rebuild failed: " + rebuilt.why;
                 return 1;
