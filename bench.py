@@ -12,10 +12,14 @@ Workloads (BASELINE.json configs; no real Sponza/Bistro asset exists offline, se
   cornell     samples/00_basic Cornell box, 1024x1024                   (config 2)
   principled  samples/03_principled, 2048x2048                          (config 5)
 
-Multi-GPU (N > 1, launched by torch.distributed.run, one process per GPU): the scene is replicated, the frame's
-64x64 tiles are dealt round-robin to the ranks (rayhip_set_shard), every rank renders all K samples of ITS tiles,
-and ONE RCCL reduce (torch.distributed, backend nccl) of the raw fp32 framebuffer assembles the frame on rank 0
-inside the timed region.  Total work is fixed -> "scaling": "strong".
+Multi-GPU (N > 1, one process per GPU: under torch.distributed.run, or -- started as a plain process -- bench.py launches
+its N ranks itself): the scene is replicated, the frame's 64x64 tiles are dealt round-robin to the ranks
+(rayhip_set_shard), every rank renders all K samples of ITS tiles, and ONE exchange inside the timed region assembles the
+frame on rank 0: the product's own collective (rayhip_comm_reduce_framebuffers: every rank's owned tiles, densely packed,
+point-to-point to the root over RCCL / xGMI; torch.distributed only carries the barrier and the communicator id).  Its
+time is reported separately (`exchange_ms`).  Total work is fixed -> "scaling": "strong".  With more ranks than devices
+(a 1-GPU box) the ranks share devices and the packed tiles travel through host memory over gloo -- RCCL cannot put two
+ranks on one device -- and the line says `"emulated_ranks": true`: a plumbing check, not a scaling measurement.
 
 Timed region: barrier + stream sync | K iterations (+ the reduce at N>1) | stream sync + barrier; max over ranks.
 Inputs (scene, PMJ table) are resident in HBM before the region starts; nothing is copied to the host inside it.
@@ -25,10 +29,11 @@ k_trace_closest<false,true> for the primary rays; "a launch" is a launch of eith
 events on the context stream during the timed region (RAYHIP_FLAG_TIME_STAGES, no synchronisation).  Three byte counts,
 all per launch:
   traffic      HBM bytes that actually moved: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE of this kernel, from a profiled run of
-               THIS command line (profiles/r02/k2_traffic.json, keyed by workload / steps / iterations per pass; written by
-               tools/k2_traffic.py from the rocprofv3 output); for another pass size or N > 1 the profiled run of the same
-               workload with the nearest pass size, scaled by rays per launch (traffic_detail.exact = false says so); null
-               when the workload was never profiled
+               THIS command line (profiles/r03/k2_traffic.json, keyed by workload / steps / iterations per pass; written by
+               tools/k2_traffic.py from the rocprofv3 output and stamped with a hash of ray_amd/csrc); for another pass size
+               or N > 1 the profiled run of the same workload with the nearest pass size, scaled by rays per launch
+               (traffic_detail.exact = false says so); traffic_detail.stale = true when the kernel sources changed since the
+               profile was taken; null when the workload was never profiled
   achieved     = traffic / launch time when traffic is known (the north star's figure: "achieved HBM GB/s from rocprof
                against the chip's memory roofline"), else the kernel's own algorithmic rate; frac = achieved / 8 TB/s
   algorithmic  the kernel's OWN algorithmic bytes: 72+20+4 per ray + 64 per TLAS node + 64 per 4-wide node + 48 per
@@ -104,6 +109,26 @@ def get_scene_blob(name, wl, rank, world, barrier):
     return blob, info
 
 
+def csrc_hash():
+    """hash of the kernel sources a committed PMC profile belongs to (tools/k2_traffic.py stamps its entries with it)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ray_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "ray_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_table_path():
+    for r in ("r03", "r02"):
+        p = os.path.join(ROOT, "profiles", r, "k2_traffic.json")
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "r03", "k2_traffic.json")
+
+
 def measured_traffic(workload, steps, batch, world=1):
     """HBM bytes per K2 launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 PMC passes (profiles/r02/k2_traffic.json,
     written by tools/k2_traffic.py).  Exact when this very command line was profiled (same workload, steps, iterations per
@@ -111,7 +136,7 @@ def measured_traffic(workload, steps, batch, world=1):
     per launch is proportional to the rays of the launch, i.e. to iterations per pass / ranks (64 vs 20 iterations per pass:
     0.5636 vs 0.5610 GB per iteration) -- and marked as such; None when the workload was never profiled."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02", "k2_traffic.json")) as f:
+        with open(traffic_table_path()) as f:
             table = json.load(f)
         runs = [e for e in table.get("runs", []) if e["workload"] == workload]
         if not runs:
@@ -123,7 +148,9 @@ def measured_traffic(workload, steps, batch, world=1):
                "fetch_bytes_per_launch": float(e["fetch_bytes_per_launch"]) * k,
                "write_bytes_per_launch": float(e["write_bytes_per_launch"]) * k,
                "profiled_avg_launch_ms": e.get("avg_launch_ms") if exact else None, "source": e.get("source"),
-               "exact": bool(exact)}
+               "exact": bool(exact), "table": os.path.relpath(traffic_table_path(), ROOT),
+               # the profile belongs to the kernels it was taken with: anything else is a stale figure
+               "stale": e.get("csrc_hash") != csrc_hash(), "profiled_csrc_hash": e.get("csrc_hash")}
         if not exact:
             out["scaled_by"] = k
             out["scaled_from"] = {"steps": e["steps"], "iterations_per_pass": e["iterations_per_pass"], "n_gpus": 1}
@@ -236,14 +263,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as a plain process: launch the N ranks ourselves (one process per GPU) and pass rank 0's line through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.dup2(real_stdout, 1)
+        raise SystemExit(subprocess.run(cmd).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
 
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    n_dev = torch.cuda.device_count()
+    emulated = world > n_dev  # more ranks than devices: ranks share devices, the exchange goes through host memory (gloo)
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     # torch initialises its device context lazily, on the first call that needs it -- which would be the
     # torch.cuda.synchronize() that opens the timed region: the first timed pass of a process then started 15-30 ms late
@@ -260,7 +299,10 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if emulated:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
@@ -277,7 +319,16 @@ def main():
     ctx.resize(W, H)
     cam = ctx.upload_scene_blob(blob)
     ctx.set_shard(TILE, world, rank)
-    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local_rank}") if dist is not None else None
+    # the exchange step: the product's collective (RCCL behind the C ABI); torch.distributed only hands the id around
+    comm = None
+    if dist is not None and not emulated:
+        ids = [hip.Comm.unique_id(ctx.L) if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = hip.Comm.for_rank(ctx.L, ids[0], world, rank, ctx)
+
+    def exchange():
+        if dist is not None:
+            multigpu.exchange_frame(ctx, rank, world, comm=comm, dist=dist, what=hip.REDUCE_RADIANCE, via_host=emulated)
 
     batch = int(os.environ.get("RAY_AMD_BATCH", "0")) or multigpu.batch_size(W * H // world, ctx.max_batch(), K)
     ctx.reserve_batch(batch)  # (the shard is set: a rank's buffers are sized for its share of the frame)
@@ -304,9 +355,7 @@ def main():
             n = min(batch, Wm - done)
             ctx.render_batch(it + 1, n)
             it, done = it + n, done + n
-    if dist is not None:  # warm the communicator too
-        ctx.export_shard_device(hip.BUF_RAW, frame.data_ptr())
-        dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+    exchange()  # warm the communicator too
     ctx.sync()
     ctx.trav_timing(reset=True)
     ctx.stage_times(reset=True)
@@ -315,21 +364,30 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # K iterations of this rank's tiles + (N>1) the one exchange step of the path: the frame reduce over RCCL/xGMI
-    multigpu.render_sharded(ctx, range(it + 1, it + 1 + K), rank, world, dist=dist, frame=frame,
+    multigpu.render_sharded(ctx, range(it + 1, it + 1 + K), rank, world, dist=None, frame=None,
                             flags=hip.FLAG_TIME_STAGES, tile=TILE, batch=batch)
     it += K
-    if dist is None:  # what the reduce is at N > 1: the finished frame leaves the GPU once per image
+    ctx.sync()
+    t_rendered = time.perf_counter()
+    if dist is None:  # what the exchange is at N > 1: the finished frame leaves the GPU once per image
         ctx.readback(hip.BUF_RAW, out=host_frame)
+    exchange()
     ctx.sync()
     torch.cuda.synchronize()
+    t_exchanged = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
     del blob
+    rank_times = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # (after the timed region) every rank's own render time and the exchange as rank 0 saw it -- the wait for the
+        # slowest rank included -- and the maximum of the region over the ranks
+        mine = [dt, t_rendered - t0, t_exchanged - t_rendered]
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        dt = max(e[0] for e in every)
+        rank_times = {"render_ms": [round(e[1] * 1e3, 3) for e in every], "exchange_ms_rank0": round(every[0][2] * 1e3, 3)}
 
     (k2_ms, k2_launches), (k3_ms, k3_launches) = ctx.trav_timing(reset=True)
     stages = ctx.stage_times(reset=True)
@@ -396,7 +454,7 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['label']}, {W}x{H}, {K} spp", "width": W, "height": H,
                        "spp": K, "unique_tris": info["tris"], "bvh_tris": info["bvh_tris"], "bvh2_nodes": info["nodes"],
                        "max_depth": int(cam.pass_settings.max_total_depth),
-                       "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 RCCL reduce/frame)",
+                       "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 gather of the owned tiles per frame over RCCL)",
                        "iterations_per_pass": batch},
             "roofline": {
                 "bound": "hbm", "kernel": "K2 closest-hit traversal: k_trace_closest_refill (secondary bounces) + k_trace_closest<false,true> (primary rays)",
@@ -408,6 +466,7 @@ def main():
                                 if hbm_gbs is not None else
                                 "the kernel's own algorithmic bytes / launch time (no PMC profile of this workload is committed): an upper "
                                 "bound of the HBM rate, every visit counted as a miss"),
+                "traffic_is_stale": bool(traffic and traffic.get("stale")),  # profile taken with other kernel sources: re-profile (tools/k2_traffic.py)
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
                 "traffic_detail": traffic,
                 "avg_launch_ms": k2_ms / launches, "launches": k2_launches,
@@ -429,6 +488,14 @@ def main():
             "stage_us_per_step": {k: v / K for k, v in stages.items() if v},
             "scene_build_s": info["build_s"],
         }
+        if rank_times is not None:
+            out["exchange_ms"] = rank_times["exchange_ms_rank0"]
+            out["rank_render_ms"] = rank_times["render_ms"]
+            out["exchange"] = ("rayhip_comm_reduce_framebuffers: owned tiles (1/N of the frame per rank) point-to-point to rank 0 over RCCL"
+                               if not emulated else "owned tiles through host memory over gloo (ranks share a device: RCCL cannot form the communicator)")
+        if emulated:
+            out["emulated_ranks"] = True
+            out["devices"] = n_dev
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
             out["parity"] = parity_check(ctx, wl)
@@ -437,6 +504,8 @@ def main():
         line = json.dumps(out)
     else:
         line = None
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

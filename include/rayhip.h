@@ -332,7 +332,9 @@ RAYHIP_API int rayhip_scene_upload(rayhip_ctx *ctx, const rayhip_scene_desc *des
  * vtx_indices for the corners of triangle lights; textures / texels may be null.  The top-level tree is rebuilt on the
  * device over those boxes (ray_amd/csrc/lbvh.hip.h).  Meshes, materials and textures must be the ones of the last
  * rayhip_scene_upload.  Returns 0; 1 = error; 2 = this change needs rayhip_scene_upload (an instance of a mesh that was
- * not in use at the last upload, geometry arrays of another size) -- nothing on the device was touched. */
+ * not in use at the last upload, geometry arrays of another size) -- nothing on the device was touched.  After 1 the
+ * context still holds the previous top-level tree (new trees are written to alternating halves of a reserved region),
+ * but instance / light arrays may already be the new ones: re-send the scene with rayhip_scene_upload. */
 RAYHIP_API int rayhip_scene_update_instances(rayhip_ctx *ctx, const rayhip_scene_desc *desc);
 
 /* Same upload from a serialised scene (ray_amd/csrc/scene_blob.h; written by the reference-side SceneHIP or by
@@ -402,9 +404,11 @@ RAYHIP_API int rayhip_set_raw_device(rayhip_ctx *ctx, const void *src_device_rgb
                                      const rayhip_camera *cam);
 
 /* ---- multi-GPU: the frame exchange behind the C ABI (new, the reference has no multi-GPU mode) ----
- * N contexts (one per GPU) render the tiles rayhip_set_shard deals them; ONE ncclReduce(sum, fp32) over RCCL/xGMI then
- * assembles the frame on `root`.  Every rank contributes only the pixels it owns (zero elsewhere), so the result equals a
- * single-GPU render bit for bit and the call can be repeated after more iterations (progressive refinement).
+ * N contexts (one per GPU) render the tiles rayhip_set_shard deals them; ONE exchange over RCCL/xGMI then assembles the
+ * frame on `root`: the shards are disjoint tiles, so every rank sends the tiles it owns, densely packed (1/N of the
+ * frame), straight to the root (ncclSend / ncclRecv in one group: N - 1 point-to-point links in parallel), which scatters
+ * them into its images.  Copies are exact: the result equals a single-GPU render bit for bit and the call can be
+ * repeated after more iterations (progressive refinement).
  *   rayhip_comm_create            one process drives all `ndev` GPUs (ncclCommInitAll): what a C++ host using RendererHIP does
  *   rayhip_comm_unique_id +       one process per GPU: rank 0 makes the id, hands its RAYHIP_COMM_ID_BYTES bytes to the other
  *   rayhip_comm_create_rank       processes by its own means, every process creates its rank (ncclCommInitRank) -- collective
@@ -432,6 +436,17 @@ RAYHIP_API void rayhip_comm_destroy(rayhip_comm *comm);
  * (RAYHIP_BUF_RAW = the running mean, BASE_COLOR, DEPTH_NORMALS, VARIANCE), zero elsewhere, tightly packed [h][w][4] into
  * DEVICE memory.  Sum over ranks = the frame; hand it to the root with rayhip_set_raw_device. */
 RAYHIP_API int rayhip_export_shard_device(rayhip_ctx *ctx, int which, void *dst_device_rgba);
+/* The same exchange with the caller's transport (MPI, torch.distributed, ...), in the packing the RCCL path uses: the
+ * tiles a rank owns, densely -- owned tile j of rank r is frame tile r + j * N, one tile x tile slot of float4 each, the
+ * images of the RAYHIP_REDUCE_* mask `what` (0 = all four) one after the other.  rayhip_owned_bytes: size of rank `rank`'s
+ * buffer; rayhip_export_owned: pack this context's tiles (its shard: rayhip_set_shard) into DEVICE memory;
+ * rayhip_import_owned: scatter rank `from_rank`'s buffer into this context's images (the root calls it once per sender);
+ * rayhip_finish_import: the assembled radiance image becomes RAW and is tonemapped into FINAL.  All three wait for the
+ * context stream. */
+RAYHIP_API size_t rayhip_owned_bytes(rayhip_ctx *ctx, uint32_t what, int nranks, int rank);
+RAYHIP_API int rayhip_export_owned(rayhip_ctx *ctx, uint32_t what, void *dst_device, size_t capacity_bytes);
+RAYHIP_API int rayhip_import_owned(rayhip_ctx *ctx, uint32_t what, int from_rank, const void *src_device, size_t bytes);
+RAYHIP_API int rayhip_finish_import(rayhip_ctx *ctx, const rayhip_camera *cam);
 
 RAYHIP_API int rayhip_sync(rayhip_ctx *ctx);
 

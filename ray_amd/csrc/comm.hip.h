@@ -1,13 +1,16 @@
-// comm.hip.h -- the one exchange step of the path: reduce the tile-sharded framebuffers of N GPUs to one rank over
+// comm.hip.h -- the one exchange step of the path: assemble the tile-sharded framebuffers of N GPUs on one rank over
 // RCCL / xGMI (rayhip_comm_create / rayhip_comm_reduce_framebuffers / rayhip_comm_destroy; 8e).
 // Included by rayhip.hip (needs rayhip_ctx).
 //
-// What is exchanged: every rank packs the pixels it OWNS (rayhip_set_shard) of the running mean (`full`), of the two aux
-// images and of the variance estimate into one staging buffer -- zero elsewhere -- and ONE ncclReduce(sum, fp32) of
-// 4 x W x H x 16 B (133 MB at 1080p; 33 MB when only the radiance image is asked for) lands the frame on the root, which
-// unpacks it into its own buffers and re-runs the tonemap.  A sum with zeros is exact, so the assembled images equal an
-// unsharded render bit for bit, and DenoiseImage on the root sees the complete guides.  The ranks' accumulation state is
-// never overwritten on pixels they own, so progressive refinement (render more, reduce again) stays exact.
+// What is exchanged: the shards are disjoint sets of 64 x 64 tiles, so the "reduce" of the frame is a GATHER.  Every rank
+// packs the tiles it owns (rayhip_set_shard) of the running mean (`full`), of the two aux images and of the variance
+// estimate densely into a staging buffer -- 1/N of the frame -- and sends it straight to the root (ncclSend / ncclRecv in
+// one group); the root scatters what arrives into its own images and re-runs the tonemap.  xGMI is point-to-point: each
+// of the N - 1 senders has its own link to the root, so the step moves 33 MB * (N - 1) / N at 1080p over N - 1 links in
+// parallel (4.1 MB per link at N = 8), where a ring ncclReduce of zero-padded full frames (what round 2 did) pushed the
+// whole 33 MB through every link in turn.  Copies are exact, so the assembled images equal an unsharded render bit for
+// bit, and DenoiseImage on the root sees the complete guides.  A rank's accumulation state is never overwritten on pixels
+// it owns, so progressive refinement (render more, gather again) stays exact.
 //
 // RCCL is loaded with dlopen when the first communicator is created: librayhip.so has no link-time dependency on it, and
 // inside a process that already carries an RCCL (PyTorch) the loaded copy is reused.
@@ -23,7 +26,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -55,7 +59,8 @@ int load_rccl() {
     RCCL_SYM(CommInitRank, "ncclCommInitRank")
     RCCL_SYM(CommInitAll, "ncclCommInitAll")
     RCCL_SYM(CommDestroy, "ncclCommDestroy")
-    RCCL_SYM(Reduce, "ncclReduce")
+    RCCL_SYM(Send, "ncclSend")
+    RCCL_SYM(Recv, "ncclRecv")
     RCCL_SYM(GroupStart, "ncclGroupStart")
     RCCL_SYM(GroupEnd, "ncclGroupEnd")
     RCCL_SYM(GetErrorString, "ncclGetErrorString")
@@ -108,36 +113,48 @@ struct rayhip_comm {
 };
 
 namespace {
-// pack the selected images of one context into its staging buffer (enqueued on the context stream)
-int comm_pack(rayhip_ctx *c, const int *sel, int n_sel) {
+// floats rank `rank` contributes for `n_sel` images of a w x h frame
+size_t comm_rank_floats(int w, int h, int tile, int nranks, int rank, int n_sel) {
+    const ShardTiles st = shard_tiles(w, h, tile);
+    return size_t(shard_owned_tiles(st.total, nranks, rank)) * size_t(tile) * size_t(tile) * 4u * size_t(n_sel);
+}
+// pack the owned tiles of the selected images of one context, image after image, at `dst` (enqueued on the context stream)
+int comm_pack(rayhip_ctx *c, const int *sel, int n_sel, float4 *dst) {
     HIP_TRY(hipSetDevice(c->device));
-    const size_t npix = size_t(c->w) * size_t(c->h);
-    if (c->shard_stage.alloc(npix * 16 * COMM_IMAGES)) {
-        return 1;
-    }
-    for (int k = 0; k < n_sel; ++k) {
-        k_pack_owned<<<grid_for(c, npix, 256), 256, 0, c->stream>>>(comm_image(c, sel[k]), c->shard_stage.as<float4>() + size_t(k) * npix, c->w,
-                                                                    c->h, c->shard);
+    const ShardTiles st = shard_tiles(c->w, c->h, c->shard.tile);
+    const int owned = shard_owned_tiles(st.total, c->shard.count, c->shard.index);
+    const size_t per_image = size_t(owned) * size_t(c->shard.tile) * size_t(c->shard.tile);
+    for (int k = 0; k < n_sel && per_image; ++k) {
+        k_pack_owned_dense<<<grid_for(c, per_image, 256), 256, 0, c->stream>>>(comm_image(c, sel[k]), dst + size_t(k) * per_image, c->w, c->h,
+                                                                             c->shard, owned);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
-// root: staging buffer -> the context's own images; the radiance image also becomes RAW and is tonemapped into FINAL
-int comm_unpack(rayhip_ctx *c, const int *sel, int n_sel, const rayhip_camera *cam) {
+// root: the packed tiles of rank `from` -> the context's own images
+int comm_unpack(rayhip_ctx *c, const int *sel, int n_sel, int from, const float4 *src) {
     HIP_TRY(hipSetDevice(c->device));
-    const size_t npix = size_t(c->w) * size_t(c->h);
-    for (int k = 0; k < n_sel; ++k) {
-        k_copy_f4<<<grid_for(c, npix, 256), 256, 0, c->stream>>>(c->shard_stage.as<float4>() + size_t(k) * npix, comm_image(c, sel[k]), npix);
-        if (sel[k] == 0) {
-            if (cam->view_transform != 0 && cam->view_transform != c->lut_transform) {
-                return fail("view transform %d needs its look-up table: rayhip_set_tonemap_lut", int(cam->view_transform));
-            }
-            const int rect[4] = {0, 0, c->w, c->h};
-            AccumParams ap = make_accum_params(*cam, c->w, rect, 1);
-            ap.lut = c->tonemap_lut.as<uint32_t>(), ap.lut_dims = c->lut_dims;
-            k_retonemap<<<grid_for(c, npix, 256), 256, 0, c->stream>>>(ap, c->px, c->h);
-        }
+    const ShardTiles st = shard_tiles(c->w, c->h, c->shard.tile);
+    const int owned = shard_owned_tiles(st.total, c->shard.count, from);
+    const size_t per_image = size_t(owned) * size_t(c->shard.tile) * size_t(c->shard.tile);
+    const Shard sender = {c->shard.tile, c->shard.count, from};
+    for (int k = 0; k < n_sel && per_image; ++k) {
+        k_unpack_owned_dense<<<grid_for(c, per_image, 256), 256, 0, c->stream>>>(src + size_t(k) * per_image, comm_image(c, sel[k]), c->w, c->h,
+                                                                               sender, owned);
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// root, after the radiance image is complete: it becomes RAW and is tonemapped into FINAL
+int comm_finish(rayhip_ctx *c, const rayhip_camera *cam) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (cam->view_transform != 0 && cam->view_transform != c->lut_transform) {
+        return fail("view transform %d needs its look-up table: rayhip_set_tonemap_lut", int(cam->view_transform));
+    }
+    const int rect[4] = {0, 0, c->w, c->h};
+    AccumParams ap = make_accum_params(*cam, c->w, rect, 1);
+    ap.lut = c->tonemap_lut.as<uint32_t>(), ap.lut_dims = c->lut_dims;
+    k_retonemap<<<grid_for(c, size_t(c->w) * c->h, 256), 256, 0, c->stream>>>(ap, c->px, c->h);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -226,34 +243,78 @@ int rayhip_comm_reduce_framebuffers(rayhip_comm *m, int root, uint32_t what, con
     if (n_sel == 0) {
         return fail("rayhip_comm_reduce_framebuffers: empty image mask");
     }
-    int w = 0, h = 0;
-    for (rayhip_ctx *c : m->ctx) {
+    int w = 0, h = 0, tile = 0;
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        rayhip_ctx *c = m->ctx[i];
         if (!c || !c->w) {
             return fail("every local rank needs a bound, resized context (rayhip_comm_bind)");
         }
-        if (w && (c->w != w || c->h != h)) {
-            return fail("the contexts of a communicator must render the same frame size");
+        if (w && (c->w != w || c->h != h || c->shard.tile != tile)) {
+            return fail("the contexts of a communicator must render the same frame size with the same shard tile");
         }
-        w = c->w, h = c->h;
+        if (c->shard.count != m->nranks || c->shard.index != m->local[i]) {
+            return fail("rank %d: the context's shard is (%d of %d); rayhip_set_shard was called after rayhip_comm_bind", m->local[i],
+                        c->shard.index, c->shard.count);
+        }
+        w = c->w, h = c->h, tile = c->shard.tile;
     }
-    for (rayhip_ctx *c : m->ctx) {
-        if (comm_pack(c, sel, n_sel)) {
+    // staging: the root holds one region per sender (rank order), every other rank its own tiles
+    std::vector<size_t> region(size_t(m->nranks) + 1, 0); // float offsets on the root
+    for (int r = 0; r < m->nranks; ++r) {
+        region[size_t(r) + 1] = region[size_t(r)] + (r == root ? 0 : comm_rank_floats(w, h, tile, m->nranks, r, n_sel));
+    }
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        rayhip_ctx *c = m->ctx[i];
+        HIP_TRY(hipSetDevice(c->device));
+        g_touch_stream = c->stream;
+        const size_t floats = m->local[i] == root ? region[size_t(m->nranks)] : comm_rank_floats(w, h, tile, m->nranks, m->local[i], n_sel);
+        if (c->shard_stage.alloc(std::max<size_t>(floats, 4) * sizeof(float))) {
+            return 1;
+        }
+        if (m->local[i] != root && comm_pack(c, sel, n_sel, c->shard_stage.as<float4>())) {
             return 1;
         }
     }
-    const size_t count = size_t(w) * size_t(h) * 4u * size_t(n_sel); // floats
-    RCCL_TRY(g_rccl.GroupStart());
-    for (size_t i = 0; i < m->ctx.size(); ++i) {
-        rayhip_ctx *c = m->ctx[i];
-        const ncclResult_t r = g_rccl.Reduce(c->shard_stage.p, c->shard_stage.p, count, ncclFloat, ncclSum, root, m->comms[i], c->stream);
+    if (m->nranks > 1) {
+        RCCL_TRY(g_rccl.GroupStart());
+        ncclResult_t r = ncclSuccess;
+        for (size_t i = 0; i < m->ctx.size() && r == ncclSuccess; ++i) {
+            rayhip_ctx *c = m->ctx[i];
+            if (m->local[i] == root) {
+                for (int from = 0; from < m->nranks && r == ncclSuccess; ++from) {
+                    const size_t n = region[size_t(from) + 1] - region[size_t(from)];
+                    if (from != root && n) {
+                        r = g_rccl.Recv(c->shard_stage.as<float>() + region[size_t(from)], n, ncclFloat, from, m->comms[i], c->stream);
+                    }
+                }
+            } else {
+                const size_t n = comm_rank_floats(w, h, tile, m->nranks, m->local[i], n_sel);
+                if (n) {
+                    r = g_rccl.Send(c->shard_stage.p, n, ncclFloat, root, m->comms[i], c->stream);
+                }
+            }
+        }
         if (r != ncclSuccess) {
             (void)g_rccl.GroupEnd();
-            return fail("ncclReduce failed: %s", g_rccl.GetErrorString(r));
+            return fail("ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(r));
         }
+        RCCL_TRY(g_rccl.GroupEnd());
     }
-    RCCL_TRY(g_rccl.GroupEnd());
     for (size_t i = 0; i < m->ctx.size(); ++i) {
-        if (m->local[i] == root && comm_unpack(m->ctx[i], sel, n_sel, cam)) {
+        if (m->local[i] != root) {
+            continue;
+        }
+        rayhip_ctx *c = m->ctx[i];
+        for (int from = 0; from < m->nranks; ++from) {
+            if (from != root && comm_unpack(c, sel, n_sel, from, reinterpret_cast<const float4 *>(c->shard_stage.as<float>() + region[size_t(from)]))) {
+                return 1;
+            }
+        }
+        bool radiance = false;
+        for (int k = 0; k < n_sel; ++k) {
+            radiance |= sel[k] == 0;
+        }
+        if (radiance && comm_finish(c, cam)) {
             return 1;
         }
     }
@@ -295,6 +356,67 @@ int rayhip_export_shard_device(rayhip_ctx *c, int which, void *dst_device_rgba) 
     const size_t npix = size_t(c->w) * size_t(c->h);
     k_pack_owned<<<grid_for(c, npix, 256), 256, 0, c->stream>>>(src, static_cast<float4 *>(dst_device_rgba), c->w, c->h, c->shard);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Bring-your-own transport (torch.distributed in ray_amd/multigpu.py, MPI in a C++ host): the same dense tile packing as
+// the RCCL path, into / out of DEVICE memory the caller owns.
+size_t rayhip_owned_bytes(rayhip_ctx *c, uint32_t what, int nranks, int rank) {
+    int sel[COMM_IMAGES];
+    const int n_sel = comm_selected(what, sel);
+    if (!c || !c->w || nranks < 1 || rank < 0 || rank >= nranks) {
+        return 0;
+    }
+    return comm_rank_floats(c->w, c->h, c->shard.tile, nranks, rank, n_sel) * sizeof(float);
+}
+
+int rayhip_export_owned(rayhip_ctx *c, uint32_t what, void *dst_device, size_t capacity_bytes) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->w) {
+        return fail("rayhip_export_owned before rayhip_resize");
+    }
+    int sel[COMM_IMAGES];
+    const int n_sel = comm_selected(what, sel);
+    if (rayhip_owned_bytes(c, what, c->shard.count, c->shard.index) > capacity_bytes) {
+        return fail("rayhip_export_owned: the destination holds %zu bytes, %zu needed", capacity_bytes,
+                    rayhip_owned_bytes(c, what, c->shard.count, c->shard.index));
+    }
+    if (comm_pack(c, sel, n_sel, static_cast<float4 *>(dst_device))) {
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rayhip_import_owned(rayhip_ctx *c, uint32_t what, int from_rank, const void *src_device, size_t bytes) {
+    if (use_device(c)) {
+        return 1;
+    }
+    if (!c->w || from_rank < 0 || from_rank >= c->shard.count) {
+        return fail("rayhip_import_owned: rank %d of a shard of %d", from_rank, c->shard.count);
+    }
+    int sel[COMM_IMAGES];
+    const int n_sel = comm_selected(what, sel);
+    if (bytes < rayhip_owned_bytes(c, what, c->shard.count, from_rank)) {
+        return fail("rayhip_import_owned: %zu bytes, rank %d sends %zu", bytes, from_rank, rayhip_owned_bytes(c, what, c->shard.count, from_rank));
+    }
+    if (from_rank != c->shard.index && comm_unpack(c, sel, n_sel, from_rank, static_cast<const float4 *>(src_device))) {
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rayhip_finish_import(rayhip_ctx *c, const rayhip_camera *cam) {
+    if (use_device(c) || !cam) {
+        return 1;
+    }
+    if (comm_finish(c, cam)) {
+        return 1;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -751,9 +751,32 @@ __global__ void __launch_bounds__(256) k_retonemap(const AccumParams p, const Pi
     }
 }
 
-// ---- multi-GPU frame exchange (rayhip_comm_reduce_framebuffers, rayhip_export_shard_device) -----------------------------
-// pack: this rank's OWNED pixels of one image, zero elsewhere -- whatever a buffer holds on pixels of other ranks (the
-// clear colour, the combined frame of an earlier reduce) never enters the sum
+// ---- multi-GPU frame exchange (rayhip_comm_reduce_framebuffers, rayhip_export_owned / rayhip_import_owned) -------------------
+// The shards of a frame are DISJOINT sets of tiles, so "reduce" is a gather: every rank packs the tiles it owns densely
+// (owned tile j of rank r = frame tile r + j * N, a full tile x tile slot each, ragged edge tiles padded with zeros) and the
+// root scatters what it receives into its images.  A rank's operand is 1/N of the frame; nothing another rank's buffers
+// hold on pixels they do not own ever travels.
+// (slot <-> pixel mapping: rt_base.h, shared with the host build)
+__global__ void __launch_bounds__(256) k_pack_owned_dense(const float4 *__restrict__ src, float4 *__restrict__ dst, const int w, const int h,
+                                                         const Shard shard, const int owned) {
+    const int n = owned * shard.tile * shard.tile;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int x, y;
+        dst[i] = shard_slot_pixel(shard, w, h, i, x, y) ? src[y * w + x] : mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+// `shard` = the SENDER's (tile, count, index)
+__global__ void __launch_bounds__(256) k_unpack_owned_dense(const float4 *__restrict__ src, float4 *__restrict__ dst, const int w, const int h,
+                                                           const Shard shard, const int owned) {
+    const int n = owned * shard.tile * shard.tile;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int x, y;
+        if (shard_slot_pixel(shard, w, h, i, x, y)) {
+            dst[y * w + x] = src[i];
+        }
+    }
+}
+// full-frame form (owned pixels, zero elsewhere): rayhip_export_shard_device, for hosts that sum frames themselves
 __global__ void __launch_bounds__(256) k_pack_owned(const float4 *__restrict__ src, float4 *__restrict__ dst, const int w, const int h,
                                                    const Shard shard) {
     const int n = w * h;

@@ -54,6 +54,9 @@ int fail(const char *fmt, ...) {
 
 constexpr int MAX_BOUNCE_SLOTS = 130; // max_total_depth is a uint8 but bounded by MAX_BOUNCES = 128 (Constants.inl:5)
 
+// the stream fresh allocations are touched on: the current context's (set by use_device)
+thread_local hipStream_t g_touch_stream = nullptr;
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -70,10 +73,15 @@ struct DevBuf {
         // touch it now: the first write to fresh device memory is several times slower than the following ones, and the
         // wavefront-state buffers would otherwise pay that inside the first large pass (measured: ray generation 31 ms
         // instead of 0.8 ms in a 20-iteration pass that followed a 5-iteration warm-up)
-        // (the null stream does not order against the context's non-blocking stream: wait, or the memset could land
-        // after the first copy into the buffer)
-        HIP_TRY(hipMemset(p, 0, n));
-        HIP_TRY(hipDeviceSynchronize());
+        // On the context's own stream, so that it is ordered before every later use without stalling other contexts /
+        // streams of the device; the wait keeps growth inside a pass out of the stage timers.
+        if (g_touch_stream) {
+            HIP_TRY(hipMemsetAsync(p, 0, n, g_touch_stream));
+            HIP_TRY(hipStreamSynchronize(g_touch_stream));
+        } else { // (no context yet: the null stream does not order against non-blocking streams, so wait for the device)
+            HIP_TRY(hipMemset(p, 0, n));
+            HIP_TRY(hipDeviceSynchronize());
+        }
         return 0;
     }
     void release() {
@@ -121,6 +129,7 @@ struct rayhip_ctx {
     // on the device
     rayhip_update::MeshRefs mesh_refs;
     uint32_t nodes_used = 0, nodes_reserved = 0;
+    uint32_t tlas_half = 0; // which half of the reserved node slots the next rebuilt top level goes to (the live one sits in the other)
     bool have_wide = false;
     uint32_t tex_table[8] = {}, textures_count = 0, tex_flags = 0;
     struct { uint32_t vertices, vtx_indices, tri_materials, materials; } geometry = {};
@@ -192,6 +201,7 @@ int upload(rayhip_ctx *c, DevBuf &b, const void *src, size_t bytes) {
 
 int use_device(rayhip_ctx *c) {
     HIP_TRY(hipSetDevice(c->device));
+    g_touch_stream = c->stream;
     return 0;
 }
 
@@ -400,6 +410,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         delete c;
         return fail("failed to initialise HIP device %d", device);
     }
+    g_touch_stream = c->stream;
     // persistent grid of the wave-per-block kernels: as many blocks as are resident (LDS stack + VGPR budget)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false, true>, WAVE, 0) != hipSuccess || per_cu <= 0) {
@@ -757,7 +768,8 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     { // room behind the nodes for top-level trees rebuilt on the device later (rayhip_scene_update_instances)
         const size_t n_now = lay.applied ? lay.nodes.size() : size_t(d->nodes_count);
         c->nodes_used = uint32_t(n_now);
-        c->nodes_reserved = uint32_t(std::max<size_t>(4096, 4 * size_t(d->mesh_instances_count)));
+        c->nodes_reserved = uint32_t(std::max<size_t>(8192, 8 * size_t(d->mesh_instances_count)));
+        c->tlas_half = 0;
         if (c->nodes.alloc((n_now + c->nodes_reserved) * sizeof(rayhip_bvh2_node))) {
             return 1;
         }
@@ -892,7 +904,8 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
             return fail("env_qtree holds %u floats, %d levels need %zu", d->env_qtree_count, d->env.qtree_levels, quads * 4);
         }
         for (const uint32_t handle : {d->env.env_map, d->env.back_map}) {
-            if (handle != 0xffffffffu && uint64_t(c->tex_table[handle >> 28]) + (handle & 0x00ffffffu) >= c->textures_count) {
+            if (handle != 0xffffffffu &&
+                ((handle >> 28) >= 8u || uint64_t(c->tex_table[handle >> 28]) + (handle & 0x00ffffffu) >= c->textures_count)) {
                 return fail("environment map handle outside the texture table on the device");
             }
         }
@@ -927,11 +940,15 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
         if (!rayhip_lbvh::build_device(c->stream, ti, tlas, why)) {
             return fail("top-level build failed: %s", why.c_str());
         }
-        if (tlas.nodes.size() > c->nodes_reserved || tlas.group_root.empty() || tlas.group_root[0] == 0xffffffffu) {
+        // two halves, used in turn: the tree the scene view still points at is never overwritten, so a failure further
+        // down (rc 1) leaves a context that renders the previous top level
+        const uint32_t half = c->nodes_reserved / 2;
+        if (tlas.nodes.size() > half || tlas.group_root.empty() || tlas.group_root[0] == 0xffffffffu) {
             (void)fail("no room for a top-level tree of %zu nodes", tlas.nodes.size());
             return 2;
         }
-        const uint32_t base = c->nodes_used;
+        const uint32_t base = c->nodes_used + c->tlas_half * half;
+        c->tlas_half ^= 1u;
         tlas_root = rayhip_update::relocate_top_level(tlas, up, base);
         root_box = tlas.bounds;
         UPLOAD_TRACE("top level built")

@@ -341,4 +341,27 @@ RT_HD bool pixel_owned(const Shard &sh, const int img_w, const int x, const int 
     return ((y / sh.tile) * tiles_x + (x / sh.tile)) % sh.count == sh.index;
 }
 
+// The frame exchange of a tile-sharded render packs the tiles a rank owns DENSELY: owned tile j of rank r is frame tile
+// r + j * N (row-major over the frame's shard tiles), one tile x tile slot each (ragged edge tiles keep their full slot).
+struct ShardTiles {
+    int tiles_x, total; // shard tiles per frame row, in the frame
+};
+RT_HD ShardTiles shard_tiles(const int w, const int h, const int tile) {
+    ShardTiles t;
+    t.tiles_x = (w + tile - 1) / tile;
+    t.total = t.tiles_x * ((h + tile - 1) / tile);
+    return t;
+}
+// tiles rank `index` of `count` owns
+RT_HD int shard_owned_tiles(const int total, const int count, const int index) {
+    return index < total ? (total - index + count - 1) / count : 0;
+}
+// slot `i` of the packed buffer of shard `sh` -> its pixel; false for the padding of a ragged tile
+RT_HD bool shard_slot_pixel(const Shard &sh, const int w, const int h, const int i, int &x, int &y) {
+    const int per_tile = sh.tile * sh.tile, tiles_x = (w + sh.tile - 1) / sh.tile;
+    const int t = sh.index + (i / per_tile) * sh.count, l = i % per_tile;
+    x = (t % tiles_x) * sh.tile + l % sh.tile, y = (t / tiles_x) * sh.tile + l / sh.tile;
+    return x < w && y < h;
+}
+
 } // namespace rt

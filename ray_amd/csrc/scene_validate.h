@@ -50,6 +50,11 @@ inline bool walk_tree(const rayhip_scene_desc &d, const uint32_t root, std::vect
             err = "scene validation: the BVH is not a tree (a node is reachable twice)";
             return false;
         }
+        if (seen[n] == 1 && tag != 1) {
+            // a bottom-level tree that links into the top-level tree: the device would read instance leaves as triangle ranges
+            err = "scene validation: a mesh's BVH links into the top-level tree";
+            return false;
+        }
         if (seen[n] != 0) {
             continue; // a subtree validated through another instance
         }
@@ -158,6 +163,9 @@ inline bool validate(const rayhip_scene_desc &d, std::string &err) {
     auto use_texture = [&](const uint32_t handle) {
         if (handle == NONE) {
             return true;
+        }
+        if ((handle >> 28) >= 8u) {
+            return false; // tex_table has eight storages; the kernels index it with these four bits unchecked
         }
         const uint64_t t = uint64_t(d.tex_table[handle >> 28]) + (handle & 0x00ffffffu);
         if (t >= d.textures_count) {

@@ -80,7 +80,7 @@ ENTRY_POINTS = (
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand", "k_shade",
     "comm_create", "comm_unique_id", "comm_create_rank", "comm_bind", "comm_reduce_framebuffers", "comm_destroy",
-    "export_shard_device",
+    "export_shard_device", "owned_bytes", "export_owned", "import_owned", "finish_import",
 )
 
 
@@ -127,6 +127,11 @@ class Library:
         f("k_shade").argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int), vp,
                                  C.POINTER(C.c_int)]
         f("scene_update_instances_blob").argtypes = [vp, vp, C.c_size_t, C.POINTER(Camera)]
+        f("owned_bytes").argtypes = [vp, C.c_uint32, C.c_int, C.c_int]
+        f("owned_bytes").restype = C.c_size_t
+        f("export_owned").argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+        f("import_owned").argtypes = [vp, C.c_uint32, C.c_int, vp, C.c_size_t]
+        f("finish_import").argtypes = [vp, C.POINTER(Camera)]
         if prefix == "rayhip_":
             f("readback_device").argtypes = [vp, C.c_int, vp, C.c_int]
             f("set_raw_device").argtypes = [vp, vp, C.c_int, C.POINTER(Camera)]
@@ -268,6 +273,19 @@ class Context:
     def export_shard_device(self, which: int, device_ptr: int):
         """this rank's OWNED pixels of image `which` (zero elsewhere) into device memory: the operand of the frame reduce"""
         self.L.check(self.L.fn("export_shard_device")(self._ctx, which, C.c_void_p(device_ptr)))
+
+    # the exchange with the caller's transport (rayhip.h: rayhip_export_owned & co.): the tiles a rank owns, densely packed
+    def owned_bytes(self, what: int, nranks: int, rank: int) -> int:
+        return int(self.L.fn("owned_bytes")(self._ctx, what, nranks, rank))
+
+    def export_owned(self, what: int, device_ptr: int, capacity_bytes: int):
+        self.L.check(self.L.fn("export_owned")(self._ctx, what, C.c_void_p(device_ptr), capacity_bytes))
+
+    def import_owned(self, what: int, from_rank: int, device_ptr: int, nbytes: int):
+        self.L.check(self.L.fn("import_owned")(self._ctx, what, from_rank, C.c_void_p(device_ptr), nbytes))
+
+    def finish_import(self, cam: Camera = None):
+        self.L.check(self.L.fn("finish_import")(self._ctx, C.byref(cam or self.cam)))
 
     def set_shard(self, tile: int, shard_count: int, shard_index: int):
         """multi-GPU tile sharding: render only the tiles whose ordinal % shard_count == shard_index"""

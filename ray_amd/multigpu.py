@@ -4,14 +4,16 @@ The reference has no multi-GPU mode; this is new.  Desig
   * the scene and the PMJ table are replicated on every GPU (a Bistro-class scene is < 1 GB of 288 GB HBM)
   * the frame is cut into 64x64 tiles, walked row-major and dealt round-robin to the ranks (rayhip_set_shard);
     each rank renders ALL iterations of ITS tiles -- no per-bounce or per-iteration communication
-  * pixels are independent (RNG keyed by x, y, iteration), so every rank's RAW buffer is exact on its tiles and
-    zero elsewhere; ONE sum-reduce of the W*H*4 fp32 frame to rank 0 (torch.distributed, backend "nccl" == RCCL
-    over xGMI; 33 MB at 1080p) assembles a frame that is bit-identical to a single-GPU render
-  * rank 0 re-runs the tonemap pass on the combined frame (rayhip_set_raw_device); a rank only ever contributes the
-    pixels it owns (rayhip_export_shard_device), so the combined values rank 0 now holds on foreign pixels never re-enter
-    a later reduce: render more iterations, reduce again -- still exact
-  * C++ hosts get the same exchange behind the C ABI (rayhip_comm_*: RCCL called from librayhip, aux images and variance
-    estimate included so that DenoiseImage works on the root)
+  * pixels are independent (RNG keyed by x, y, iteration), so every rank's RAW buffer is exact on its tiles; the shards
+    are disjoint, so ONE gather of the owned tiles (1/N of the frame per rank, point-to-point to rank 0 over RCCL / xGMI)
+    assembles a frame that is bit-identical to a single-GPU render
+  * three transports, one packing (rayhip.h): `exchange_frame` below with a rayhip_comm (RCCL called from librayhip behind
+    the C ABI -- what bench.py and a C++ host use; aux images and variance estimate included so that DenoiseImage works
+    on the root), with torch.distributed on device tensors (rayhip_export_owned / rayhip_import_owned), or -- for the CPU
+    tests over gloo and for ranks that share one device -- through host memory
+  * rank 0 re-runs the tonemap pass on the combined frame; a rank only ever contributes the pixels it owns, so the
+    combined values rank 0 now holds on foreign pixels never re-enter a later exchange: render more iterations, exchange
+    again -- still exact
 The same code runs on CPU tensors over gloo with the host build of the kernels (tests/test_distributed.py).
 """
 from typing import Iterable, Optional
@@ -73,6 +75,38 @@ def render_sharded(ctx: hip.Context, iterations: Iterable[int], rank: int, world
     if rank == 0 and frame.is_cuda:
         ctx.set_raw_device(frame.data_ptr())
     return frame
+
+
+def exchange_frame(ctx: hip.Context, rank: int, world: int, comm: Optional[hip.Comm] = None, dist=None,
+                   what: int = hip.REDUCE_RADIANCE, via_host: bool = False):
+    """The one exchange step of the path, after the ranks rendered their tiles: rank 0 ends up with the whole frame.
+
+    comm: a rayhip_comm of this rank (RCCL behind the C ABI) -- the product path.  Otherwise `dist` (torch.distributed) moves
+    the packed tiles: device tensors over its RCCL backend, or (`via_host`) host tensors over gloo when several ranks share
+    one device and RCCL therefore cannot form a communicator."""
+    if comm is not None:
+        comm.reduce_framebuffers(0, ctx.cam, what)
+        return
+    import torch
+    sizes = [ctx.owned_bytes(what, world, r) for r in range(world)]
+    cap = max(sizes)  # gather wants equal operands: rank 0 owns the most tiles
+    on_host = ctx.L.prefix != "rayhip_"  # the host build of the kernels (tests): its "device memory" is host memory
+    dev = torch.device("cpu") if on_host else torch.device("cuda", torch.cuda.current_device())
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if rank != 0:
+        ctx.export_owned(what, mine.data_ptr(), cap)
+    if via_host or on_host:
+        parts = [torch.zeros(cap, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine.cpu(), parts, dst=0)
+        parts = [p.to(dev) for p in parts] if rank == 0 else None
+    else:
+        parts = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, parts, dst=0)
+        torch.cuda.current_stream(dev).synchronize()  # the collective is only enqueued; librayhip works on its own stream
+    if rank == 0:
+        for r in range(1, world):
+            ctx.import_owned(what, r, parts[r].data_ptr(), sizes[r])
+        ctx.finish_import()
 
 
 def owned_pixel_mask(w: int, h: int, rank: int, world: int, tile: int = TILE) -> np.ndarray:

@@ -576,6 +576,84 @@ HS_API int hostsim_set_shard(hostsim_ctx *c, int tile, int shard_count, int shar
     return 0;
 }
 
+// the exchange of a tile-sharded render with the caller's transport (twins of rayhip_owned_bytes / _export_owned / _import_owned /
+// _finish_import over the same slot <-> pixel mapping, rt_base.h: shard_slot_pixel); images: running mean, base colour,
+// depth-normals (this build keeps no separate variance image)
+namespace {
+int hs_selected(uint32_t what, std::vector<float4> *out[3], hostsim_ctx *c) {
+    if (what == 0) {
+        what = 7u;
+    }
+    int n = 0;
+    std::vector<float4> *all[3] = {&c->full, &c->base_color, &c->depth_normals};
+    for (int k = 0; k < 3; ++k) {
+        if (what & (1u << k)) {
+            out[n++] = all[k];
+        }
+    }
+    return n;
+}
+} // namespace
+HS_API size_t hostsim_owned_bytes(hostsim_ctx *c, uint32_t what, int nranks, int rank) {
+    std::vector<float4> *sel[3];
+    const int n_sel = hs_selected(what, sel, c);
+    const ShardTiles st = shard_tiles(c->w, c->h, c->shard.tile);
+    return size_t(shard_owned_tiles(st.total, nranks, rank)) * size_t(c->shard.tile) * size_t(c->shard.tile) * 16u * size_t(n_sel);
+}
+HS_API int hostsim_export_owned(hostsim_ctx *c, uint32_t what, void *dst, size_t capacity) {
+    std::vector<float4> *sel[3];
+    const int n_sel = hs_selected(what, sel, c);
+    if (hostsim_owned_bytes(c, what, c->shard.count, c->shard.index) > capacity) {
+        g_err = "hostsim_export_owned: destination too small";
+        return 1;
+    }
+    const ShardTiles st = shard_tiles(c->w, c->h, c->shard.tile);
+    const int n = shard_owned_tiles(st.total, c->shard.count, c->shard.index) * c->shard.tile * c->shard.tile;
+    float4 *out = static_cast<float4 *>(dst);
+    for (int k = 0; k < n_sel; ++k) {
+        for (int i = 0; i < n; ++i) {
+            int x, y;
+            out[size_t(k) * n + i] = shard_slot_pixel(c->shard, c->w, c->h, i, x, y) ? (*sel[k])[size_t(y) * c->w + x] : float4{0, 0, 0, 0};
+        }
+    }
+    return 0;
+}
+HS_API int hostsim_import_owned(hostsim_ctx *c, uint32_t what, int from_rank, const void *src, size_t bytes) {
+    std::vector<float4> *sel[3];
+    const int n_sel = hs_selected(what, sel, c);
+    if (from_rank < 0 || from_rank >= c->shard.count || bytes < hostsim_owned_bytes(c, what, c->shard.count, from_rank)) {
+        g_err = "hostsim_import_owned: bad rank or short buffer";
+        return 1;
+    }
+    if (from_rank == c->shard.index) {
+        return 0;
+    }
+    const Shard sender = {c->shard.tile, c->shard.count, from_rank};
+    const ShardTiles st = shard_tiles(c->w, c->h, c->shard.tile);
+    const int n = shard_owned_tiles(st.total, c->shard.count, from_rank) * c->shard.tile * c->shard.tile;
+    const float4 *in = static_cast<const float4 *>(src);
+    for (int k = 0; k < n_sel; ++k) {
+        for (int i = 0; i < n; ++i) {
+            int x, y;
+            if (shard_slot_pixel(sender, c->w, c->h, i, x, y)) {
+                (*sel[k])[size_t(y) * c->w + x] = in[size_t(k) * n + i];
+            }
+        }
+    }
+    return 0;
+}
+HS_API int hostsim_finish_import(hostsim_ctx *c, const rayhip_camera *cam) {
+    const int rect[4] = {0, 0, c->w, c->h};
+    AccumParams ap = make_accum_params(*cam, c->w, rect, 1);
+    ap.lut = c->tonemap_lut.empty() ? nullptr : c->tonemap_lut.data(), ap.lut_dims = c->lut_dims;
+    for (size_t i = 0; i < c->full.size(); ++i) {
+        c->raw[i] = c->full[i];
+        const f4 t = tonemap(ap, f4{c->full[i].x, c->full[i].y, c->full[i].z, c->full[i].w});
+        c->final_[i] = float4{t.x, t.y, t.z, t.w};
+    }
+    return 0;
+}
+
 HS_API int hostsim_get_trav_counters(hostsim_ctx *c, rayhip_trav_counters out[2], int reset) {
     out[0] = c->counters[0], out[1] = c->counters[1];
     if (reset) {

@@ -134,3 +134,53 @@ def test_a_texture_outside_the_texel_pool_is_refused():
     bad = patched(blob, "textures", 96, "<I", 0x7ffffff0)  # offset[0] of the first texture
     with pytest.raises(RuntimeError):
         upload(bad)
+
+
+def test_a_texture_handle_beyond_the_eight_storages_is_refused():
+    """handle >> 28 selects one of EIGHT storages (tex_table[8]); values 8..15 would index behind the table -- on the host into
+    the fields that follow it in the desc, on the device into other fields of the scene view, so a sum that happens to pass on
+    the host bounds nothing on the device.  Every material whose slot the shade stage reads is patched (the pool is sparse)."""
+    blob = util.golden_scene("cornell_principled")
+    _, off, size = sections(blob)["materials"]
+    hit = 0
+    bad = bytearray(blob)
+    for m in range(size // 76):
+        for k in range(5):
+            h = struct.unpack_from("<I", blob, off + 76 * m + 4 * k)[0]
+            if h != 0xffffffff and (h >> 28) < 8 and struct.unpack_from("<I", blob, off + 76 * m + 36)[0] != 4:  # not a mix node
+                struct.pack_into("<I", bad, off + 76 * m + 4 * k, (h & 0x0fffffff) | (0xb << 28))
+                hit += 1
+    assert hit > 0
+    with pytest.raises(RuntimeError) as e:
+        upload(bytes(bad))
+    print(e.value)
+    assert "texture" in str(e.value)
+    # and the environment map handles (rayhip_environment: env_col[3], env_map, back_col[3], back_map, ...)
+    for word in (3, 7):
+        with pytest.raises(RuntimeError) as e:
+            upload(patched(blob, "scalars", 32 + 4 * word, "<I", 0x90000000))
+        assert "environment map" in str(e.value)
+
+
+def test_a_mesh_tree_that_links_into_the_top_level_is_refused():
+    """an instance whose BLAS root IS the top-level root: the device would read instance leaves as triangle ranges"""
+    blob = util.golden_scene("cornell_instances")
+    s = sections(blob)
+    tlas_root = struct.unpack_from("<I", blob, s["scalars"][1] + 32 + 64)[0]
+    _, off, size = s["nodes"]
+    nodes = np.frombuffer(blob, dtype=np.uint32, count=size // 4, offset=off).reshape(-1, 16)
+    if int(nodes[tlas_root, 12]) & (7 << 29) and int(nodes[tlas_root, 13]) & (7 << 29):
+        pytest.skip("the top level is a single node of two leaves")
+    # first live instance (reachable from the top level)
+    stack, mi = [int(tlas_root)], None
+    while stack and mi is None:
+        w = stack.pop()
+        if w & (7 << 29):
+            mi = w & ~(7 << 29)
+        else:
+            stack += [int(nodes[w, 12]), int(nodes[w, 13])]
+    bad = patched(blob, "mesh_instances", 144 * mi + 4, "<I", tlas_root)
+    with pytest.raises(RuntimeError) as e:
+        upload(bad)
+    print(e.value)
+    assert "top-level" in str(e.value) or "not a tree" in str(e.value)

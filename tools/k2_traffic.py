@@ -69,6 +69,9 @@ def main():
              "launches_sampled": len(f), "launches_per_pass": per_pass,
              "fetch_bytes_per_launch": fsum / max(len(f), 1), "write_bytes_per_launch": wsum / max(len(w), 1),
              "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) -- python bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline"}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    entry["csrc_hash"] = bench.csrc_hash()  # the kernels this profile belongs to (bench.py marks it stale for any other)
     if dd:
         entry["avg_launch_ms"] = sum(v for _, _, v in dd) / len(dd)
         entry["hbm_GBps_under_profiler"] = (entry["fetch_bytes_per_launch"] + entry["write_bytes_per_launch"]) / 1e9 / (entry["avg_launch_ms"] / 1e3)
