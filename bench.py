@@ -36,8 +36,8 @@ all per launch:
                profile was taken; null when the workload was never profiled
   achieved     = traffic / launch time when traffic is known (the north star's figure: "achieved HBM GB/s from rocprof
                against the chip's memory roofline"), else the kernel's own algorithmic rate; frac = achieved / 8 TB/s
-  algorithmic  the kernel's OWN algorithmic bytes: 72+20+4 per ray + 64 per TLAS node + 64 per 4-wide node + 48 per
-               triangle + 144 per instance, counted by the instrumented product kernel (RAYHIP_FLAG_COUNT_WIDE) on iterations
+  algorithmic  the kernel's OWN algorithmic bytes: 72+20+4 per ray + 64 per TLAS node + 80 per 8-wide node (64 per 4-wide
+               node with RAYHIP_BVH_WIDTH=4) + 48 per triangle + 144 per instance, counted by the instrumented product kernel (RAYHIP_FLAG_COUNT_WIDE) on iterations
                of the same workload right after the timed region; next to it the same for the reference's BVH2 walk
                (SURVEY 8d's formula, RAYHIP_FLAG_COUNT_TRAVERSAL) -- what a cache-less machine would have to move
 cpu_baseline: the reference's own AVX2 backend (oracle/_ref, kind "reference"), one persistent pool of worker threads (as
@@ -339,7 +339,11 @@ def main():
     # exists -- and is touched -- before the first pass, the blob stays referenced until after it, and the garbage collector
     # rests.  (A C++ host has the same rule: allocate the read-back buffer once.)
     import gc
-    host_frame = np.zeros((H, W, 4), dtype=np.float32) if dist is None else None
+    # ... in page-locked memory: the device copies straight into it, and a pageable
+    # np.zeros buffer is not even mapped before its first write (first process on a box: 7 ms of page faults inside the region)
+    host_frame = torch.zeros((H, W, 4), dtype=torch.float32).pin_memory().numpy() if dist is None else None
+    if host_frame is not None:
+        host_frame.fill(0.0)
     gc.collect()
     gc.disable()
     it = 0
@@ -422,8 +426,11 @@ def main():
             ctx.render(it, flags=flag)
         return ctx.trav_counters(reset=True)
 
+    bvh_width = ctx.bvh_width()
+    wide_node_bytes = 80 if bvh_width == 8 else 64  # what a node visit reads: the 8-wide node uses 80 bytes of its 128-byte line
+
     def alg_bytes(c, per_ray):
-        return (per_ray * c["rays"] + 64 * (c["nodes"] + c.get("nodes4", 0)) + 48 * c["tris"] + 144 * c["instances"]) * scale
+        return (per_ray * c["rays"] + 64 * c["nodes"] + wide_node_bytes * c.get("nodes4", 0) + 48 * c["tris"] + 144 * c["instances"]) * scale
 
     w2, w3 = count_pass(hip.FLAG_COUNT_WIDE)
     c2, c3 = count_pass(hip.FLAG_COUNT_TRAVERSAL)
@@ -457,7 +464,7 @@ def main():
                        "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 gather of the owned tiles per frame over RCCL)",
                        "iterations_per_pass": batch},
             "roofline": {
-                "bound": "hbm", "kernel": "K2 closest-hit traversal: k_trace_closest_refill (secondary bounces) + k_trace_closest<false,true> (primary rays)",
+                "bound": "hbm", "kernel": f"K2 closest-hit traversal over the {bvh_width}-wide BLAS: k_trace_closest_refill<{bvh_width}> (secondary bounces) + k_trace_closest<false,{bvh_width}> (primary rays)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "achieved_is": (("HBM traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE of a profiled run of this command) / launch time"
                                  if traffic.get("exact") else
@@ -473,7 +480,8 @@ def main():
                 "algorithmic": {
                     "bytes_per_launch": k2_bytes / launches, "GBps": alg_gbs, "frac_of_peak": alg_gbs / HBM_PEAK_GBS,
                     "bytes_per_ray": k2_bytes / scale / max(w2["rays"], 1),
-                    "tlas_nodes_per_ray": w2["nodes"] / max(w2["rays"], 1), "nodes4_per_ray": w2["nodes4"] / max(w2["rays"], 1),
+                    "bvh_width": bvh_width, "wide_node_bytes": wide_node_bytes,
+                    "tlas_nodes_per_ray": w2["nodes"] / max(w2["rays"], 1), "wide_nodes_per_ray": w2["nodes4"] / max(w2["rays"], 1),
                     "tris_per_ray": w2["tris"] / max(w2["rays"], 1),
                     "reference_bvh2": {"bytes_per_launch": k2_bytes_ref / launches,
                                        "bytes_per_ray": k2_bytes_ref / scale / max(c2["rays"], 1),

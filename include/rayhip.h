@@ -337,6 +337,12 @@ RAYHIP_API int rayhip_scene_upload(rayhip_ctx *ctx, const rayhip_scene_desc *des
  * but instance / light arrays may already be the new ones: re-send the scene with rayhip_scene_upload. */
 RAYHIP_API int rayhip_scene_update_instances(rayhip_ctx *ctx, const rayhip_scene_desc *desc);
 
+/* which acceleration-structure form the traversal kernels walk for the uploaded scene: 8 = the 8-wide quantised BLAS
+ * (ray_amd/csrc/rt_bvh8.h, the default), 4 = the 4-wide one (rt_bvh4.h; RAYHIP_BVH_WIDTH=4, or the 8-wide collapse was not
+ * possible), 2 = the reference's BVH2 as handed over; 0 = no scene.  (What the algorithmic-bytes figure of bench.py prices a
+ * node visit with: 80 / 64 / 64 bytes.) */
+RAYHIP_API int rayhip_scene_bvh_width(rayhip_ctx *ctx);
+
 /* Same upload from a serialised scene (ray_amd/csrc/scene_blob.h; written by the reference-side SceneHIP or by
  * tests/golden/make_fixtures.py): uploads the arrays AND the filter table stored in the blob and returns the
  * camera stored with it.  `blob` must be 16-byte aligned. */
@@ -409,14 +415,16 @@ RAYHIP_API int rayhip_set_raw_device(rayhip_ctx *ctx, const void *src_device_rgb
  * frame), straight to the root (ncclSend / ncclRecv in one group: N - 1 point-to-point links in parallel), which scatters
  * them into its images.  Copies are exact: the result equals a single-GPU render bit for bit and the call can be
  * repeated after more iterations (progressive refinement).
- *   rayhip_comm_create            one process drives all `ndev` GPUs (ncclCommInitAll): what a C++ host using RendererHIP does
+ *   rayhip_comm_create            one process drives all `ndev` GPUs (what RendererHIP does with RAY_HIP_DEVICES): the root pulls the
+ *                                 senders' tiles with peer copies on its stream -- no collective library; ranks may share a device
  *   rayhip_comm_unique_id +       one process per GPU: rank 0 makes the id, hands its RAYHIP_COMM_ID_BYTES bytes to the other
  *   rayhip_comm_create_rank       processes by its own means, every process creates its rank (ncclCommInitRank) -- collective
  *   rayhip_comm_bind              attach the context of `rank` (a GPU of `devices[rank]`); also sets its shard to (tile, N, rank)
  *   rayhip_comm_reduce_framebuffers   `what`: RAYHIP_REDUCE_* mask, 0 = all four images.  On return the root context holds the
  *                                 combined running mean (RAW, and FINAL re-tonemapped with `cam`), aux images and variance
  *                                 estimate, i.e. everything DenoiseImage reads.  Blocking (synchronises the local streams).
- * RCCL is loaded on first use (dlopen librccl.so.1; RAYHIP_RCCL_LIB overrides); librayhip itself does not link it. */
+ * RCCL is only used by the one-process-per-GPU form and loaded on first use (dlopen librccl.so.1; RAYHIP_RCCL_LIB
+ * overrides); librayhip itself does not link it. */
 typedef struct rayhip_comm rayhip_comm;
 #define RAYHIP_COMM_ID_BYTES 128
 enum {

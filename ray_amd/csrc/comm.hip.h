@@ -12,8 +12,14 @@
 // bit, and DenoiseImage on the root sees the complete guides.  A rank's accumulation state is never overwritten on pixels
 // it owns, so progressive refinement (render more, gather again) stays exact.
 //
-// RCCL is loaded with dlopen when the first communicator is created: librayhip.so has no link-time dependency on it, and
-// inside a process that already carries an RCCL (PyTorch) the loaded copy is reused.
+// Two transports, one packing:
+//   * rayhip_comm_create -- ONE process drives all GPUs (a C++ host using RendererHIP with RAY_HIP_DEVICES): the root pulls
+//     every sender's buffer with hipMemcpyPeerAsync on its own stream, ordered behind the sender's pack kernel by an event:
+//     plain peer DMA over the sender's xGMI link, no collective library involved (and two contexts may share a device,
+//     which is how the path is tested on a one-GPU box);
+//   * rayhip_comm_unique_id + rayhip_comm_create_rank -- one process per GPU (bench.py under torch.distributed.run): ncclSend /
+//     ncclRecv in one group.  RCCL is loaded with dlopen when the first such communicator is created: librayhip.so has no
+//     link-time dependency on it, and inside a process that already carries an RCCL (PyTorch) the loaded copy is reused.
 #pragma once
 
 #include <dlfcn.h>
@@ -107,9 +113,12 @@ int comm_selected(uint32_t mask, int out[COMM_IMAGES]) {
 
 struct rayhip_comm {
     int nranks = 0;             // ranks of the communicator
+    bool in_process = false;    // rayhip_comm_create: every rank is a context of this process, transport = peer copies
     std::vector<int> local;     // ranks this process drives (all of them for rayhip_comm_create, one for _create_rank)
-    std::vector<ncclComm_t> comms;
+    std::vector<ncclComm_t> comms; // (one-process-per-GPU form only)
     std::vector<rayhip_ctx *> ctx;
+    std::vector<hipEvent_t> packed; // in-process form: "this rank's tiles are packed", recorded on its stream
+    std::vector<int> devices;
 };
 
 namespace {
@@ -166,21 +175,35 @@ int rayhip_comm_create(int ndev, const int *devices, rayhip_comm **out) {
     if (ndev < 1 || !devices || !out) {
         return fail("rayhip_comm_create: bad arguments");
     }
-    if (load_rccl()) {
-        return 1;
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have == 0) {
+        return fail("no HIP device available (librayhip has no CPU path)");
     }
     rayhip_comm *m = new rayhip_comm();
     m->nranks = ndev;
-    m->comms.resize(size_t(ndev));
+    m->in_process = true;
     m->ctx.assign(size_t(ndev), nullptr);
+    m->packed.assign(size_t(ndev), nullptr);
     for (int r = 0; r < ndev; ++r) {
+        if (devices[r] < 0 || devices[r] >= have) {
+            delete m;
+            return fail("rayhip_comm_create: device %d out of range (have %d)", devices[r], have);
+        }
         m->local.push_back(r);
+        m->devices.push_back(devices[r]);
     }
-    const ncclResult_t r = g_rccl.CommInitAll(m->comms.data(), ndev, devices);
-    if (r != ncclSuccess) {
-        delete m;
-        return fail("ncclCommInitAll failed: %s", g_rccl.GetErrorString(r));
+    // direct peer access where the devices allow it (the copy works either way; without it the runtime stages through the host)
+    for (int a = 0; a < ndev; ++a) {
+        for (int b = 0; b < ndev; ++b) {
+            int can = 0;
+            if (devices[a] != devices[b] && hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+                if (hipSetDevice(devices[a]) == hipSuccess) {
+                    (void)hipDeviceEnablePeerAccess(devices[b], 0); // (already enabled: an error that does not matter)
+                }
+            }
+        }
     }
+    (void)hipGetLastError();
     *out = m;
     return 0;
 }
@@ -226,8 +249,15 @@ int rayhip_comm_bind(rayhip_comm *m, int rank, rayhip_ctx *ctx) {
     }
     for (size_t i = 0; i < m->local.size(); ++i) {
         if (m->local[i] == rank) {
+            if (m->in_process && ctx->device != m->devices[i]) {
+                return fail("rank %d was created for device %d, the context lives on device %d", rank, m->devices[i], ctx->device);
+            }
             m->ctx[i] = ctx;
             ctx->shard = Shard{ctx->shard.tile, m->nranks, rank}; // rank r renders the tiles r, r + N, r + 2N, ...
+            if (m->in_process && !m->packed[i]) {
+                HIP_TRY(hipSetDevice(ctx->device));
+                HIP_TRY(hipEventCreateWithFlags(&m->packed[i], hipEventDisableTiming));
+            }
             return 0;
         }
     }
@@ -275,7 +305,26 @@ int rayhip_comm_reduce_framebuffers(rayhip_comm *m, int root, uint32_t what, con
             return 1;
         }
     }
-    if (m->nranks > 1) {
+    if (m->in_process) {
+        // the root pulls every sender's buffer: a peer copy on ITS stream, behind the event the sender records after packing
+        rayhip_ctx *rc = nullptr;
+        for (size_t i = 0; i < m->ctx.size(); ++i) {
+            rc = m->local[i] == root ? m->ctx[i] : rc;
+        }
+        for (size_t i = 0; i < m->ctx.size(); ++i) {
+            rayhip_ctx *c = m->ctx[i];
+            const size_t n = comm_rank_floats(w, h, tile, m->nranks, m->local[i], n_sel);
+            if (m->local[i] == root || n == 0) {
+                continue;
+            }
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipEventRecord(m->packed[i], c->stream));
+            HIP_TRY(hipSetDevice(rc->device));
+            HIP_TRY(hipStreamWaitEvent(rc->stream, m->packed[i], 0));
+            HIP_TRY(hipMemcpyPeerAsync(rc->shard_stage.as<float>() + region[size_t(m->local[i])], rc->device, c->shard_stage.p, c->device,
+                                       n * sizeof(float), rc->stream));
+        }
+    } else if (m->nranks > 1) {
         RCCL_TRY(g_rccl.GroupStart());
         ncclResult_t r = ncclSuccess;
         for (size_t i = 0; i < m->ctx.size() && r == ncclSuccess; ++i) {
@@ -332,6 +381,11 @@ void rayhip_comm_destroy(rayhip_comm *m) {
     for (size_t i = 0; i < m->comms.size(); ++i) {
         if (m->comms[i] && g_rccl.CommDestroy) {
             (void)g_rccl.CommDestroy(m->comms[i]);
+        }
+    }
+    for (hipEvent_t e : m->packed) {
+        if (e) {
+            (void)hipEventDestroy(e);
         }
     }
     delete m;

@@ -74,15 +74,11 @@ namespace rt {
 //                        spill to a per-wave slab in HBM (same depth-major layout), so any depth up to
 //                        RT_STACK_TOTAL_DEPTH stays correct; SAH trees of the Bistro-class scene use <= 17.
 //   RT_TRACE_MIN_WAVES   __launch_bounds__ occupancy hint (waves per SIMD) for the traversal kernels
-//   RT_SHADE_MIN_WAVES   same for the shade kernel
 #ifndef RT_LDS_STACK_DEPTH
 #define RT_LDS_STACK_DEPTH 24
 #endif
 #ifndef RT_TRACE_MIN_WAVES
 #define RT_TRACE_MIN_WAVES 6 // 80 VGPRs.  Sweep with the final kernels, 32-iteration passes: 4 waves 289, 5 waves 319, 6 waves 328 Msamples/s
-#endif
-#ifndef RT_SHADE_MIN_WAVES
-#define RT_SHADE_MIN_WAVES 3 // 168 VGPRs: with the final kernels 2.10 ms/iteration vs 2.32 at 2 waves (215 VGPRs) and at 4 (128 VGPRs, 284 B scratch)
 #endif
 constexpr int LDS_STACK_DEPTH = RT_LDS_STACK_DEPTH;
 constexpr int STACK_TOTAL_DEPTH = 2 * MAX_STACK_SIZE; // TLAS + BLAS, 48 each in the reference
@@ -126,6 +122,26 @@ struct LdsStack {
             return lane_base[idx * WAVE];
         }
         return idx < uint32_t(STACK_TOTAL_DEPTH) ? spill_base[(idx - LDS_STACK_DEPTH) * WAVE] : 0x1fffffffu;
+    }
+    // two-word entries of the 8-wide walk (rt_bvh8.h): slots idx and idx + 1 (one address, two immediate offsets -> a single
+    // ds_write2st64_b32 / ds_read2st64_b32 while both are in the LDS part)
+    __device__ __forceinline__ void write2_at(const uint32_t idx, const uint32_t a, const uint32_t b) {
+        if (idx + 2 <= uint32_t(LDS_STACK_DEPTH)) {
+            uint32_t *p = lane_base + idx * WAVE;
+            p[0] = a, p[WAVE] = b;
+        } else {
+            write_at(idx, a), write_at(idx + 1, b);
+        }
+    }
+    __device__ __forceinline__ void read2_at(const uint32_t idx, uint32_t &a, uint32_t &b) const {
+        if (idx + 2 <= uint32_t(LDS_STACK_DEPTH)) {
+            const uint32_t *p = lane_base + idx * WAVE;
+            a = p[0], b = p[WAVE];
+        } else if (idx + 2 <= uint32_t(STACK_TOTAL_DEPTH)) {
+            a = read_at(idx), b = read_at(idx + 1);
+        } else {
+            a = 0xffffffffu, b = 0u; // beyond every stack: the walk's own sentinel (as read_at hands out the BVH2 one)
+        }
     }
 };
 
@@ -222,15 +238,16 @@ __device__ __forceinline__ void flush_trav_count(unsigned long long *__restrict_
 
 // ---- K2 ---------------------------------------------------------------------------------------------------
 // One ray per lane; grid-stride over the device-resident ray count.
-// COUNT: with visit counters; WIDE: 4-wide BLAS (rt_bvh4.h).  <true, false> = instrumented walk of the reference's BVH2
-// (counters = the reference algorithm's bytes), <true, true> = the product walk with counters (its OWN algorithmic bytes)
+// COUNT: with visit counters; WIDE: 0 = the reference's BVH2, 4 / 8 = the quantised wide BLAS (rt_bvh4.h / rt_bvh8.h).
+// <true, 0> = instrumented walk of the reference's BVH2 (counters = the reference algorithm's bytes), <true, 4 | 8> = the
+// product walk with counters (its OWN algorithmic bytes)
 // MINW: occupancy hint.  The default (6 waves/SIMD, 80 VGPRs, some spills outside the hot loop) is best when node and
 // triangle fetches miss the caches; a scene that fits L2 (RT_TRACE_SMALL_WAVES = 5: 96 VGPRs, fewer spills) has little
 // latency to hide and runs 15 % faster in K2 with the smaller footprint (Cornell: 0.42 -> 0.35 ms per iteration).
 #ifndef RT_TRACE_SMALL_WAVES
 #define RT_TRACE_SMALL_WAVES 5
 #endif
-template <bool COUNT, bool WIDE, int MINW = RT_TRACE_MIN_WAVES>
+template <bool COUNT, int WIDE, int MINW = RT_TRACE_MIN_WAVES>
 __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc, const TraceParams tp, const RaySoA rays,
                                                        const HitSoA hits, const RayQueue queue,
                                                        const int init_hits, uint32_t *__restrict__ stack_spill,
@@ -350,6 +367,7 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 #ifndef RT_REFILL_MIN_WAVES
 #define RT_REFILL_MIN_WAVES 5 // 96 VGPRs, no scratch (6 waves: 80 VGPRs with spills in the loop, slower)
 #endif
+template <int WIDE>
 __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_refill(const SceneView sc, const TraceParams tp, const RaySoA rays,
                                                                const HitSoA hits, const RayQueue queue, const int init_hits,
                                                                uint32_t *__restrict__ stack_spill, const Layering layers) {
@@ -372,8 +390,11 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
 #ifdef RT_PROFILE_TRACE
     uint32_t st_a = 0, st_b = 0, st_iter = 0; // (uniform)
 #endif
-    // lane state
+    // lane state.  4-wide: `cur` / `tos` are node words at both levels.  8-wide (rt_bvh8.h): inside an instance `cur` / `tos` are the
+    // child_base of the current / topmost group and `cur_bits` / `tos_bits` their pending masks, (`tri_base`, `l0`, `l1`) the hit leaf
+    // children of the node visited last; at the top level they are BVH2 node words as before.
     uint32_t lvl = IDLE, slot = 0, cur = BVH4_SENTINEL, tos = BVH4_SENTINEL, size = 0, mi_index = 0, ray_flags = 0;
+    uint32_t cur_bits = 0, tos_bits = 0, tri_base = 0, l0 = 0, l1 = 0, oct_inv = 0;
     bool res = false;
     f3 ro = {0.0f, 0.0f, 0.0f}, rd = {0.0f, 0.0f, 1.0f}; // world-space origin of the current transparency segment, direction
     f3 o = ro, d = rd, inv_d = rd;                        // object-space ray of the instance being walked
@@ -398,10 +419,21 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
     };
     // the pop that ends a BLAS walk hands back the sentinel and restores the TLAS `tos`: continue the TLAS walk
     auto leave_blas = [&]() {
-        if (lvl == BLAS && cur == BVH4_SENTINEL) {
+        if (WIDE == 8) {
+            if (lvl == BLAS && cur == BVH8_SENTINEL) { // (a real group never stays current once it is exhausted: pop8)
+                lvl = TLAS;
+                cur = st.read_at(--size); // the top-level `tos` saved at the entry of the instance
+                tos = st.read_at(--size);
+            }
+        } else if (lvl == BLAS && cur == BVH4_SENTINEL) {
             lvl = TLAS;
             pop();
         }
+    };
+    auto pop8 = [&]() {
+        cur = tos, cur_bits = tos_bits;
+        size -= 2;
+        st.read2_at(size, tos, tos_bits);
     };
 
     uint32_t n_dead = 0; // idle lanes that can no longer be refilled (uniform)
@@ -410,7 +442,8 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
         // as RT_REFILL_MIN lanes wait outside for the service part below
         for (;;) {
             const bool in_blas = (lvl == BLAS);
-            const bool at_leaf = in_blas && (cur & BVH2_PRIM_COUNT_BITS) != 0; // (the sentinel never stays in `cur`: leave_blas)
+            // (the sentinel never stays in `cur`: leave_blas)
+            const bool at_leaf = in_blas && (WIDE == 8 ? (l0 | l1) != 0u : (cur & BVH2_PRIM_COUNT_BITS) != 0);
             const bool at_node = in_blas && !at_leaf;
             const int n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf));
             const int n_out = WAVE - n_node - n_leaf - int(n_dead);
@@ -422,15 +455,37 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
             }
             if (__builtin_amdgcn_readfirstlane(int(n_node >= n_leaf))) {
                 if (at_node) {
-                    bvh4_visit(sc.nodes4, o, inv_d, h.t, st, cur, tos, size);
+                    if (WIDE == 8) {
+                        const uint32_t node = bvh8_take_child(cur, cur_bits, oct_inv);
+                        if ((cur_bits >> 8) != 0u) { // siblings remain: the group goes onto the stack
+                            st.write2_at(size, tos, tos_bits);
+                            size += 2;
+                            tos = cur, tos_bits = cur_bits;
+                        }
+                        Bvh8Visit v;
+                        bvh8_test_node(sc.nodes8, node, o, inv_d, h.t, oct_inv, v);
+                        cur = v.child_base, cur_bits = v.bits, tri_base = v.tri_base, l0 = v.leaf[0], l1 = v.leaf[1];
+                        if ((cur_bits >> 8) == 0u && (l0 | l1) == 0u) {
+                            pop8();
+                        }
+                    } else {
+                        bvh4_visit(sc.nodes4, o, inv_d, h.t, st, cur, tos, size);
+                    }
                     leave_blas();
                 }
                 RT_PROF_T(19)
             } else {
                 if (at_leaf) {
-                    const int tri_start = int(cur & BVH2_PRIM_INDEX_BITS), tri_end = int(tri_start + ((cur & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
+                    const uint32_t word = WIDE == 8 ? bvh8_take_leaf(tri_base, l0, l1) : cur;
+                    const int tri_start = int(word & BVH2_PRIM_INDEX_BITS), tri_end = int(tri_start + ((word & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
                     res |= intersect_tris_closest(o, d, sc.tris, tri_start, tri_end, int(mi_index), h);
-                    pop();
+                    if (WIDE == 8) {
+                        if ((l0 | l1) == 0u && (cur_bits >> 8) == 0u) {
+                            pop8();
+                        }
+                    } else {
+                        pop();
+                    }
                     leave_blas();
                 }
                 RT_PROF_T(26)
@@ -561,8 +616,17 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                         d = transform_direction(rd, inst.inv_xform);
                         inv_d = safe_invert(d);
                         st.write_at(size++, tos); // the TLAS walk resumes from here
-                        tos = BVH4_SENTINEL;
-                        cur = sc.blas_root4[mi];
+                        if (WIDE == 8) {
+                            oct_inv = bvh8_oct_inv(inv_d);
+                            st.write2_at(size, BVH8_SENTINEL, 0u); // (second sentinel: the read-ahead of a pop stays inside this level)
+                            size += 2;
+                            tos = BVH8_SENTINEL, tos_bits = 0u;
+                            cur = sc.blas_root4[mi], cur_bits = (1u << (8u + oct_inv)) | 1u; // a virtual group holding the root in slot 0
+                            l0 = l1 = 0u;
+                        } else {
+                            tos = BVH4_SENTINEL;
+                            cur = sc.blas_root4[mi];
+                        }
                         lvl = BLAS;
                         leave_blas(); // (a BLAS whose root is the sentinel: nothing to walk)
                     } else {
@@ -586,7 +650,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
 }
 
 // ---- K3 ---------------------------------------------------------------------------------------------------
-template <bool COUNT, bool WIDE, int MINW = RT_TRACE_MIN_WAVES>
+template <bool COUNT, int WIDE, int MINW = RT_TRACE_MIN_WAVES>
 __global__ void __launch_bounds__(WAVE, MINW) k_trace_shadow(const SceneView sc, const TraceParams tp, const ShadowSoA shadow,
                                                       const RayQueue queue, const float limit,
                                                       const int img_w, float4 *__restrict__ temp_buf,

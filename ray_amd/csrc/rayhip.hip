@@ -21,6 +21,7 @@
 #include "kernels.hip.h" // first: it configures the profiling macros the rt_*.h headers expand
 #include "shade_launch.h"
 #include "bvh4_build.h"
+#include "bvh8_build.h"
 #include "bvh_layout.h"
 #include "lbvh.hip.h"
 #include "scene_blob.h"
@@ -110,7 +111,7 @@ struct rayhip_ctx {
     DevBuf pmj, filter_table;
     // scene
     DevBuf nodes, tris, tri_indices, tri_materials, materials, vertices, vtx_indices, mesh_instances, lights, li_indices,
-        light_cwnodes, light_children, light_tri_geom, tri_verts, tri_bitangents, textures, texels, nodes4, blas_root4, env_qtree;
+        light_cwnodes, light_children, light_tri_geom, tri_verts, tri_bitangents, textures, texels, nodes4, nodes8, blas_root4, env_qtree;
     SceneView sc = {};
     float bbox_min[3] = {}, bbox_max[3] = {};
     bool have_scene = false;
@@ -130,7 +131,7 @@ struct rayhip_ctx {
     rayhip_update::MeshRefs mesh_refs;
     uint32_t nodes_used = 0, nodes_reserved = 0;
     uint32_t tlas_half = 0; // which half of the reserved node slots the next rebuilt top level goes to (the live one sits in the other)
-    bool have_wide = false;
+    int wide = 0; // the wide BLAS form the kernels walk: 8 (rt_bvh8.h, default), 4 (rt_bvh4.h) or 0 (the reference's BVH2)
     uint32_t tex_table[8] = {}, textures_count = 0, tex_flags = 0;
     struct { uint32_t vertices, vtx_indices, tri_materials, materials; } geometry = {};
     bool adaptive_dirty = false; // a pass ran with variance_threshold != 0 since the last Clear / Resize: required_samples may
@@ -413,7 +414,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     g_touch_stream = c->stream;
     // persistent grid of the wave-per-block kernels: as many blocks as are resident (LDS stack + VGPR budget)
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false, true>, WAVE, 0) != hipSuccess || per_cu <= 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false, 8>, WAVE, 0) != hipSuccess || per_cu <= 0) {
         per_cu = 8;
     }
     // 16x more blocks than are resident: each block then owns 1/16 of the chunks a resident wave would, and the
@@ -450,7 +451,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         const int mode = getenv("RAYHIP_REFILL") != nullptr ? atoi(getenv("RAYHIP_REFILL")) : 2;
         if (mode != 0) {
             int per_cu_refill = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_refill, k_trace_closest_refill, WAVE, 0) != hipSuccess || per_cu_refill <= 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_refill, k_trace_closest_refill<8>, WAVE, 0) != hipSuccess || per_cu_refill <= 0) {
                 per_cu_refill = per_cu;
             }
             int refill_mult = 16;
@@ -494,7 +495,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         (void)hipEventDestroy(e);
     }
     DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
-                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->light_tri_geom, &c->tri_verts, &c->tri_bitangents, &c->nodes4, &c->blas_root4, &c->env_qtree,
+                     &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->light_tri_geom, &c->tri_verts, &c->tri_bitangents, &c->nodes4, &c->nodes8, &c->blas_root4, &c->env_qtree,
                      &c->textures, &c->texels, &c->px_temp, &c->px_full, &c->px_half, &c->px_raw, &c->px_final, &c->px_base,
                      &c->px_dn, &c->px_req, &c->px_aux_base, &c->px_aux_dn, &c->px_variance, &c->nlm_tm, &c->nlm_var_h, &c->nlm_var,
                      &c->tonemap_lut, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
@@ -644,8 +645,9 @@ static void refresh_scene_view(rayhip_ctx *c, const rayhip_scene_desc *d, const 
             off += 1 << (2 * (d->env.qtree_levels - 1 - lod));
         }
     }
-    v.nodes4 = c->have_wide ? c->nodes4.as<Bvh4Node>() : nullptr;
-    v.blas_root4 = c->have_wide ? c->blas_root4.as<uint32_t>() : nullptr;
+    v.nodes4 = c->wide == 4 ? c->nodes4.as<Bvh4Node>() : nullptr;
+    v.nodes8 = c->wide == 8 ? c->nodes8.as<Bvh8Node>() : nullptr;
+    v.blas_root4 = c->wide ? c->blas_root4.as<uint32_t>() : nullptr;
     v.light_cwnodes = c->light_cwnodes.as<rayhip_light_cwbvh_node>(), v.textures = c->textures.as<rayhip_texture>();
     v.texels = c->texels.as<uint32_t>();
     memcpy(v.tex_table, c->tex_table, sizeof(v.tex_table));
@@ -776,50 +778,70 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     }
     if (lay.applied) {
         tlas_root = lay.tlas_root;
-        if (upload(c, c->nodes, lay.nodes.data(), lay.nodes.size() * sizeof(rayhip_bvh2_node)) ||
-            upload(c, c->tris, lay.tris.data(), lay.tris.size() * sizeof(rayhip_tri_accel)) ||
-            upload(c, c->tri_indices, lay.tri_indices.data(), lay.tri_indices.size() * sizeof(uint32_t)) ||
-            upload(c, c->mesh_instances, lay.mesh_instances.data(), lay.mesh_instances.size() * sizeof(rayhip_mesh_instance))) {
-            return 1;
-        }
-    } else {
-        UP(nodes)
-        UP(tris)
-        UP(tri_indices)
-        UP(mesh_instances)
     }
-    // 4-wide quantised BLAS trees (rt_bvh4.h) over the node order that was just uploaded; RAYHIP_NO_BVH4=1 keeps the
-    // kernels on the reference's BVH2 (A/B measurements)
-    bool have_wide = false;
+    // Wide quantised BLAS trees over the node order just decided.  RAYHIP_BVH_WIDTH: 8 (default; rt_bvh8.h -- it also decides the
+    // order of the triangle records and re-bases the BVH2's leaf words onto it), 4 (rt_bvh4.h: round 2's form), 2 keeps the
+    // kernels on the reference's BVH2 (RAYHIP_NO_BVH4=1 says the same; A/B measurements)
+    int wide = 0;
     std::vector<uint32_t> blas_root4;
     {
-        const char *e = getenv("RAYHIP_NO_BVH4");
-        if (!(e && e[0] == '1')) {
-            const rayhip_bvh2_node *n2 = lay.applied ? lay.nodes.data() : d->nodes;
-            const uint32_t n2_count = lay.applied ? uint32_t(lay.nodes.size()) : d->nodes_count;
-            const rayhip_mesh_instance *mis = lay.applied ? lay.mesh_instances.data() : d->mesh_instances;
+        int want = 8;
+        if (const char *e = getenv("RAYHIP_BVH_WIDTH")) {
+            want = atoi(e);
+        }
+        if (const char *e = getenv("RAYHIP_NO_BVH4")) {
+            want = e[0] == '1' ? 2 : want;
+        }
+        std::vector<rayhip_bvh2_node> nodes2_own; // a copy the 8-wide build may re-base (the caller's arrays are const)
+        rayhip_bvh2_node *n2 = nullptr;
+        if (lay.applied) {
+            n2 = lay.nodes.data();
+        } else {
+            nodes2_own.assign(d->nodes, d->nodes + d->nodes_count);
+            n2 = nodes2_own.data();
+        }
+        const uint32_t n2_count = lay.applied ? uint32_t(lay.nodes.size()) : d->nodes_count;
+        const rayhip_mesh_instance *mis = lay.applied ? lay.mesh_instances.data() : d->mesh_instances;
+        const rayhip_tri_accel *tris_in = lay.applied ? lay.tris.data() : d->tris;
+        const uint32_t *tri_indices_in = lay.applied ? lay.tri_indices.data() : d->tri_indices;
+        size_t n_tris = lay.applied ? lay.tris.size() : size_t(d->tris_count);
+        rayhip_bvh8::Result b8;
+        if (want == 8) {
+            b8 = rayhip_bvh8::build(n2, n2_count, mis, d->mesh_instances_count, tlas_root, tris_in, tri_indices_in, uint32_t(n_tris));
+            UPLOAD_TRACE(b8.ok ? "bvh8 built" : b8.why_not)
+        }
+        if (b8.ok && !b8.nodes.empty()) {
+            tris_in = b8.tris.data(), tri_indices_in = b8.tri_indices.data(), n_tris = b8.tris.size();
+        }
+        if (upload(c, c->nodes, n2, size_t(n2_count) * sizeof(rayhip_bvh2_node)) ||
+            upload(c, c->tris, tris_in, n_tris * sizeof(rayhip_tri_accel)) ||
+            upload(c, c->tri_indices, tri_indices_in, n_tris * sizeof(uint32_t)) ||
+            upload(c, c->mesh_instances, mis, size_t(d->mesh_instances_count) * sizeof(rayhip_mesh_instance))) {
+            return 1;
+        }
+        size_t wide_bytes = 0;
+        if (b8.ok && !b8.nodes.empty()) {
+            if (upload(c, c->nodes8, b8.nodes.data(), b8.nodes.size() * sizeof(Bvh8Node)) ||
+                upload(c, c->blas_root4, b8.blas_root8.data(), b8.blas_root8.size() * sizeof(uint32_t))) {
+                return 1;
+            }
+            wide = 8, blas_root4 = b8.blas_root8, wide_bytes = b8.nodes.size() * sizeof(Bvh8Node);
+        } else if (want == 4 || want == 8) {
             rayhip_bvh4::Result b4 = rayhip_bvh4::build(n2, n2_count, mis, d->mesh_instances_count, tlas_root);
             if (b4.ok && !b4.nodes.empty()) {
                 if (upload(c, c->nodes4, b4.nodes.data(), b4.nodes.size() * sizeof(Bvh4Node)) ||
                     upload(c, c->blas_root4, b4.blas_root4.data(), b4.blas_root4.size() * sizeof(uint32_t))) {
                     return 1;
                 }
-                HIP_TRY(hipStreamSynchronize(c->stream)); // b4 goes out of scope
-                have_wide = true;
-                blas_root4 = b4.blas_root4;
-                // "small": the BLAS working set (nodes + triangle records) fits one XCD's 4 MB L2 with room to spare
-                const size_t n_tris = lay.applied ? lay.tris.size() : size_t(d->tris_count);
-                c->small_scene = getenv("RAYHIP_NO_SMALL") == nullptr &&
-                                 b4.nodes.size() * sizeof(Bvh4Node) + n_tris * sizeof(rayhip_tri_accel) <= (size_t(2) << 20);
+                wide = 4, blas_root4 = b4.blas_root4, wide_bytes = b4.nodes.size() * sizeof(Bvh4Node);
             }
+            UPLOAD_TRACE(wide == 4 ? "bvh4 built" : "no wide BLAS")
         }
-    }
-    UPLOAD_TRACE(have_wide ? "bvh4 built" : "no bvh4")
-    { // the meshes in use, for rayhip_scene_update_instances: the roots of their trees as uploaded
-        const rayhip_bvh2_node *n2 = lay.applied ? lay.nodes.data() : d->nodes;
-        const uint32_t n2_count = lay.applied ? uint32_t(lay.nodes.size()) : d->nodes_count;
-        const rayhip_mesh_instance *mis = lay.applied ? lay.mesh_instances.data() : d->mesh_instances;
-        rayhip_update::collect_mesh_refs(n2, n2_count, mis, d->mesh_instances_count, tlas_root, have_wide ? blas_root4.data() : nullptr, c->mesh_refs);
+        HIP_TRY(hipStreamSynchronize(c->stream)); // the builders' arrays go out of scope
+        // "small": the BLAS working set (nodes + triangle records) fits one XCD's 4 MB L2 with room to spare
+        c->small_scene = wide != 0 && getenv("RAYHIP_NO_SMALL") == nullptr && wide_bytes + n_tris * sizeof(rayhip_tri_accel) <= (size_t(2) << 20);
+        // the meshes in use, for rayhip_scene_update_instances: the roots of their trees as uploaded
+        rayhip_update::collect_mesh_refs(n2, n2_count, mis, d->mesh_instances_count, tlas_root, wide ? blas_root4.data() : nullptr, c->mesh_refs);
     }
     UPLOAD_TRACE("bvh uploaded")
     UP(tri_materials)
@@ -849,7 +871,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     UP(env_qtree)
 #undef UP
     HIP_TRY(hipStreamSynchronize(c->stream)); // host arrays may go away after this call
-    c->have_wide = have_wide;
+    c->wide = wide;
     memcpy(c->tex_table, d->tex_table, sizeof(c->tex_table));
     c->textures_count = d->textures_count;
     c->tex_flags = d->texture_flags;
@@ -874,6 +896,8 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
 // device does not share after the layout pass) only tells which instance slots are alive and their world-space boxes.
 // Returns 0, 1 = error, 2 = the scene needs rayhip_scene_upload (an instance of a mesh that is not on the device, geometry
 // arrays of another size, no room for the tree).
+int rayhip_scene_bvh_width(rayhip_ctx *c) { return !c || !c->have_scene ? 0 : c->wide ? c->wide : 2; }
+
 int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
     if (use_device(c)) {
         return 1;
@@ -958,7 +982,7 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
         HIP_TRY(hipStreamSynchronize(c->stream)); // `tlas` goes out of scope
     }
     if (upload(c, c->mesh_instances, mis.data(), mis.size() * sizeof(rayhip_mesh_instance)) ||
-        (c->have_wide && upload(c, c->blas_root4, root4.data(), root4.size() * sizeof(uint32_t)))) {
+        (c->wide && upload(c, c->blas_root4, root4.data(), root4.size() * sizeof(uint32_t)))) {
         return 1;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1134,25 +1158,36 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     const uint32_t stripes = sort_rays ? 1u : QUEUE_MAX_STRIPES;
     // K2 launcher (instrumented variant on request)
     auto launch_closest = [&](const RaySoA &r, const RayQueue &q, int init_hits) {
-        if (count_wide && c->sc.nodes4) {
-            k_trace_closest<true, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
+        const int wide = c->wide;
+#define K2_ARGS c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers
+        if (count_wide && wide == 8) {
+            k_trace_closest<true, 8><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
+        } else if (count_wide && wide == 4) {
+            k_trace_closest<true, 4><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
         } else if (count) {
-            k_trace_closest<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
-        } else if (c->sc.nodes4 && c->refill_waves && !(c->refill_secondary_only && !init_hits)) {
+            k_trace_closest<true, 0><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
+        } else if (wide && c->refill_waves && !(c->refill_secondary_only && !init_hits)) {
             // blocks: enough to even out the end of the launch (16 per wave slot on a full-size pass), but never so many that a
             // block gets fewer than ~8 chunks of 64 rays -- below that the kernel degenerates into the plain one with extra
             // set-up per block (a rank of 8 at 20 spp: 5.2 M rays per pass; 16 blocks per slot 6.6 ms, 4: 5.97, plain 5.98)
             const int want = int(std::min<size_t>(size_t(c->refill_waves), std::max<size_t>(size_t(c->refill_resident), nslots / WAVE / 8)));
-            k_trace_closest_refill<<<std::min(gtrace, want), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
-        } else if (c->sc.nodes4 && c->tune_primary_waves == 4) { // (tuning)
-            k_trace_closest<false, true, 4><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
-        } else if (c->sc.nodes4 && (c->small_scene || c->tune_primary_waves == 5)) {
-            k_trace_closest<false, true, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
-        } else if (c->sc.nodes4) {
-            k_trace_closest<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
+            if (wide == 8) {
+                k_trace_closest_refill<8><<<std::min(gtrace, want), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
+            } else {
+                k_trace_closest_refill<4><<<std::min(gtrace, want), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
+            }
+        } else if (wide == 8 && (c->small_scene || c->tune_primary_waves == 5)) {
+            k_trace_closest<false, 8, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
+        } else if (wide == 8) {
+            k_trace_closest<false, 8><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
+        } else if (wide == 4 && (c->small_scene || c->tune_primary_waves == 5)) {
+            k_trace_closest<false, 4, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
+        } else if (wide == 4) {
+            k_trace_closest<false, 4><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
         } else {
-            k_trace_closest<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, tc, layers);
+            k_trace_closest<false, 0><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
         }
+#undef K2_ARGS
     };
 
     StageTimer tm(c, stats != nullptr || (flags & RAYHIP_FLAG_TIME_STAGES) != 0);
@@ -1221,24 +1256,27 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         if (c->sc.blocker_lights_count != 0) {
             k_shadow_blockers<<<gtrace, WAVE, 0, s>>>(c->sc, c->shadow, c->shadow_queue(bounce, nslots, stripes));
         }
-        if (count_wide && c->sc.nodes4) {
-            k_trace_shadow<true, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                               vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
-        } else if (count) {
-            k_trace_shadow<true, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
-        } else if (c->sc.nodes4 && c->tune_shadow_waves == 4) { // (tuning)
-            k_trace_shadow<false, true, 4><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes),
-                                                                   limit, vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
-        } else if (c->sc.nodes4 && (c->small_scene || c->tune_shadow_waves == 5)) {
-            k_trace_shadow<false, true, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes),
-                                                                                      limit, vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
-        } else if (c->sc.nodes4) {
-            k_trace_shadow<false, true><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
-        } else {
-            k_trace_shadow<false, false><<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit,
-                                                                 vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers);
+        {
+            const int wide = c->wide;
+#define K3_ARGS c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit, vw, c->px.temp, nullptr, spill, tc + TRAV_COUNTER_WORDS, layers
+            if (count_wide && wide == 8) {
+                k_trace_shadow<true, 8><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
+            } else if (count_wide && wide == 4) {
+                k_trace_shadow<true, 4><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
+            } else if (count) {
+                k_trace_shadow<true, 0><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
+            } else if (wide == 8 && (c->small_scene || c->tune_shadow_waves == 5)) {
+                k_trace_shadow<false, 8, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
+            } else if (wide == 8) {
+                k_trace_shadow<false, 8><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
+            } else if (wide == 4 && (c->small_scene || c->tune_shadow_waves == 5)) {
+                k_trace_shadow<false, 4, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
+            } else if (wide == 4) {
+                k_trace_shadow<false, 4><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
+            } else {
+                k_trace_shadow<false, 0><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
+            }
+#undef K3_ARGS
         }
         cur ^= 1;
     }
@@ -1591,16 +1629,27 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     const RayQueue q = c->ray_queue(0, size_t(count), 1);
-    if ((flags & RAYHIP_FLAG_COUNT_WIDE) && c->sc.nodes4) { // the product walk with counters
-        k_trace_closest<true, true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
-    } else if (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) { // instrumented walk of the reference's BVH2
-        k_trace_closest<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
-    } else if (c->sc.nodes4 && c->refill_waves) { // what rayhip_render launches
-        k_trace_closest_refill<<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
-    } else if (c->sc.nodes4) {
-        k_trace_closest<false, true><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
-    } else {
-        k_trace_closest<false, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
+    {
+        const int gg = g ? g : 1;
+#define KK_ARGS c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h)
+        if ((flags & RAYHIP_FLAG_COUNT_WIDE) && c->wide == 8) { // the product walk with counters
+            k_trace_closest<true, 8><<<gg, WAVE, 0, s>>>(KK_ARGS);
+        } else if ((flags & RAYHIP_FLAG_COUNT_WIDE) && c->wide == 4) {
+            k_trace_closest<true, 4><<<gg, WAVE, 0, s>>>(KK_ARGS);
+        } else if (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) { // instrumented walk of the reference's BVH2
+            k_trace_closest<true, 0><<<gg, WAVE, 0, s>>>(KK_ARGS);
+        } else if (c->wide == 8 && c->refill_waves) { // what rayhip_render launches
+            k_trace_closest_refill<8><<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
+        } else if (c->wide == 4 && c->refill_waves) {
+            k_trace_closest_refill<4><<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
+        } else if (c->wide == 8) {
+            k_trace_closest<false, 8><<<gg, WAVE, 0, s>>>(KK_ARGS);
+        } else if (c->wide == 4) {
+            k_trace_closest<false, 4><<<gg, WAVE, 0, s>>>(KK_ARGS);
+        } else {
+            k_trace_closest<false, 0><<<gg, WAVE, 0, s>>>(KK_ARGS);
+        }
+#undef KK_ARGS
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -1661,7 +1710,7 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     // results land in the (otherwise idle) hit plane
-    k_trace_shadow<true, false><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
+    k_trace_shadow<true, 0><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
                                                     c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));

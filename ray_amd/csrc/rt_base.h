@@ -41,6 +41,14 @@
 #define RT_D inline
 #endif
 
+// RT_HD_RARE: bodies that run for a few rays in a thousand (a transparent surface was crossed) and whose registers should
+// not be charged to the loop around them: a real call on the device when RT_NOINLINE_RARE is set (tuning)
+#if defined(__HIPCC__) && defined(RT_NOINLINE_RARE)
+#define RT_HD_RARE __host__ __device__ __attribute__((noinline))
+#else
+#define RT_HD_RARE RT_HD
+#endif
+
 #include <float.h>
 #include <math.h>
 

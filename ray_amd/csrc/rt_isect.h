@@ -10,7 +10,7 @@ namespace rt {
 
 // plain array stack (host simulation)
 struct ArrayStack {
-    uint32_t data[2 * MAX_STACK_SIZE];
+    uint32_t data[4 * MAX_STACK_SIZE]; // (the 8-wide walk of rt_bvh8.h keeps 8-byte entries, one per level with pending siblings)
     uint32_t size = 0;
     RT_HD void push(uint32_t v) { data[size++] = v; }
     RT_HD uint32_t pop() { return data[--size]; }
@@ -19,6 +19,9 @@ struct ArrayStack {
     RT_HD void write_at(uint32_t idx, uint32_t v) { data[idx] = v; }
     RT_HD void write3_fast(uint32_t idx, uint32_t a, uint32_t b, uint32_t c) { data[idx] = a, data[idx + 1] = b, data[idx + 2] = c; }
     RT_HD uint32_t read_at(uint32_t idx) const { return data[idx]; }
+    // two-word entries of the 8-wide walk (rt_bvh8.h), `idx` in words
+    RT_HD void write2_at(uint32_t idx, uint32_t a, uint32_t b) { data[idx] = a, data[idx + 1] = b; }
+    RT_HD void read2_at(uint32_t idx, uint32_t &a, uint32_t &b) const { a = data[idx], b = data[idx + 1]; }
 };
 
 #define RT_SIGN_OF(f) (((f) >= 0) ? 1 : -1)

@@ -17,6 +17,7 @@
 #pragma once
 
 #include "rt_bvh4.h"
+#include "rt_bvh8.h"
 #include "rt_isect.h"
 
 namespace rt {
@@ -158,10 +159,11 @@ RT_HD bool intersect_tris_any(const f3 ro, const f3 rd, const rayhip_tri_accel *
 }
 
 // Traverse_TLAS_WithStack_ClosestHit(bvh2), CoreRef.cpp:1943-2025 (+ BLAS :2428-2493)
-// WIDE: the BLAS level walks the 4-wide quantised tree (rt_bvh4.h) instead of the reference's BVH2 -- same leaves,
-// same triangle tests, conservative culling.  Counters: `nodes` = BVH2 nodes (TLAS level in the WIDE walk), `nodes4` =
-// 4-wide nodes, so the product kernel's own algorithmic bytes can be stated next to the reference algorithm's.
-template <bool WIDE = false, class Stack>
+// WIDE (0, 4 or 8): the BLAS level walks the 4-wide (rt_bvh4.h) or the 8-wide (rt_bvh8.h) quantised tree instead of the
+// reference's BVH2 -- same leaves, same triangle tests, conservative culling.  Counters: `nodes` = BVH2 nodes (TLAS level in
+// the wide walks), `nodes4` = wide nodes, so the product kernel's own algorithmic bytes can be stated next to the reference
+// algorithm's.
+template <int WIDE = 0, class Stack>
 RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const uint32_t ray_flags,
                             const uint32_t root_index, Hit &inter, Stack &st, TravCount *cnt) {
     bool res = false;
@@ -188,7 +190,9 @@ RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const
                 res |= intersect_tris_closest(_ro, _rd, sc.tris, tri_start, tri_end, int(mi_index), inter);
                 return false;
             };
-            if (WIDE) {
+            if (WIDE == 8) {
+                walk_bvh8(sc.nodes8, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn, cnt);
+            } else if (WIDE == 4) {
                 walk_bvh4(sc.nodes4, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn, cnt);
             } else {
                 walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, blas_leaf_fn);
@@ -207,7 +211,7 @@ RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const
 }
 
 // Traverse_TLAS_WithStack_AnyHit(bvh2), CoreRef.cpp:2193-2280 (+ BLAS :2619-2693); returns "solid hit found"
-template <bool WIDE = false, class Stack>
+template <int WIDE = 0, class Stack>
 RT_HD bool traverse_any(const SceneView &sc, const f3 ro, const f3 rd, const int ray_type, const uint32_t root_index,
                         Hit &inter, Stack &st, TravCount *cnt) {
     const uint32_t ray_vismask = (1u << ray_type);
@@ -242,7 +246,10 @@ RT_HD bool traverse_any(const SceneView &sc, const f3 ro, const f3 rd, const int
                 }
                 return false;
             };
-            if (WIDE) {
+            if (WIDE == 8) {
+                return walk_bvh8(sc.nodes8, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn, cnt);
+            }
+            if (WIDE == 4) {
                 return walk_bvh4(sc.nodes4, sc.blas_root4[mi_index], _ro, _inv_d, inter.t, st, blas_leaf_fn, cnt);
             }
             return walk_bvh2(sc.nodes, mi.node_index, _ro, _inv_d, inter.t, st, cnt, blas_leaf_fn);
@@ -271,7 +278,7 @@ struct TraceParams {
 // means.  Returns true when the ray crossed a transparent surface and must be traced again from the advanced
 // origin `ro` (inter, r.c, r.depth and rand_dim are updated for the next round); false when the hit is final
 // (solid surface, opaque material after mix resolve, or the path was terminated -> r.c = 0).
-RT_HD bool closest_resolve_transparency(const SceneView &sc, const TraceParams &tp, Ray &r, Hit &inter, const float t_val,
+RT_HD_RARE bool closest_resolve_transparency(const SceneView &sc, const TraceParams &tp, Ray &r, Hit &inter, const float t_val,
                                         const f3 rd, f3 &ro, uint32_t &rand_dim, const uint32_t rand_hash) {
     const bool is_backfacing = (inter.prim_index < 0);
     const uint32_t tri_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
@@ -362,7 +369,7 @@ RT_HD bool hit_side_is_solid(const SceneView &sc, const Hit &inter) {
 struct RayTailComplete {
     RT_HD void operator()(Ray &, TraceParams &) const {}
 };
-template <bool WIDE = false, class Stack, class Tail = RayTailComplete>
+template <int WIDE = 0, class Stack, class Tail = RayTailComplete>
 RT_HD void intersect_scene_closest(const SceneView &sc, const TraceParams &tp_in, Ray &r, Hit &inter, Stack &st, TravCount *cnt,
                                    Tail &&tail = Tail()) {
     const f3 rd = r.d;
@@ -393,8 +400,60 @@ RT_HD void intersect_scene_closest(const SceneView &sc, const TraceParams &tp_in
     inter.t += length(r.o - ro);
 }
 
+// What a non-solid surface lets through towards the light: the weights of the Transparent leaves of its material tree
+// (CoreRef.cpp:3202-3246).  Runs for the few shadow rays that cross such a surface.
+RT_HD_RARE f3 shadow_surface_throughput(const SceneView &sc, const TraceParams &tp, const Hit &inter, const uint32_t rand_dim, const uint32_t rand_hash) {
+    const bool is_backfacing = (inter.prim_index < 0);
+    const uint32_t tri_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
+
+    const uint32_t mat_index = is_backfacing ? (sc.tri_materials[tri_index].back_mi & MATERIAL_INDEX_BITS)
+                                             : (sc.tri_materials[tri_index].front_mi & MATERIAL_INDEX_BITS);
+
+    const rayhip_vertex &v1 = sc.vertices[sc.vtx_indices[tri_index * 3 + 0]];
+    const rayhip_vertex &v2 = sc.vertices[sc.vtx_indices[tri_index * 3 + 1]];
+    const rayhip_vertex &v3 = sc.vertices[sc.vtx_indices[tri_index * 3 + 2]];
+
+    const float w = 1.0f - inter.u - inter.v;
+    const f2 sh_uvs = mk2(v1.t[0], v1.t[1]) * w + mk2(v2.t[0], v2.t[1]) * inter.u + mk2(v3.t[0], v3.t[1]) * inter.v;
+
+    const f2 tex_rand = get_scrambled_2d_rand(rand_dim + RAND_DIM_TEX, rand_hash, tp.iteration - 1, sc.pmj);
+
+    struct {
+        uint32_t index;
+        float weight;
+    } stack[16];
+    int stack_size = 0;
+
+    stack[stack_size].index = mat_index;
+    stack[stack_size++].weight = 1.0f;
+
+    f3 throughput = {0.0f, 0.0f, 0.0f};
+
+    while (stack_size--) {
+        const rayhip_material *mat = &sc.materials[stack[stack_size].index];
+        const float weight = stack[stack_size].weight;
+
+        // resolve mix material
+        if (mat->type == NODE_MIX) {
+            float mix_val = mat->tangent_rotation_or_strength;
+            const uint32_t base_texture = mat->textures[BASE_TEXTURE];
+            if (base_texture != 0xffffffff) {
+                const f4 tex_color = sample_color(sc, base_texture, sh_uvs, 0, tex_rand);
+                mix_val *= tex_color.x;
+            }
+            stack[stack_size].index = mat->textures[MIX_MAT1];
+            stack[stack_size++].weight = weight * (1.0f - mix_val);
+            stack[stack_size].index = mat->textures[MIX_MAT2];
+            stack[stack_size++].weight = weight * mix_val;
+        } else if (mat->type == NODE_TRANSPARENT) {
+            throughput += weight * mk3(mat->base_color);
+        }
+    }
+    return throughput;
+}
+
 // Ref::IntersectScene(shadow_ray_t): visibility * throughput towards the light.  CoreRef.cpp:3160-3262.
-template <bool WIDE = false, class Stack>
+template <int WIDE = 0, class Stack>
 RT_HD f3 intersect_scene_shadow(const SceneView &sc, const TraceParams &tp, const ShadowRay &r, Stack &st,
                                 TravCount *cnt) {
     const f3 rd = r.d;
@@ -421,52 +480,7 @@ RT_HD f3 intersect_scene_shadow(const SceneView &sc, const TraceParams &tp, cons
             break;
         }
 
-        const bool is_backfacing = (inter.prim_index < 0);
-        const uint32_t tri_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
-
-        const uint32_t mat_index = is_backfacing ? (sc.tri_materials[tri_index].back_mi & MATERIAL_INDEX_BITS)
-                                                 : (sc.tri_materials[tri_index].front_mi & MATERIAL_INDEX_BITS);
-
-        const rayhip_vertex &v1 = sc.vertices[sc.vtx_indices[tri_index * 3 + 0]];
-        const rayhip_vertex &v2 = sc.vertices[sc.vtx_indices[tri_index * 3 + 1]];
-        const rayhip_vertex &v3 = sc.vertices[sc.vtx_indices[tri_index * 3 + 2]];
-
-        const float w = 1.0f - inter.u - inter.v;
-        const f2 sh_uvs = mk2(v1.t[0], v1.t[1]) * w + mk2(v2.t[0], v2.t[1]) * inter.u + mk2(v3.t[0], v3.t[1]) * inter.v;
-
-        const f2 tex_rand = get_scrambled_2d_rand(rand_dim + RAND_DIM_TEX, rand_hash, tp.iteration - 1, sc.pmj);
-
-        struct {
-            uint32_t index;
-            float weight;
-        } stack[16];
-        int stack_size = 0;
-
-        stack[stack_size].index = mat_index;
-        stack[stack_size++].weight = 1.0f;
-
-        f3 throughput = {0.0f, 0.0f, 0.0f};
-
-        while (stack_size--) {
-            const rayhip_material *mat = &sc.materials[stack[stack_size].index];
-            const float weight = stack[stack_size].weight;
-
-            // resolve mix material
-            if (mat->type == NODE_MIX) {
-                float mix_val = mat->tangent_rotation_or_strength;
-                const uint32_t base_texture = mat->textures[BASE_TEXTURE];
-                if (base_texture != 0xffffffff) {
-                    const f4 tex_color = sample_color(sc, base_texture, sh_uvs, 0, tex_rand);
-                    mix_val *= tex_color.x;
-                }
-                stack[stack_size].index = mat->textures[MIX_MAT1];
-                stack[stack_size++].weight = weight * (1.0f - mix_val);
-                stack[stack_size].index = mat->textures[MIX_MAT2];
-                stack[stack_size++].weight = weight * mix_val;
-            } else if (mat->type == NODE_TRANSPARENT) {
-                throughput += weight * mk3(mat->base_color);
-            }
-        }
+        const f3 throughput = shadow_surface_throughput(sc, tp, inter, rand_dim, rand_hash);
 
         rc *= throughput;
         if (lum(rc) < FLT_EPS_) {

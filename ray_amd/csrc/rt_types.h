@@ -17,12 +17,14 @@ struct uint2 {
 namespace rt {
 
 struct Bvh4Node; // rt_bvh4.h
+struct Bvh8Node; // rt_bvh8.h
 
 // Device-side view of the flat scene (pointers into HBM).  Mirrors reference Core.h:511-535 scene_data_t.
 struct SceneView {
     const rayhip_bvh2_node *nodes;
     const Bvh4Node *nodes4;     // 4-wide quantised BLAS trees built from `nodes` at upload (rt_bvh4.h), or null
-    const uint32_t *blas_root4; // per mesh instance: root of its tree in nodes4
+    const Bvh8Node *nodes8;     // 8-wide quantised BLAS trees (rt_bvh8.h), or null; at most one of the two wide forms is set
+    const uint32_t *blas_root4; // per mesh instance: root of its tree in the wide form that is set (nodes4 or nodes8)
     const rayhip_tri_accel *tris;
     const uint32_t *tri_indices;
     const rayhip_tri_mat_data *tri_materials;

@@ -93,9 +93,16 @@ class Scene final : public Cpu::Scene {
 #undef BUMP
 };
 
+// One device, or several (RAY_HIP_DEVICES=0,1,2,3 | all; settings_t::preferred_device takes the same list): the scene is
+// replicated, rank r renders the 64 x 64 tiles r, r + N, ... of every RenderScene (rayhip_comm_bind deals them), and the
+// moment somebody looks at pixels the root gathers the other ranks' tiles (rayhip_comm_reduce_framebuffers: peer copies
+// over xGMI) -- the whole of the reference API stays as it is, a host that asks for four devices gets one image.
 class Renderer final : public RendererBase {
     ILog *log_;
-    rayhip_ctx *ctx_ = nullptr;
+    rayhip_ctx *ctx_ = nullptr;        // the root: the context pixels are read from
+    std::vector<rayhip_ctx *> ctxs_;   // all ranks, ctxs_[0] == ctx_
+    rayhip_comm *comm_ = nullptr;      // set when ctxs_.size() > 1
+    mutable bool assembled_ = true;    // the root holds every rank's tiles of what was rendered so far
     std::string device_name_;
     int w_ = 0, h_ = 0;
 
@@ -124,9 +131,24 @@ class Renderer final : public RendererBase {
         if (pending_count_ > 0) {
             const int n = pending_count_;
             pending_count_ = 0;
-            check(rayhip_render_batch(ctx_, &pending_cam_, pending_rect_, pending_first_, n,
-                                      collect_stats_ ? RAYHIP_FLAG_TIME_STAGES : 0u, nullptr),
-                  "rayhip_render_batch");
+            for (rayhip_ctx *c : ctxs_) { // (a pass is only enqueued: the devices work side by side)
+                check(rayhip_render_batch(c, &pending_cam_, pending_rect_, pending_first_, n, collect_stats_ ? RAYHIP_FLAG_TIME_STAGES : 0u, nullptr),
+                      "rayhip_render_batch");
+            }
+            assembled_ = comm_ == nullptr;
+        }
+    }
+    // several devices: bring the other ranks' tiles (radiance, aux images, variance estimate) to the root
+    void Assemble() const {
+        Flush();
+        if (!assembled_ && comm_) {
+            check(rayhip_comm_reduce_framebuffers(comm_, 0, RAYHIP_REDUCE_ALL, &pending_cam_), "rayhip_comm_reduce_framebuffers");
+            assembled_ = true;
+        }
+    }
+    template <class F> void ForAll(F &&f, const char *what) const {
+        for (rayhip_ctx *c : ctxs_) {
+            check(f(c), what);
         }
     }
 
@@ -140,7 +162,7 @@ class Renderer final : public RendererBase {
     }
 
     color_data_rgba_t fetch(const int which) const {
-        Flush();
+        Assemble();
         if (host_dirty_[which]) {
             host_[which].resize(size_t(w_) * h_);
             check(rayhip_readback(ctx_, which, &host_[which][0].v[0], w_), "rayhip_readback");
@@ -171,7 +193,31 @@ class Renderer final : public RendererBase {
         }
         const std::vector<float> table = Ray::CDFInverted(FILTER_TABLE_SIZE, 0.0f, filter_width * 0.5f,
                                                           std::bind(filter_func, std::placeholders::_1, filter_width), true);
-        check(rayhip_set_filter_table(ctx_, table.data(), int(table.size())), "rayhip_set_filter_table");
+        ForAll([&](rayhip_ctx *c) { return rayhip_set_filter_table(c, table.data(), int(table.size())); }, "rayhip_set_filter_table");
+    }
+
+    // "0,2,3" | "all" -> device ordinals
+    static std::vector<int> ParseDevices(const std::string &spec, const int have) {
+        std::vector<int> out;
+        if (spec == "all") {
+            for (int d = 0; d < have; ++d) {
+                out.push_back(d);
+            }
+            return out;
+        }
+        size_t pos = 0;
+        while (pos < spec.size()) {
+            const size_t end = spec.find(',', pos);
+            const std::string item = spec.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+            if (!item.empty()) {
+                out.push_back(atoi(item.c_str()));
+            }
+            if (end == std::string::npos) {
+                break;
+            }
+            pos = end + 1;
+        }
+        return out;
     }
 
   public:
@@ -179,20 +225,55 @@ class Renderer final : public RendererBase {
         if (rayhip_device_count() <= 0) {
             throw std::runtime_error("no HIP device found");
         }
-        int device = 0;
+        std::vector<int> devices = {0};
         if (const char *e = getenv("RAY_HIP_DEVICE")) {
-            device = atoi(e);
+            devices = {atoi(e)};
+        }
+        if (const char *e = getenv("RAY_HIP_DEVICES")) {
+            devices = ParseDevices(e, rayhip_device_count());
         }
         if (!s.preferred_device.empty()) {
-            // settings_t::preferred_device (RendererBase.h:54): a plain device ordinal for this backend
-            device = atoi(std::string(s.preferred_device).c_str());
+            // settings_t::preferred_device (RendererBase.h:54): device ordinals for this backend, "1" or "0,1,2,3" or "all"
+            devices = ParseDevices(std::string(s.preferred_device), rayhip_device_count());
         }
-        if (rayhip_ctx_create(device, &ctx_) != 0) {
-            throw std::runtime_error(std::string("rayhip_ctx_create: ") + rayhip_last_error());
+        if (devices.empty()) {
+            throw std::runtime_error("RendererHIP: empty device list");
+        }
+        auto destroy_all = [&]() {
+            if (comm_) {
+                rayhip_comm_destroy(comm_);
+            }
+            for (rayhip_ctx *c : ctxs_) {
+                rayhip_ctx_destroy(c);
+            }
+        };
+        for (const int d : devices) {
+            rayhip_ctx *c = nullptr;
+            if (rayhip_ctx_create(d, &c) != 0) {
+                const std::string err = rayhip_last_error();
+                destroy_all();
+                throw std::runtime_error("rayhip_ctx_create: " + err);
+            }
+            ctxs_.push_back(c);
+        }
+        ctx_ = ctxs_[0];
+        if (ctxs_.size() > 1) {
+            bool ok = rayhip_comm_create(int(devices.size()), devices.data(), &comm_) == 0;
+            for (size_t r = 0; ok && r < ctxs_.size(); ++r) {
+                ok = rayhip_comm_bind(comm_, int(r), ctxs_[r]) == 0;
+            }
+            if (!ok) {
+                const std::string err = rayhip_last_error();
+                destroy_all();
+                throw std::runtime_error("rayhip_comm_create: " + err);
+            }
         }
         char name[256] = {};
         rayhip_ctx_device_name(ctx_, name, sizeof(name));
         device_name_ = name;
+        if (ctxs_.size() > 1) {
+            device_name_ += " x" + std::to_string(ctxs_.size());
+        }
         collect_stats_ = getenv("RAY_HIP_NO_STATS") == nullptr;
         if (const char *e = getenv("RAY_HIP_BATCH")) { // 1 = render every iteration in its own pass
             max_batch_ = atoi(e) > 0 ? atoi(e) : 1;
@@ -200,20 +281,28 @@ class Renderer final : public RendererBase {
 
         log->Info("============================================================================");
         log->Info("Device       is %s", device_name_.c_str());
-        log->Info("Wavefront    is 64 lanes, traversal stack %i entries/lane in LDS", MAX_STACK_SIZE);
+        log->Info("Wavefront    is 64 lanes, traversal stack 24 words/lane in LDS (+ spill to HBM up to %i)", 2 * MAX_STACK_SIZE);
+        log->Info("Devices      %i (the frame's 64x64 tiles are dealt round-robin)", int(ctxs_.size()));
         log->Info("============================================================================");
 
         // PMJ02 table upload, RendererVK.cpp:299-311
-        if (rayhip_upload_static(ctx_, __pmj02_samples, uint32_t(__pmj02_dims_count) * 2u * uint32_t(__pmj02_sample_count)) != 0) {
-            const std::string err = rayhip_last_error();
-            rayhip_ctx_destroy(ctx_);
-            throw std::runtime_error("rayhip_upload_static: " + err);
+        for (rayhip_ctx *c : ctxs_) {
+            if (rayhip_upload_static(c, __pmj02_samples, uint32_t(__pmj02_dims_count) * 2u * uint32_t(__pmj02_sample_count)) != 0) {
+                const std::string err = rayhip_last_error();
+                destroy_all();
+                throw std::runtime_error("rayhip_upload_static: " + err);
+            }
         }
         Resize(s.w, s.h);
     }
     ~Renderer() override {
         pending_count_ = 0; // nobody can look at them any more
-        rayhip_ctx_destroy(ctx_);
+        if (comm_) {
+            rayhip_comm_destroy(comm_);
+        }
+        for (rayhip_ctx *c : ctxs_) {
+            rayhip_ctx_destroy(c);
+        }
     }
 
     eRendererType type() const override { return RendererTypeHIP; }
@@ -236,7 +325,7 @@ class Renderer final : public RendererBase {
     void Resize(const int w, const int h) override {
         Flush();
         if (w_ != w || h_ != h) {
-            check(rayhip_resize(ctx_, w, h), "rayhip_resize");
+            ForAll([&](rayhip_ctx *c) { return rayhip_resize(c, w, h); }, "rayhip_resize");
             w_ = w, h_ = h;
             for (bool &d : host_dirty_) {
                 d = true;
@@ -245,7 +334,8 @@ class Renderer final : public RendererBase {
     }
     void Clear(const color_rgba_t &c) override {
         Flush();
-        check(rayhip_clear(ctx_, c.v), "rayhip_clear");
+        ForAll([&](rayhip_ctx *cx) { return rayhip_clear(cx, c.v); }, "rayhip_clear");
+        assembled_ = true;
         for (bool &d : host_dirty_) {
             d = true;
         }
@@ -269,7 +359,12 @@ class Renderer final : public RendererBase {
                 if (uploaded_scene_ == s && uploaded_geometry_version_ == s->geometry_version()) {
                     // instances / lights / environment only: the top level is rebuilt on the device
                     SceneAccess::Export(*s, flat, false /* with_textures */);
-                    rc = rayhip_scene_update_instances(ctx_, &flat.desc);
+                    for (rayhip_ctx *c : ctxs_) { // (the same decision on every device: they hold the same scene)
+                        rc = rayhip_scene_update_instances(c, &flat.desc);
+                        if (rc != 0) {
+                            break;
+                        }
+                    }
                     if (rc == 1) {
                         // the device state may be half replaced: nothing usable until a full upload succeeds
                         log_->Error("RendererHIP: rayhip_scene_update_instances failed: %s", rayhip_last_error());
@@ -279,7 +374,11 @@ class Renderer final : public RendererBase {
                 }
                 if (rc == 2) {
                     SceneAccess::Export(*s, flat);
-                    if (rayhip_scene_upload(ctx_, &flat.desc) != 0) {
+                    bool ok = true;
+                    for (rayhip_ctx *c : ctxs_) {
+                        ok = ok && rayhip_scene_upload(c, &flat.desc) == 0;
+                    }
+                    if (!ok) {
                         // nothing usable is on the device: forget what was there, so that the next RenderScene tries again
                         log_->Error("RendererHIP: rayhip_scene_upload failed: %s", rayhip_last_error());
                         uploaded_scene_ = nullptr, uploaded_version_ = uploaded_geometry_version_ = 0;
@@ -308,8 +407,8 @@ class Renderer final : public RendererBase {
             // what RendererVK::RenderScene does with its 3-D texture (RendererVK.cpp:404-415)
             Flush();
             try {
-                check(rayhip_set_tonemap_lut(ctx_, int(cam.view_transform), transform_luts[int(cam.view_transform)], LUT_DIMS),
-                      "rayhip_set_tonemap_lut");
+                ForAll([&](rayhip_ctx *c) { return rayhip_set_tonemap_lut(c, int(cam.view_transform), transform_luts[int(cam.view_transform)], LUT_DIMS); },
+                       "rayhip_set_tonemap_lut");
             } catch (std::exception &e) {
                 log_->Error("RendererHIP: %s", e.what());
                 return;
@@ -347,7 +446,7 @@ class Renderer final : public RendererBase {
     // NLM denoiser (RendererCPU.h:661-783): filters what the iterations so far accumulated, with the camera (tonemap, adaptive
     // sampling threshold) of the last RenderScene, as the reference does through tonemap_params_ / variance_threshold_
     void DenoiseImage(const RegionContext &region) override {
-        Flush();
+        Assemble(); // the filter reads every pixel's radiance, guides and variance estimate: on the root, after the gather
         if (!have_cam_) {
             log_->Error("RendererHIP: DenoiseImage before the first RenderScene");
             return;

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../ray_amd/csrc/bvh4_build.h"
+#include "../../ray_amd/csrc/bvh8_build.h"
 #include "../../ray_amd/csrc/bvh_layout.h"
 #include "../../ray_amd/csrc/rt_arealights.h"
 #include "../../ray_amd/csrc/rt_denoise.h"
@@ -49,7 +50,8 @@ struct HostScene {
     std::vector<float4> light_children, light_tri_geom, tri_verts, tri_bitangents;
     std::vector<float> env_qtree;
     std::vector<Bvh4Node> nodes4;
-    std::vector<uint32_t> blas_root4;
+    std::vector<Bvh8Node> nodes8;
+    std::vector<uint32_t> blas_root4; // roots in the wide form in use (nodes4 or nodes8)
     std::vector<rayhip_texture> textures;
     std::vector<uint32_t> texels;
 };
@@ -67,7 +69,7 @@ struct hostsim_ctx {
     rayhip_trav_counters counters[2] = {};
     Shard shard = {64, 1, 0};
     bool layout_applied = false;
-    bool wide = false; // walk the 4-wide BLAS (HOSTSIM_BVH4=1)
+    int wide = 0; // walk the 4-wide BLAS (HOSTSIM_BVH4=1) or the 8-wide one (HOSTSIM_BVH8=1)
     rayhip_update::MeshRefs mesh_refs; // for hostsim_scene_update_instances_blob (scene_update.h)
     uint32_t nodes_used = 0;           // node slots of the last full upload; top levels built later go behind them
     bool have_scene = false;
@@ -206,18 +208,49 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
             }
         }
     }
-    // 4-wide quantised BLAS (rt_bvh4.h), used when HOSTSIM_BVH4=1
-    c->wide = false;
+    // wide quantised BLAS: 8-wide (rt_bvh8.h, HOSTSIM_BVH8=1: re-orders the triangle records and re-bases the BVH2's leaf
+    // words with them) or 4-wide (rt_bvh4.h, HOSTSIM_BVH4=1)
+    c->wide = 0;
+    s.nodes4.clear(), s.nodes8.clear(), s.blas_root4.clear();
     {
-        rayhip_bvh4::Result b4 = rayhip_bvh4::build(s.nodes.data(), uint32_t(s.nodes.size()), s.mesh_instances.data(),
-                                                    uint32_t(s.mesh_instances.size()), tlas_root);
-        if (b4.ok) {
-            s.nodes4.swap(b4.nodes), s.blas_root4.swap(b4.blas_root4);
-            const char *e = getenv("HOSTSIM_BVH4");
-            c->wide = e && e[0] == '1';
-        } else {
-            s.nodes4.clear(), s.blas_root4.clear();
-            if (getenv("HOSTSIM_VERBOSE")) {
+        const char *e8 = getenv("HOSTSIM_BVH8"), *e4 = getenv("HOSTSIM_BVH4");
+        if (e8 && e8[0] == '1') {
+            rayhip_bvh8::CostModel cm;
+            if (const char *e = getenv("HOSTSIM_BVH8_CPRIM")) {
+                cm.c_prim = float(atof(e));
+            }
+            if (const char *e = getenv("HOSTSIM_BVH8_PMAX")) {
+                cm.p_max = uint32_t(atoi(e));
+            }
+            rayhip_bvh8::Result b8 = rayhip_bvh8::build(s.nodes.data(), uint32_t(s.nodes.size()), s.mesh_instances.data(),
+                                                        uint32_t(s.mesh_instances.size()), tlas_root, s.tris.data(), s.tri_indices.data(),
+                                                        uint32_t(s.tris.size()), cm);
+            if (b8.ok) {
+                s.nodes8.swap(b8.nodes), s.blas_root4.swap(b8.blas_root8);
+                s.tris.swap(b8.tris), s.tri_indices.swap(b8.tri_indices);
+                c->wide = 8;
+                if (getenv("HOSTSIM_VERBOSE")) {
+                    size_t inner = 0, leaves = 0;
+                    for (const Bvh8Node &n : s.nodes8) {
+                        inner += size_t(__builtin_popcount(n.exps_imask >> 24));
+                        for (int k = 0; k < 8; ++k) {
+                            leaves += ((n.meta[k >> 2] >> (8 * (k & 3))) & 0xffu) != 0u;
+                        }
+                    }
+                    fprintf(stderr, "hostsim: BVH8: %zu nodes, %.2f inner + %.2f leaf children per node, %zu triangle records\n", s.nodes8.size(),
+                            double(inner) / double(s.nodes8.size()), double(leaves) / double(s.nodes8.size()), s.tris.size());
+                }
+            } else if (getenv("HOSTSIM_VERBOSE")) {
+                fprintf(stderr, "hostsim: BVH8 build failed: %s\n", b8.why_not);
+            }
+        }
+        if (c->wide == 0) {
+            rayhip_bvh4::Result b4 = rayhip_bvh4::build(s.nodes.data(), uint32_t(s.nodes.size()), s.mesh_instances.data(),
+                                                        uint32_t(s.mesh_instances.size()), tlas_root);
+            if (b4.ok) {
+                s.nodes4.swap(b4.nodes), s.blas_root4.swap(b4.blas_root4);
+                c->wide = (e4 && e4[0] == '1') ? 4 : 0;
+            } else if (getenv("HOSTSIM_VERBOSE")) {
                 fprintf(stderr, "hostsim: BVH4 build failed\n");
             }
         }
@@ -229,6 +262,7 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     SceneView &v = c->sc;
     v.nodes = s.nodes.data(), v.tris = s.tris.data(), v.tri_indices = s.tri_indices.data();
     v.nodes4 = s.nodes4.empty() ? nullptr : s.nodes4.data(), v.blas_root4 = s.blas_root4.empty() ? nullptr : s.blas_root4.data();
+    v.nodes8 = s.nodes8.empty() ? nullptr : s.nodes8.data();
     v.tri_materials = s.tri_materials.data(), v.materials = s.materials.data(), v.vertices = s.vertices.data();
     v.vtx_indices = s.vtx_indices.data(), v.mesh_instances = s.mesh_instances.data(), v.lights = s.lights.data();
     v.light_children = s.light_children.data();
@@ -335,6 +369,8 @@ HS_API int hostsim_scene_update_instances_blob(hostsim_ctx *c, const void *blob,
     return hostsim_scene_update_instances(c, &d);
 }
 
+HS_API int hostsim_scene_bvh_width(hostsim_ctx *c) { return !c->have_scene ? 0 : c->wide ? c->wide : 2; }
+
 HS_API int hostsim_set_filter_table(hostsim_ctx *c, const float *t, int count) {
     c->filter_table.assign(t, t + count);
     return 0;
@@ -370,15 +406,19 @@ HS_API int hostsim_scene_upload_blob(hostsim_ctx *c, const void *blob, size_t si
 
 template <class Stack>
 static void trace_closest(const hostsim_ctx *c, const TraceParams &tp, Ray &r, Hit &h, Stack &st, TravCount *cnt) {
-    if (c->wide) {
-        intersect_scene_closest<true>(c->sc, tp, r, h, st, cnt);
+    if (c->wide == 8) {
+        intersect_scene_closest<8>(c->sc, tp, r, h, st, cnt);
+    } else if (c->wide == 4) {
+        intersect_scene_closest<4>(c->sc, tp, r, h, st, cnt);
     } else {
-        intersect_scene_closest<false>(c->sc, tp, r, h, st, cnt);
+        intersect_scene_closest<0>(c->sc, tp, r, h, st, cnt);
     }
 }
 template <class Stack>
 static f3 trace_shadow(const hostsim_ctx *c, const TraceParams &tp, const ShadowRay &r, Stack &st, TravCount *cnt) {
-    return c->wide ? intersect_scene_shadow<true>(c->sc, tp, r, st, cnt) : intersect_scene_shadow<false>(c->sc, tp, r, st, cnt);
+    return c->wide == 8   ? intersect_scene_shadow<8>(c->sc, tp, r, st, cnt)
+           : c->wide == 4 ? intersect_scene_shadow<4>(c->sc, tp, r, st, cnt)
+                          : intersect_scene_shadow<0>(c->sc, tp, r, st, cnt);
 }
 
 static void add_counters(rayhip_trav_counters &dst, const TravCount &tc) {
@@ -704,7 +744,7 @@ HS_API int hostsim_k_generate_primary_rays(hostsim_ctx *c, const rayhip_camera *
 
 HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam, rayhip_ray *rays, rayhip_hit *hits,
                                        int count, int iteration, uint32_t flags, rayhip_trav_counters *out_counters) {
-    const bool wide = c->wide && (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) == 0;
+    const int wide = (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) == 0 ? c->wide : 0;
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     ArrayStack st;
     rayhip_trav_counters acc = {};
@@ -712,10 +752,12 @@ HS_API int hostsim_k_intersect_closest(hostsim_ctx *c, const rayhip_camera *cam,
         Ray r = from_abi(rays[i]);
         Hit h = {hits[i].obj_index, hits[i].prim_index, hits[i].t, hits[i].u, hits[i].v};
         TravCount tc = {};
-        if (wide) {
-            intersect_scene_closest<true>(c->sc, tp, r, h, st, &tc);
+        if (wide == 8) {
+            intersect_scene_closest<8>(c->sc, tp, r, h, st, &tc);
+        } else if (wide == 4) {
+            intersect_scene_closest<4>(c->sc, tp, r, h, st, &tc);
         } else {
-            intersect_scene_closest<false>(c->sc, tp, r, h, st, &tc);
+            intersect_scene_closest<0>(c->sc, tp, r, h, st, &tc);
         }
         add_counters(acc, tc);
         rays[i] = to_abi(r);

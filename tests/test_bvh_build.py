@@ -5,7 +5,8 @@ A BVH only culls, so a correct tree over the same triangle records must reproduc
   * leaf refinement (the scene's trees, every leaf above `leaf_max` triangles replaced by a subtree; what librayhip does at
     upload) and
   * a full rebuild of both levels from triangles and instance transforms
-are rendered through the BVH2 walk and the 4-wide walk and compared with RendererRef's golden frames -- bit for bit on the
+are rendered through the BVH2 walk, the 4-wide walk and the 8-wide walk (rt_bvh8.h: its own collapse, octant-ordered slots,
+its own triangle order) and compared with RendererRef's golden frames -- bit for bit on the
 fixture scenes (instancing, transparency, every light kind).  What a different tree may legitimately change is the winner
 of an EXACT tie between two triangles at the same distance (the reference's own tree flavours differ there, SURVEY
 Appendix A.1): the material-zoo scene, which stacks coplanar surfaces, is allowed a handful of such pixels.
@@ -28,13 +29,14 @@ def _render(name, spp=8):
     return ctx
 
 
-@pytest.mark.parametrize("wide", ["0", "1"], ids=["bvh2", "bvh4"])
+@pytest.mark.parametrize("wide", ["0", "4", "8"], ids=["bvh2", "bvh4", "bvh8"])
 @pytest.mark.parametrize("mode,leaf_max", [("HOSTSIM_REFINE", "1"), ("HOSTSIM_REFINE", "2"), ("HOSTSIM_REFINE", "4"),
                                            ("HOSTSIM_LBVH", "2"), ("HOSTSIM_LBVH", "4"), ("HOSTSIM_LBVH", "8")])
 @pytest.mark.parametrize("name", SCENES)
 def test_rebuilt_trees_reproduce_the_oracle(name, mode, leaf_max, wide, monkeypatch):
     monkeypatch.setenv(mode, leaf_max)
-    monkeypatch.setenv("HOSTSIM_BVH4", wide)
+    monkeypatch.setenv("HOSTSIM_BVH4", "1" if wide == "4" else "0")
+    monkeypatch.setenv("HOSTSIM_BVH8", "1" if wide == "8" else "0")
     g = util.golden_ref(name)
     ctx = _render(name)
     assert np.array_equal(ctx.readback(hip.BUF_RAW), g["raw_spp8"])
@@ -58,11 +60,13 @@ def test_refinement_shortens_the_leaves(monkeypatch):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("wide8", ["0", "1"], ids=["bvh2", "bvh8"])
 @pytest.mark.parametrize("mode,leaf_max", [("HOSTSIM_REFINE", "2"), ("HOSTSIM_LBVH", "4")])
-def test_rebuilt_trees_on_live_scenes(mode, leaf_max, monkeypatch):
+def test_rebuilt_trees_on_live_scenes(mode, leaf_max, wide8, monkeypatch):
     """bigger meshes (the atrium at test size), many instances, and the scene with coplanar overlaps"""
     from ray_amd import scenes
     monkeypatch.setenv(mode, leaf_max)
+    monkeypatch.setenv("HOSTSIM_BVH8", wide8)
     for fn, exact in ((scenes.atrium_small, True), (scenes.cornell_principled_zoo, False)):
         r, s = O.render_ref(fn, 64, 64, 4)
         ctx = O.hostsim_context(64, 64, O.export_scene(s))
@@ -78,7 +82,7 @@ def test_rebuilt_trees_on_live_scenes(mode, leaf_max, monkeypatch):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("mode,leaf_max", [("HOSTSIM_REFINE", "2"), ("HOSTSIM_LBVH", "2")])
+@pytest.mark.parametrize("mode,leaf_max", [("HOSTSIM_REFINE", "2"), ("HOSTSIM_LBVH", "2"), ("HOSTSIM_BVH8", "1")])
 @pytest.mark.parametrize("seed", range(6))
 def test_rebuilt_trees_on_fuzzed_instance_scenes(seed, mode, leaf_max, monkeypatch):
     """random two-level scenes (2-9 instances of shared meshes, rotations, non-uniform scales, ray-type visibility masks,
@@ -86,6 +90,8 @@ def test_rebuilt_trees_on_fuzzed_instance_scenes(seed, mode, leaf_max, monkeypat
     leaf, top levels of few instances -- against RendererRef"""
     from ray_amd import scenes
     monkeypatch.setenv(mode, leaf_max)
+    if mode == "HOSTSIM_BVH8":
+        monkeypatch.setenv("HOSTSIM_REFINE", "2")  # (what the upload does before the 8-wide collapse)
     w, h, spp = 48, 48, 3
     r, s = O.render_ref(lambda sc: scenes.random_instances(sc, seed), w, h, spp)
     ctx = O.hostsim_context(w, h, O.export_scene(s))

@@ -79,6 +79,35 @@ def test_two_shards_on_one_gpu_sum_to_the_frame_across_refinement_steps(lib):
         assert np.array_equal(ctxs[0].readback(hip.BUF_FINAL), _reference(lib, done)["final"])
 
 
+def test_packed_tiles_of_three_shards_on_one_gpu_assemble_the_frame(lib):
+    """the packing of the product's exchange on the device (rayhip_export_owned -> rayhip_import_owned -> rayhip_finish_import):
+    three contexts on one GPU stand in for three ranks, the root imports the other two ranks' tiles -- every image of the
+    mask, a ragged frame, a second round after more iterations"""
+    import torch
+    n = 3
+    ctxs = [util.make_context(lib, NAME, W, H) for _ in range(n)]
+    for r, c in enumerate(ctxs):
+        c.set_shard(64, n, r)
+    done = 0
+    for k in (2, 3):
+        for c in ctxs:
+            c.render_batch(done + 1, k)
+        done += k
+        for r in range(1, n):
+            nbytes = ctxs[r].owned_bytes(hip.REDUCE_ALL, n, r)
+            assert nbytes == ctxs[0].owned_bytes(hip.REDUCE_ALL, n, r) and nbytes % (64 * 64 * 16 * 4) == 0
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+            ctxs[r].export_owned(hip.REDUCE_ALL, buf.data_ptr(), nbytes)
+            ctxs[0].import_owned(hip.REDUCE_ALL, r, buf.data_ptr(), nbytes)
+        ctxs[0].finish_import()
+        ref = _reference(lib, done)
+        for key, b in (("raw", hip.BUF_RAW), ("final", hip.BUF_FINAL), ("base", hip.BUF_BASE_COLOR), ("dn", hip.BUF_DEPTH_NORMALS),
+                       ("var", hip.BUF_VARIANCE)):
+            assert np.array_equal(ctxs[0].readback(b), ref[key]), (key, done)
+    with pytest.raises(RuntimeError):  # a buffer that is too small is refused, not overrun
+        ctxs[1].export_owned(hip.REDUCE_ALL, buf.data_ptr(), 16)
+
+
 def test_render_sharded_over_torch_distributed_twice(lib):
     import torch
     import torch.distributed as dist

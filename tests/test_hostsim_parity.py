@@ -181,14 +181,15 @@ def test_scene_mutation_against_live_reference(lib):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("wide", ["0", "1"], ids=["bvh2", "bvh4"])
+@pytest.mark.parametrize("wide", ["0", "1", "8"], ids=["bvh2", "bvh4", "bvh8"])
 def test_instance_update_against_live_reference(lib, wide, monkeypatch):
     """the same mutation through the UPDATE path (rayhip_scene_update_instances; here the host build of its planning,
     scene_update.h, with the linear builder as host loops): the geometry of the first upload stays, instances / lights /
     environment are replaced and the top level is rebuilt -- frames must still be the reference's, including its habit of
     numbering top-level leaves by position among the live instances after a RemoveMeshInstance"""
     from ray_amd import api, scenes
-    monkeypatch.setenv("HOSTSIM_BVH4", wide)
+    monkeypatch.setenv("HOSTSIM_BVH4", "1" if wide == "1" else "0")
+    monkeypatch.setenv("HOSTSIM_BVH8", "1" if wide == "8" else "0")
     w, h = 64, 48
     r, s = O.render_ref(scenes.cornell_instances_mutable, w, h, 2)
     ctx = O.hostsim_context(w, h, O.export_scene(s))
@@ -204,12 +205,13 @@ def test_instance_update_against_live_reference(lib, wide, monkeypatch):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("wide", ["0", "1"], ids=["bvh2", "bvh4"])
+@pytest.mark.parametrize("wide", ["0", "1", "8"], ids=["bvh2", "bvh4", "bvh8"])
 def test_instance_update_with_a_single_instance(lib, wide, monkeypatch):
     """the smallest top level: ONE instance (the linear builder has nothing to split: its root gets a far-away point box as
     second child), moved and rotated; then removed altogether (an empty scene with lights), then added again"""
     from ray_amd import api, scenes
-    monkeypatch.setenv("HOSTSIM_BVH4", wide)
+    monkeypatch.setenv("HOSTSIM_BVH4", "1" if wide == "1" else "0")
+    monkeypatch.setenv("HOSTSIM_BVH8", "1" if wide == "8" else "0")
     w, h, spp = 48, 48, 2
     handle = {}
 
@@ -359,14 +361,16 @@ def test_delta_lights_and_texture_corners_against_live_reference(lib):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("wide", ["0", "1"])
+@pytest.mark.parametrize("wide", ["0", "1", "8"])
 def test_atrium_against_live_reference(lib, wide, monkeypatch):
     """the procedural atrium bench.py renders (Sponza- / Bistro-class at full detail), at a detail the CPU reference
     finishes in seconds: deep SAH BVH, thousands of emissive triangles in the light tree, textures; BVH2 and 4-wide walks"""
     from functools import partial
     from ray_amd import scenes
 
-    monkeypatch.setenv("HOSTSIM_BVH4", wide)
+    monkeypatch.setenv("HOSTSIM_BVH4", "1" if wide == "1" else "0")
+    monkeypatch.setenv("HOSTSIM_BVH8", "1" if wide == "8" else "0")
+    monkeypatch.setenv("HOSTSIM_REFINE", "2" if wide == "8" else "0")  # (the 8-wide collapse is built over refined leaves)
     w, h, spp = 96, 54, 3
     r, s = O.render_ref(partial(scenes.atrium, detail=0.02), w, h, spp)
     assert s.triangle_count() > 5000
@@ -494,11 +498,16 @@ def test_layout_pass_is_exercised(lib, name):
     assert f(ctx._ctx) == 1
 
 
+@pytest.mark.parametrize("width", ["4", "8"])
 @pytest.mark.parametrize("name", SCENES)
-def test_wide_bvh_is_bit_exact(lib, name, monkeypatch):
-    """the 4-wide quantised BLAS the GPU kernels walk (ray_amd/csrc/rt_bvh4.h): conservative boxes + the reference's own
-    slab and triangle tests must reproduce RendererRef bit for bit, hits and frames"""
-    monkeypatch.setenv("HOSTSIM_BVH4", "1")
+def test_wide_bvh_is_bit_exact(lib, name, width, monkeypatch):
+    """the quantised wide BLAS forms the GPU kernels walk -- 8-wide (ray_amd/csrc/rt_bvh8.h, the product default: octant-ordered
+    slots, one stack entry per level, its own triangle order) and 4-wide (rt_bvh4.h): conservative boxes + the reference's own
+    triangle test must reproduce RendererRef bit for bit, hits and frames"""
+    monkeypatch.setenv("HOSTSIM_BVH4", "1" if width == "4" else "0")
+    monkeypatch.setenv("HOSTSIM_BVH8", "1" if width == "8" else "0")
+    if width == "8":
+        monkeypatch.setenv("HOSTSIM_REFINE", "2")
     g = util.golden_ref(name)
     ctx = util.make_context(lib, name)
     _, hits, tc = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)

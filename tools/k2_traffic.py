@@ -15,7 +15,7 @@ instrumented passes (other kernels: k_trace_closest<true,...>); every product pa
 Unit of both counters: KiB.  Appends / replaces the entry for this (workload, steps, iterations_per_pass)."""
 import csv, glob, json, os, re, sys
 
-K2_FORMS = ("k_trace_closest<false, true", "k_trace_closest_refill")
+K2_FORMS = ("k_trace_closest<false, 8", "k_trace_closest<false, 4", "k_trace_closest<false, true", "k_trace_closest_refill")
 
 
 def short(name):
