@@ -375,6 +375,7 @@ def main():
     t_rendered = time.perf_counter()
     if dist is None:  # what the exchange is at N > 1: the finished frame leaves the GPU once per image
         ctx.readback(hip.BUF_RAW, out=host_frame)
+    t_readback = time.perf_counter()
     exchange()
     ctx.sync()
     torch.cuda.synchronize()
@@ -496,6 +497,9 @@ def main():
             "stage_us_per_step": {k: v / K for k, v in stages.items() if v},
             "scene_build_s": info["build_s"],
         }
+        out["render_ms"] = (t_rendered - t0) * 1e3   # the K iterations, stream drained
+        if dist is None:
+            out["readback_ms"] = (t_readback - t_rendered) * 1e3  # the finished frame to (page-locked) host memory, once per image
         if rank_times is not None:
             out["exchange_ms"] = rank_times["exchange_ms_rank0"]
             out["rank_render_ms"] = rank_times["render_ms"]

@@ -409,6 +409,18 @@ RAYHIP_API int rayhip_readback_device(rayhip_ctx *ctx, int which, void *dst_devi
 RAYHIP_API int rayhip_set_raw_device(rayhip_ctx *ctx, const void *src_device_rgba, int pitch_px,
                                      const rayhip_camera *cam);
 
+/* ---- UNet denoiser (RendererBase::InitUNetFilter + DenoiseImage(int pass, const RegionContext &), RendererBase.h:199-227;
+ * reference implementation RendererCPU.h:790-1007, 1261-1310 over internal/Convolution.h; GPU twin shaders/convolution.comp.glsl) ----
+ * Sixteen 3 x 3 convolution passes of OIDN's UNet over (running mean, base colour, depth-normals), each one implicit GEMM on
+ * the f32 matrix cores (ray_amd/csrc/unet_kernels.hip).  rayhip_unet_init takes the weights exactly as the reference's own
+ * SetupUNetWeights<float>(alignment, &offsets, weights) lays them out (internal/UNetFilter.h:27-47: `offsets` is
+ * unet_weight_offsets_t as 32 ints) and re-packs them for the device.  rayhip_denoise_unet runs pass 0 .. 15 (or -1: all) on
+ * `rect` (corner a multiple of 16); the last pass writes RAW (alpha untouched) and FINAL = Tonemap(RAW) with `cam`. */
+RAYHIP_API int rayhip_unet_init(rayhip_ctx *ctx, const float *weights, int weights_count, const int32_t offsets[32], int alignment);
+RAYHIP_API int rayhip_denoise_unet(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int pass);
+/* test hook: activation tensor `which` (0 .. 14 in the order of unet_filter_tensors_t) incl. its one-pixel border, NHWC */
+RAYHIP_API int rayhip_unet_read_tensor(rayhip_ctx *ctx, int which, float *dst, size_t capacity_floats, int out_dims[3]);
+
 /* ---- multi-GPU: the frame exchange behind the C ABI (new, the reference has no multi-GPU mode) ----
  * N contexts (one per GPU) render the tiles rayhip_set_shard deals them; ONE exchange over RCCL/xGMI then assembles the
  * frame on `root`: the shards are disjoint tiles, so every rank sends the tiles it owns, densely packed (1/N of the

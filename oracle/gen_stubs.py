@@ -5,11 +5,16 @@ TEST INFRASTRUCTURE (oracle build).  Writes ONLY under oracle/_ref/gen (git-igno
 
 * Config.h -- what CMake's configure_file would emit from Config.h.in (reference
   CMakeLists.txt:204) with ENABLE_REF_IMPL and ENABLE_SIMD_IMPL on, VK/DX off.
-* zero-filled stand-ins for the three headers named in /root/reference/.MISSING_LARGE_BLOBS:
-  internal/precomputed/__3d_noise_tex.inl, __cirrus_tex.inl (physical-sky clouds,
-  AtmosphereRef.cpp:8-9) and __oidn_weights_hdr_alb_nrm.inl (UNet denoiser, UNetFilter.cpp:12-14).
-  Neither subsystem is on the hot path (OUT OF SCOPE) and neither is exercised
-  by any scene used here; the stubs only satisfy the linker.
+* stand-ins for the three headers named in /root/reference/.MISSING_LARGE_BLOBS:
+  internal/precomputed/__3d_noise_tex.inl, __cirrus_tex.inl (physical-sky clouds, AtmosphereRef.cpp:8-9):
+  zero-filled, that subsystem is out of scope (SURVEY.md section 2) and no scene used here reaches it;
+  __oidn_weights_hdr_alb_nrm.inl (UNet denoiser, UNetFilter.cpp:12-14): the trained network is not in the
+  tree, so the 32 arrays are filled with DETERMINISTIC pseudo-random half-precision weights of the right
+  shapes (uniform in +-sqrt(6 / fan_in): activations stay O(1) through the sixteen passes).  The filter then
+  computes a well-defined function of its inputs -- not a denoised picture, but exactly the arithmetic the
+  HIP restatement (ray_amd/csrc/unet_kernels.hip) has to reproduce pass by pass, with the same file feeding
+  the oracle (oracle/_ref) and the product's host library (ray_amd/host: RendererHIP::InitUNetFilter takes
+  the weights from the reference's own SetupUNetWeights).
 """
 import os
 import re
@@ -27,12 +32,29 @@ def main(ref: str, gen: str) -> None:
     with open(os.path.join(pre, "__cirrus_tex.inl"), "w") as f:
         f.write("extern const int CIRRUS_TEX_RES = 2;\nextern const uint8_t __cirrus_tex[8] = {0};\n")
 
-    # weight array names are whatever UNetFilter.cpp pulls out of the namespace
+    # weight array names are whatever UNetFilter.cpp pulls out of the namespace; shapes: the (out, in) channel counts of the
+    # sixteen convolutions as SetupUNetWeights reorders them (UNetFilter.cpp:412-570), 3x3 kernels
+    import numpy as np
     src = open(os.path.join(ref, "internal", "UNetFilter.cpp"), encoding="utf-8", errors="ignore").read()
     names = sorted(set(re.findall(r"unet_weights_hdr_alb_nrm::(\w+)", src)))
+    shapes = {"enc_conv0": (32, 9), "enc_conv1": (32, 32), "enc_conv2": (48, 32), "enc_conv3": (64, 48), "enc_conv4": (80, 64),
+              "enc_conv5a": (96, 80), "enc_conv5b": (96, 96), "dec_conv4a": (112, 96 + 64), "dec_conv4b": (112, 112),
+              "dec_conv3a": (96, 112 + 48), "dec_conv3b": (96, 96), "dec_conv2a": (64, 96 + 32), "dec_conv2b": (64, 64),
+              "dec_conv1a": (64, 64 + 9), "dec_conv1b": (32, 64), "dec_conv0": (3, 32)}
     with open(os.path.join(pre, "__oidn_weights_hdr_alb_nrm.inl"), "w") as f:
-        for n in names:
-            f.write(f"const uint16_t {n}[1] = {{0}};\n")
+        for k, n in enumerate(names):
+            layer, kind = n.rsplit("_", 1)
+            out_ch, in_ch = shapes[layer]
+            rng = np.random.Generator(np.random.PCG64(1234567 + k))  # (bit-reproducible across numpy versions)
+            if kind == "weight":
+                a = (6.0 / (9.0 * in_ch)) ** 0.5
+                vals = rng.uniform(-a, a, size=out_ch * in_ch * 9)
+            else:
+                vals = rng.uniform(-0.1, 0.1, size=out_ch)
+            bits = vals.astype(np.float16).view(np.uint16)
+            f.write(f"const uint16_t {n}[{len(bits)}] = {{")
+            f.write(",".join(str(int(b)) for b in bits))
+            f.write("};\n")
 
 
 if __name__ == "__main__":

@@ -12,7 +12,9 @@
 #include "internal/CDFUtils.h"
 #include "internal/CoreRef.h"
 #include "internal/SceneCPU.h"
+#include "internal/DenoiseRef.h"
 #include "internal/ShadeRef.h"
+#include "internal/UNetFilter.h"
 
 #include "../ray_amd/csrc/scene_blob.h"
 #include "../ray_amd/host/scene_export.h"
@@ -226,3 +228,201 @@ int refk_shade(ray_scene *s, int w, int h, int bounce, int iteration, const rayh
 }
 
 } // extern "C"
+
+
+int refk_unet_weights(float *out, const int capacity, int32_t out_offsets[32]) {
+    const int n = Ray::SetupUNetWeights<float>(8, nullptr, nullptr);
+    if (!out) {
+        return n;
+    }
+    if (capacity < n) {
+        return 0;
+    }
+    Ray::unet_weight_offsets_t offsets;
+    static_assert(sizeof(offsets) == 32 * sizeof(int32_t), "unet_weight_offsets_t is 32 ints");
+    Ray::SetupUNetWeights(8, &offsets, out);
+    memcpy(out_offsets, &offsets, sizeof(offsets));
+    return n;
+}
+
+// ---- the UNet denoiser, pass by pass (RendererCPU.h:790-1007 restated over the reference's own convolution kernels) ----
+size_t refk_unet_passes(const int w_, const int h_, const float *full_rgba, const float *base_rgba, const float *depth_normals_rgba,
+                        const int last_pass, float *out, const size_t capacity, int out_dims[3]) {
+    using namespace Ray;
+    if (last_pass < 0 || last_pass > 15) {
+        return 0;
+    }
+    // InitUNetFilter / UpdateUNetFilterMemory, RendererCPU.h:1261-1310
+    unet_weight_offsets_t offsets_v;
+    std::vector<float> weights_v(size_t(SetupUNetWeights<float>(8, nullptr, nullptr)));
+    SetupUNetWeights(8, &offsets_v, weights_v.data());
+    unet_filter_tensors_t T;
+    SmallVector<int, 2> deps[UNetFilterPasses];
+    const int required = SetupUNetFilter(w_, h_, false, false, T, deps);
+    std::vector<float> heap(size_t(required), 0.0f);
+    struct {
+        float *encConv0, *pool1, *pool2, *pool3, *pool4, *enc_conv5a, *upsample4, *dec_conv4a, *upsample3, *dec_conv3a, *upsample2,
+            *dec_conv2a, *upsample1, *dec_conv1a, *dec_conv1b;
+    } t = {heap.data() + T.enc_conv0_offset, heap.data() + T.pool1_offset,     heap.data() + T.pool2_offset,
+           heap.data() + T.pool3_offset,     heap.data() + T.pool4_offset,     heap.data() + T.enc_conv5a_offset,
+           heap.data() + T.upsample4_offset, heap.data() + T.dec_conv4a_offset, heap.data() + T.upsample3_offset,
+           heap.data() + T.dec_conv3a_offset, heap.data() + T.upsample2_offset, heap.data() + T.dec_conv2a_offset,
+           heap.data() + T.upsample1_offset, heap.data() + T.dec_conv1a_offset, heap.data() + T.dec_conv1b_offset};
+    const float *weights = weights_v.data();
+    const unet_weight_offsets_t *offsets = &offsets_v;
+    const int w_rounded = 16 * ((w_ + 15) / 16), h_rounded = 16 * ((h_ + 15) / 16);
+    aligned_vector<float, 64> temp_data;
+    std::vector<float> filtered(full_rgba, full_rgba + size_t(w_) * h_ * 4); // raw_filtered_buf_ starts as the running mean (:635)
+    float *written = nullptr;
+    int dims[3] = {0, 0, 0};
+    for (int pass = 0; pass <= last_pass; ++pass) {
+        rect_t r = {0, 0, w_, h_};
+        if (pass < 15) {
+            r.w = 16 * ((r.w + 15) / 16), r.h = 16 * ((r.h + 15) / 16);
+        }
+        auto scaled = [&](const int div) {
+            r.x /= div, r.y /= div, r.w = (r.w + div - 1) / div, r.h = (r.h + div - 1) / div;
+        };
+        auto wrote = [&](float *p, const int div, const int ch) {
+            written = p, dims[0] = h_rounded / div + 2, dims[1] = w_rounded / div + 2, dims[2] = ch;
+        };
+        switch (pass) {
+        case 0:
+            Ref::Convolution3x3<3, 3, 3, 4, 32, ePreOp::HDRTransfer, ePreOp::None, ePreOp::PositiveNormalize>(
+                full_rgba, base_rgba, depth_normals_rgba, r, w_, h_, w_rounded, h_rounded, w_, &weights[offsets->enc_conv0_weight],
+                &weights[offsets->enc_conv0_bias], t.encConv0 + (w_rounded + 3) * 32, w_rounded + 2, temp_data);
+            Ref::ClearBorders(r, w_rounded, h_rounded, false, 32, t.encConv0);
+            wrote(t.encConv0, 1, 32);
+            break;
+        case 1:
+            Ref::Convolution3x3<32, 32, 32, ePostOp::Downsample>(t.encConv0 + (w_rounded + 3) * 32, r, w_rounded, h_rounded, w_rounded + 2,
+                                                                  &weights[offsets->enc_conv1_weight], &weights[offsets->enc_conv1_bias],
+                                                                  t.pool1 + (w_rounded / 2 + 3) * 32, w_rounded / 2 + 2);
+            Ref::ClearBorders(r, w_rounded, h_rounded, true, 32, t.pool1);
+            wrote(t.pool1, 2, 32);
+            break;
+        case 2:
+            scaled(2);
+            Ref::Convolution3x3<32, 48, 48, ePostOp::Downsample>(t.pool1 + (w_rounded / 2 + 3) * 32, r, w_rounded / 2, h_rounded / 2,
+                                                                  w_rounded / 2 + 2, &weights[offsets->enc_conv2_weight],
+                                                                  &weights[offsets->enc_conv2_bias], t.pool2 + (w_rounded / 4 + 3) * 48,
+                                                                  w_rounded / 4 + 2);
+            Ref::ClearBorders(r, w_rounded / 2, h_rounded / 2, true, 48, t.pool2);
+            wrote(t.pool2, 4, 48);
+            break;
+        case 3:
+            scaled(4);
+            Ref::Convolution3x3<48, 64, 64, ePostOp::Downsample>(t.pool2 + (w_rounded / 4 + 3) * 48, r, w_rounded / 4, h_rounded / 4,
+                                                                  w_rounded / 4 + 2, &weights[offsets->enc_conv3_weight],
+                                                                  &weights[offsets->enc_conv3_bias], t.pool3 + (w_rounded / 8 + 3) * 64,
+                                                                  w_rounded / 8 + 2);
+            Ref::ClearBorders(r, w_rounded / 4, h_rounded / 4, true, 64, t.pool3);
+            wrote(t.pool3, 8, 64);
+            break;
+        case 4:
+            scaled(8);
+            Ref::Convolution3x3<64, 80, 80, ePostOp::Downsample>(t.pool3 + (w_rounded / 8 + 3) * 64, r, w_rounded / 8, h_rounded / 8,
+                                                                  w_rounded / 8 + 2, &weights[offsets->enc_conv4_weight],
+                                                                  &weights[offsets->enc_conv4_bias], t.pool4 + (w_rounded / 16 + 3) * 80,
+                                                                  w_rounded / 16 + 2);
+            Ref::ClearBorders(r, w_rounded / 8, h_rounded / 8, true, 80, t.pool4);
+            wrote(t.pool4, 16, 80);
+            break;
+        case 5:
+            scaled(16);
+            Ref::Convolution3x3<80, 96, 96>(t.pool4 + (w_rounded / 16 + 3) * 80, r, w_rounded / 16, h_rounded / 16, w_rounded / 16 + 2,
+                                            &weights[offsets->enc_conv5a_weight], &weights[offsets->enc_conv5a_bias],
+                                            t.enc_conv5a + (w_rounded / 16 + 3) * 96, w_rounded / 16 + 2);
+            Ref::ClearBorders(r, w_rounded / 16, h_rounded / 16, false, 96, t.enc_conv5a);
+            wrote(t.enc_conv5a, 16, 96);
+            break;
+        case 6:
+            scaled(16);
+            Ref::Convolution3x3<96, 96, 96>(t.enc_conv5a + (w_rounded / 16 + 3) * 96, r, w_rounded / 16, h_rounded / 16, w_rounded / 16 + 2,
+                                            &weights[offsets->enc_conv5b_weight], &weights[offsets->enc_conv5b_bias],
+                                            t.upsample4 + (w_rounded / 16 + 3) * 96, w_rounded / 16 + 2);
+            Ref::ClearBorders(r, w_rounded / 16, h_rounded / 16, false, 96, t.upsample4);
+            wrote(t.upsample4, 16, 96);
+            break;
+        case 7:
+            scaled(8);
+            Ref::ConvolutionConcat3x3<96, 64, 112, ePreOp::Upsample>(t.upsample4 + (w_rounded / 16 + 3) * 96, t.pool3 + (w_rounded / 8 + 3) * 64, r,
+                                                                      w_rounded / 8, h_rounded / 8, w_rounded / 16 + 2, w_rounded / 8 + 2,
+                                                                      &weights[offsets->dec_conv4a_weight], &weights[offsets->dec_conv4a_bias],
+                                                                      t.dec_conv4a + (w_rounded / 8 + 3) * 112, w_rounded / 8 + 2);
+            Ref::ClearBorders(r, w_rounded / 8, h_rounded / 8, false, 112, t.dec_conv4a);
+            wrote(t.dec_conv4a, 8, 112);
+            break;
+        case 8:
+            scaled(8);
+            Ref::Convolution3x3<112, 112, 112>(t.dec_conv4a + (w_rounded / 8 + 3) * 112, r, w_rounded / 8, h_rounded / 8, w_rounded / 8 + 2,
+                                               &weights[offsets->dec_conv4b_weight], &weights[offsets->dec_conv4b_bias],
+                                               t.upsample3 + (w_rounded / 8 + 3) * 112, w_rounded / 8 + 2);
+            Ref::ClearBorders(r, w_rounded / 8, h_rounded / 8, false, 112, t.upsample3);
+            wrote(t.upsample3, 8, 112);
+            break;
+        case 9:
+            scaled(4);
+            Ref::ConvolutionConcat3x3<112, 48, 96, ePreOp::Upsample>(t.upsample3 + (w_rounded / 8 + 3) * 112, t.pool2 + (w_rounded / 4 + 3) * 48, r,
+                                                                      w_rounded / 4, h_rounded / 4, w_rounded / 8 + 2, w_rounded / 4 + 2,
+                                                                      &weights[offsets->dec_conv3a_weight], &weights[offsets->dec_conv3a_bias],
+                                                                      t.dec_conv3a + (w_rounded / 4 + 3) * 96, w_rounded / 4 + 2);
+            Ref::ClearBorders(r, w_rounded / 4, h_rounded / 4, false, 96, t.dec_conv3a);
+            wrote(t.dec_conv3a, 4, 96);
+            break;
+        case 10:
+            scaled(4);
+            Ref::Convolution3x3<96, 96, 96>(t.dec_conv3a + (w_rounded / 4 + 3) * 96, r, w_rounded / 4, h_rounded / 4, w_rounded / 4 + 2,
+                                            &weights[offsets->dec_conv3b_weight], &weights[offsets->dec_conv3b_bias],
+                                            t.upsample2 + (w_rounded / 4 + 3) * 96, w_rounded / 4 + 2);
+            Ref::ClearBorders(r, w_rounded / 4, h_rounded / 4, false, 96, t.upsample2);
+            wrote(t.upsample2, 4, 96);
+            break;
+        case 11:
+            scaled(2);
+            Ref::ConvolutionConcat3x3<96, 32, 64, ePreOp::Upsample>(t.upsample2 + (w_rounded / 4 + 3) * 96, t.pool1 + (w_rounded / 2 + 3) * 32, r,
+                                                                     w_rounded / 2, h_rounded / 2, w_rounded / 4 + 2, w_rounded / 2 + 2,
+                                                                     &weights[offsets->dec_conv2a_weight], &weights[offsets->dec_conv2a_bias],
+                                                                     t.dec_conv2a + (w_rounded / 2 + 3) * 64, w_rounded / 2 + 2);
+            Ref::ClearBorders(r, w_rounded / 2, h_rounded / 2, false, 64, t.dec_conv2a);
+            wrote(t.dec_conv2a, 2, 64);
+            break;
+        case 12:
+            scaled(2);
+            Ref::Convolution3x3<64, 64, 64>(t.dec_conv2a + (w_rounded / 2 + 3) * 64, r, w_rounded / 2, h_rounded / 2, w_rounded / 2 + 2,
+                                            &weights[offsets->dec_conv2b_weight], &weights[offsets->dec_conv2b_bias],
+                                            t.upsample1 + (w_rounded / 2 + 3) * 64, w_rounded / 2 + 2);
+            Ref::ClearBorders(r, w_rounded / 2, h_rounded / 2, false, 64, t.upsample1);
+            wrote(t.upsample1, 2, 64);
+            break;
+        case 13:
+            Ref::ConvolutionConcat3x3<64, 3, 3, 3, 4, 64, ePreOp::Upsample, ePreOp::HDRTransfer, ePreOp::None, ePreOp::PositiveNormalize>(
+                t.upsample1 + (w_rounded / 2 + 3) * 64, full_rgba, base_rgba, depth_normals_rgba, r, w_rounded, h_rounded, w_, h_,
+                w_rounded / 2 + 2, w_, &weights[offsets->dec_conv1a_weight], &weights[offsets->dec_conv1a_bias],
+                t.dec_conv1a + (w_rounded + 3) * 64, w_rounded + 2, temp_data);
+            Ref::ClearBorders(r, w_rounded, h_rounded, false, 64, t.dec_conv1a);
+            wrote(t.dec_conv1a, 1, 64);
+            break;
+        case 14:
+            Ref::Convolution3x3<64, 32, 32>(t.dec_conv1a + (w_rounded + 3) * 64, r, w_rounded, h_rounded, w_rounded + 2,
+                                            &weights[offsets->dec_conv1b_weight], &weights[offsets->dec_conv1b_bias],
+                                            t.dec_conv1b + (w_rounded + 3) * 32, w_rounded + 2);
+            Ref::ClearBorders(r, w_rounded, h_rounded, false, 32, t.dec_conv1b);
+            wrote(t.dec_conv1b, 1, 32);
+            break;
+        case 15:
+            Ref::Convolution3x3<32, 3, 4, ePostOp::HDRTransfer>(t.dec_conv1b + (w_rounded + 3) * 32, r, w_, h_, w_rounded + 2,
+                                                                 &weights[offsets->dec_conv0_weight], &weights[offsets->dec_conv0_bias],
+                                                                 filtered.data(), w_);
+            written = filtered.data(), dims[0] = h_, dims[1] = w_, dims[2] = 4;
+            break;
+        }
+    }
+    const size_t n = size_t(dims[0]) * dims[1] * dims[2];
+    if (!written || n > capacity) {
+        return 0;
+    }
+    memcpy(out, written, n * sizeof(float));
+    out_dims[0] = dims[0], out_dims[1] = dims[1], out_dims[2] = dims[2];
+    return n;
+}

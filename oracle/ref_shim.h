@@ -48,6 +48,19 @@ int refk_shade(ray_scene *s, int w, int h, int bounce, int iteration, const rayh
                int count, float *inout_color, rayhip_ray *out_secondary, int *out_secondary_count,
                rayhip_shadow_ray *out_shadow, int *out_shadow_count);
 
+/* The UNet denoiser pass by pass, on caller-provided images: the schedule of Cpu::Renderer::DenoiseImage(pass, region)
+ * (RendererCPU.h:790-1007) with the reference's own Ref::Convolution3x3 / ConvolutionConcat3x3 / ClearBorders
+ * (DenoiseRef.cpp, Convolution.h), weights from SetupUNetWeights<float>(8) and tensor sizes from SetupUNetFilter (no
+ * aliasing), full-frame region.  Runs passes 0 .. last_pass and copies out the tensor pass `last_pass` wrote -- including
+ * its one-pixel border, NHWC, dims = {rows, columns, channels} -- or, for pass 15, the w*h*4 filtered image (alpha taken
+ * from `full`).  Returns the number of floats written, 0 on error.  (The end-to-end path through the renderer is
+ * ray_renderer_init_unet / ray_renderer_denoise_unet; tests check that the two agree bit for bit.) */
+/* SetupUNetWeights<float>(8, &offsets, weights) (UNetFilter.cpp:296-570): the weight blob Cpu::Renderer::InitUNetFilter keeps and
+ * unet_weight_offsets_t as 32 ints; returns the number of floats (call with out == NULL for the size) */
+int refk_unet_weights(float *out, int capacity, int32_t out_offsets[32]);
+size_t refk_unet_passes(int w, int h, const float *full_rgba, const float *base_rgba, const float *depth_normals_rgba, int last_pass,
+                        float *out, size_t capacity, int out_dims[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,8 @@ def declare(lib):
         "ray_renderer_create_scene": (vp, [vp]),
         "ray_renderer_render": (None, [vp, vp, vp]),
         "ray_renderer_denoise": (None, [vp, vp]),
+        "ray_renderer_init_unet": (C.c_int, [vp]),
+        "ray_renderer_denoise_unet": (None, [vp, C.c_int, vp]),
         "ray_renderer_get_pixels": (C.c_int, [vp, C.c_int, vp]),
         "ray_renderer_get_stats": (None, [vp, C.POINTER(Stats)]),
         "ray_renderer_reset_stats": (None, [vp]),

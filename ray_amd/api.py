@@ -347,6 +347,14 @@ class RendererBase:
         """RendererBase::DenoiseImage(const RegionContext &): the NLM denoiser"""
         self._lib.ray_renderer_denoise(self._ptr, region._bind(self._lib))
 
+    def InitUNetFilter(self) -> int:
+        """RendererBase::InitUNetFilter(alias_memory=false): returns the number of passes (16)"""
+        return int(self._lib.ray_renderer_init_unet(self._ptr))
+
+    def DenoiseImageUNet(self, pass_index: int, region: RegionContext):
+        """RendererBase::DenoiseImage(int pass, const RegionContext &): one pass of the UNet denoiser"""
+        self._lib.ray_renderer_denoise_unet(self._ptr, pass_index, region._bind(self._lib))
+
     def _pixels(self, which: int) -> np.ndarray:
         w, h = self.size()
         out = np.empty((h, w, 4), dtype=np.float32)

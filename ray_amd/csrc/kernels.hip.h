@@ -367,7 +367,11 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 #ifndef RT_REFILL_MIN_WAVES
 #define RT_REFILL_MIN_WAVES 5 // 96 VGPRs, no scratch (6 waves: 80 VGPRs with spills in the loop, slower)
 #endif
-template <int WIDE>
+// MIN_WAIT: lanes that must be waiting before the wavefront leaves the BLAS loop to serve them.  RT_REFILL_MIN for the incoherent
+// secondary bounces; WAVE for coherent primary rays -- the wavefront then finishes its 64 rays together and takes the next
+// chunk whole, i.e. the schedule of the plain kernel, with this kernel's flat register footprint (96 VGPRs, no spill stores
+// inside the walk, where the plain kernel's nested walks spill 60 VGPRs at 80: 7.8 GB of scratch writes per primary launch)
+template <int WIDE, int MIN_WAIT = RT_REFILL_MIN>
 __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_refill(const SceneView sc, const TraceParams tp, const RaySoA rays,
                                                                const HitSoA hits, const RayQueue queue, const int init_hits,
                                                                uint32_t *__restrict__ stack_spill, const Layering layers) {
@@ -450,7 +454,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
 #ifdef RT_PROFILE_TRACE
             st_a += n_node, st_b += n_leaf, st_iter += 1;
 #endif
-            if (__builtin_amdgcn_readfirstlane(int(n_node + n_leaf == 0 || n_out >= RT_REFILL_MIN))) {
+            if (__builtin_amdgcn_readfirstlane(int(n_node + n_leaf == 0 || n_out >= MIN_WAIT))) {
                 break;
             }
             if (__builtin_amdgcn_readfirstlane(int(n_node >= n_leaf))) {
@@ -812,6 +816,17 @@ __global__ void __launch_bounds__(256) k_retonemap(const AccumParams p, const Pi
         px.raw[i] = ff;
         const f4 c = tonemap(p, f4{ff.x, ff.y, ff.z, ff.w});
         px.final_[i] = mkfloat4(c.x, c.y, c.z, c.w);
+    }
+}
+
+// FINAL <- Tonemap(RAW) over a rect: the tail of DenoiseImage(pass 15) (RendererCPU.h:984-995)
+__global__ void __launch_bounds__(256) k_tonemap_raw_rect(const AccumParams p, const PixelBuffers px) {
+    const int n = p.rect[2] * p.rect[3];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int idx = (p.rect[1] + i / p.rect[2]) * p.w + p.rect[0] + i % p.rect[2];
+        const float4 r = px.raw[idx];
+        const f4 c = tonemap(p, f4{r.x, r.y, r.z, r.w});
+        px.final_[idx] = mkfloat4(c.x, c.y, c.z, c.w);
     }
 }
 

@@ -80,6 +80,7 @@ ENTRY_POINTS = (
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand", "k_shade",
     "comm_create", "comm_unique_id", "comm_create_rank", "comm_bind", "comm_reduce_framebuffers", "comm_destroy",
+    "unet_init", "denoise_unet", "unet_read_tensor",
     "export_shard_device", "owned_bytes", "export_owned", "import_owned", "finish_import",
 )
 
@@ -134,6 +135,9 @@ class Library:
         f("import_owned").argtypes = [vp, C.c_uint32, C.c_int, vp, C.c_size_t]
         f("finish_import").argtypes = [vp, C.POINTER(Camera)]
         if prefix == "rayhip_":
+            f("unet_init").argtypes = [vp, vp, C.c_int, vp, C.c_int]
+            f("denoise_unet").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int]
+            f("unet_read_tensor").argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_int * 3)]
             f("readback_device").argtypes = [vp, C.c_int, vp, C.c_int]
             f("set_raw_device").argtypes = [vp, vp, C.c_int, C.POINTER(Camera)]
             f("export_shard_device").argtypes = [vp, C.c_int, vp]
@@ -291,6 +295,25 @@ class Context:
 
     def finish_import(self, cam: Camera = None):
         self.L.check(self.L.fn("finish_import")(self._ctx, C.byref(cam or self.cam)))
+
+    # UNet denoiser (rayhip.h: rayhip_unet_init / rayhip_denoise_unet)
+    def unet_init(self, weights: np.ndarray, offsets: np.ndarray, alignment: int = 8):
+        weights = np.ascontiguousarray(weights, dtype=np.float32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        assert offsets.size == 32
+        self.L.check(self.L.fn("unet_init")(self._ctx, weights.ctypes.data, weights.size, offsets.ctypes.data, alignment))
+
+    def denoise_unet(self, pass_index: int = -1, rect=None, cam: Camera = None):
+        r = (C.c_int * 4)(*((0, 0, self.w, self.h) if rect is None else rect))
+        self.L.check(self.L.fn("denoise_unet")(self._ctx, C.byref(cam or self.cam), C.byref(r), pass_index))
+
+    def unet_read_tensor(self, which: int) -> np.ndarray:
+        wr, hr = 16 * ((self.w + 15) // 16), 16 * ((self.h + 15) // 16)
+        buf = np.zeros((wr + 2) * (hr + 2) * 112, dtype=np.float32)
+        dims = (C.c_int * 3)()
+        self.L.check(self.L.fn("unet_read_tensor")(self._ctx, which, buf.ctypes.data, buf.size, C.byref(dims)))
+        n = dims[0] * dims[1] * dims[2]
+        return buf[:n].reshape(dims[0], dims[1], dims[2]).copy()
 
     def set_shard(self, tile: int, shard_count: int, shard_index: int):
         """multi-GPU tile sharding: render only the tiles whose ordinal % shard_count == shard_index"""

@@ -25,6 +25,7 @@
 #include "internal/CDFUtils.h"
 #include "internal/Core.h"
 #include "internal/SceneCPU.h"
+#include "internal/UNetFilter.h"
 
 #include "../../include/rayhip.h"
 #include "../csrc/scene_blob.h"
@@ -126,6 +127,7 @@ class Renderer final : public RendererBase {
     int lut_transform_ = 0; // view transform whose look-up table is on the device
     bool use_tex_compression_ = false; // settings_t::use_tex_compression, handed to the scenes this renderer creates
     int max_batch_ = 64; // further limited by rayhip_max_batch() (frame size)
+    bool unet_ready_ = false;
 
     void Flush() const {
         if (pending_count_ > 0) {
@@ -458,7 +460,25 @@ class Renderer final : public RendererBase {
             d = true;
         }
     }
-    void DenoiseImage(int, const RegionContext &) override { log_->Warning("RendererHIP: UNet denoiser is not implemented"); }
+    // UNet denoiser (RendererCPU.h:790-1007): the sixteen convolution passes run on the matrix cores of the root device
+    // (rayhip_denoise_unet), on what the iterations so far accumulated -- every rank's tiles gathered first
+    void DenoiseImage(const int pass, const RegionContext &region) override {
+        Assemble();
+        if (!have_cam_) {
+            log_->Error("RendererHIP: DenoiseImage before the first RenderScene");
+            return;
+        }
+        if (!unet_ready_) {
+            log_->Error("RendererHIP: DenoiseImage(pass, region) needs InitUNetFilter first");
+            return;
+        }
+        const rect_t &r = region.rect();
+        const int rect[4] = {r.x, r.y, r.w, r.h};
+        check(rayhip_denoise_unet(ctx_, &pending_cam_, rect, pass), "rayhip_denoise_unet");
+        for (bool &d : host_dirty_) {
+            d = true;
+        }
+    }
     void UpdateSpatialCache(const SceneBase &, RegionContext &) override {}
     void ResolveSpatialCache(const SceneBase &, const std::function<void(int, int, ParallelForFunction &&)> &) override {}
     void ResetSpatialCache(const SceneBase &, const std::function<void(int, int, ParallelForFunction &&)> &) override {}
@@ -477,9 +497,22 @@ class Renderer final : public RendererBase {
         check(rayhip_get_stage_times(ctx_, &rs, 1), "rayhip_get_stage_times");
     }
 
+    // the network's weights come from the reference's own tables, laid out by its own SetupUNetWeights (UNetFilter.cpp:296-570,
+    // what Cpu::Renderer::InitUNetFilter does at RendererCPU.h:1261-1266); librayhip re-packs them for its kernels.  The passes
+    // do not alias memory here, so no pass depends on another one's storage being free.
     unet_filter_properties_t InitUNetFilter(bool, const std::function<void(int, int, ParallelForFunction &&)> &) override {
-        log_->Warning("RendererHIP: UNet denoiser is not implemented");
-        return {};
+        unet_weight_offsets_t offsets;
+        std::vector<float> weights(size_t(SetupUNetWeights<float>(8, nullptr, nullptr)));
+        SetupUNetWeights(8, &offsets, weights.data());
+        static_assert(sizeof(offsets) == 32 * sizeof(int32_t), "unet_weight_offsets_t is 32 ints");
+        check(rayhip_unet_init(ctx_, weights.data(), int(weights.size()), reinterpret_cast<const int32_t *>(&offsets), 8), "rayhip_unet_init");
+        unet_ready_ = true;
+        unet_filter_properties_t props;
+        props.pass_count = UNetFilterPasses;
+        for (int i = 0; i < UNetFilterPasses; ++i) {
+            std::fill(&props.alias_dependencies[i][0], &props.alias_dependencies[i][0] + 4, -1);
+        }
+        return props;
     }
 };
 

@@ -207,6 +207,8 @@ ray_scene *ray_renderer_create_scene(ray_renderer *r) {
 }
 void ray_renderer_render(ray_renderer *r, ray_scene *s, ray_region *region) { r->r->RenderScene(*s->s, region->ctx); }
 void ray_renderer_denoise(ray_renderer *r, ray_region *region) { r->r->DenoiseImage(region->ctx); }
+int ray_renderer_init_unet(ray_renderer *r) { return r->r->InitUNetFilter(false, Ray::parallel_for_serial).pass_count; }
+void ray_renderer_denoise_unet(ray_renderer *r, int pass, ray_region *region) { r->r->DenoiseImage(pass, region->ctx); }
 int ray_renderer_get_pixels(ray_renderer *r, int which, float *dst) {
     Ray::color_data_rgba_t px = {};
     switch (which) {

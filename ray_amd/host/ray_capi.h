@@ -169,6 +169,9 @@ void ray_renderer_clear(ray_renderer *r, const float rgba[4]);     /* RendererBa
 ray_scene *ray_renderer_create_scene(ray_renderer *r);             /* RendererBase::CreateScene */
 void ray_renderer_render(ray_renderer *r, ray_scene *s, ray_region *region); /* RendererBase::RenderScene */
 void ray_renderer_denoise(ray_renderer *r, ray_region *region);              /* RendererBase::DenoiseImage(region): NLM */
+/* RendererBase::InitUNetFilter(alias_memory = false, serial parallel_for); returns unet_filter_properties_t::pass_count */
+int ray_renderer_init_unet(ray_renderer *r);
+void ray_renderer_denoise_unet(ray_renderer *r, int pass, ray_region *region); /* RendererBase::DenoiseImage(pass, region) */
 /* which: 0 get_pixels_ref, 1 get_raw_pixels_ref, 2 aux BaseColor, 3 aux DepthNormals; dst = w*h*4 floats */
 int ray_renderer_get_pixels(ray_renderer *r, int which, float *dst);
 void ray_renderer_get_stats(ray_renderer *r, ray_stats *st); /* RendererBase::GetStats */

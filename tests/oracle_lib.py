@@ -44,8 +44,33 @@ def ref_lib():
         lib.refk_scrambled_rand.restype = None
         lib.refk_shade.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int), vp,
                                    C.POINTER(C.c_int)]
+        lib.refk_unet_weights.argtypes = [vp, C.c_int, vp]
+        lib.refk_unet_passes.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_int * 3)]
+        lib.refk_unet_passes.restype = C.c_size_t
         _ref = lib
     return _ref
+
+
+def ref_unet_weights():
+    """(weights, offsets[32]) as the reference's SetupUNetWeights<float>(8) lays them out"""
+    lib = ref_lib()
+    n = lib.refk_unet_weights(None, 0, None)
+    w = np.zeros(n, dtype=np.float32)
+    off = np.zeros(32, dtype=np.int32)
+    assert lib.refk_unet_weights(w.ctypes.data, n, off.ctypes.data) == n
+    return w, off
+
+
+def ref_unet_passes(full, base, dn, last_pass):
+    """the tensor (with border) pass `last_pass` of the reference's UNet writes, given the three input images [h, w, 4]"""
+    h, w = full.shape[:2]
+    full, base, dn = (np.ascontiguousarray(a, dtype=np.float32) for a in (full, base, dn))
+    wr, hr = 16 * ((w + 15) // 16), 16 * ((h + 15) // 16)
+    buf = np.zeros((wr + 2) * (hr + 2) * 112, dtype=np.float32)
+    dims = (C.c_int * 3)()
+    n = ref_lib().refk_unet_passes(w, h, full.ctypes.data, base.ctypes.data, dn.ctypes.data, last_pass, buf.ctypes.data, buf.size, C.byref(dims))
+    assert n > 0
+    return buf[:n].reshape(dims[0], dims[1], dims[2]).copy()
 
 
 def create_renderer(w, h, renderer_type="REF", verbose=False, use_tex_compression=False):
