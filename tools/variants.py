@@ -46,8 +46,10 @@ def build_one(name, flags):
         rr = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
         r.stderr += rr.stderr
         r.returncode |= rr.returncode
+    # (sort.o and unet_kernels.o carry no tuning knobs: the objects of the regular build are linked as they are)
     subprocess.run([g._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *[os.path.join(out, o + ".o") for o in objs],
-                    os.path.join(CSRC, "_build", "sort.o"), "-o", os.path.join(out, "librayhip.so")], cwd=CSRC, check=True)
+                    os.path.join(CSRC, "_build", "sort.o"), os.path.join(CSRC, "_build", "unet_kernels.o"), "-o", os.path.join(out, "librayhip.so")],
+                   cwd=CSRC, check=True)
     res = {}
     cur = None
     for line in r.stderr.splitlines():
