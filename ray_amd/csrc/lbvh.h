@@ -26,6 +26,8 @@
 //   7 emit        scan the emitted nodes / leaf entries into dense arrays, write reference-format nodes   (emit_node)
 #pragma once
 
+#include "host_parallel.h"
+
 #include <stdint.h>
 
 #include <algorithm>
@@ -208,6 +210,29 @@ inline std::vector<Box> centroid_boxes(const Input &in) {
         return std::vector<Box>(in.group_centroids, in.group_centroids + in.n_groups);
     }
     std::vector<Box> cbox(in.n_groups, empty_box());
+    // when the primitives come group after group (the leaf refinement hands them over that way) the groups are independent
+    // ranges and the loop is shared out over the host cores; min / max do not depend on the order, so the boxes are the same
+    bool grouped = true;
+    for (uint32_t p = 1; p < in.n_prims && grouped; ++p) {
+        grouped = in.prim_group[p] >= in.prim_group[p - 1];
+    }
+    if (grouped && in.n_prims > (1u << 16)) {
+        rayhip_host::parallel_blocks(in.n_prims, 1 << 16, [&](size_t b, size_t e) {
+            // a block takes the groups that START inside it (a group that straddles the block's end is finished by this block)
+            while (b < e && b > 0 && in.prim_group[b] == in.prim_group[b - 1]) {
+                ++b;
+            }
+            if (b >= e) {
+                return; // (the whole block belongs to a group that started earlier)
+            }
+            for (size_t p = b; p < in.n_prims && (p < e || in.prim_group[p] == in.prim_group[p - 1]); ++p) {
+                float c[3];
+                centroid_of(in.prim_box[p], c);
+                grow_point(cbox[in.prim_group[p]], c);
+            }
+        });
+        return cbox;
+    }
     for (uint32_t p = 0; p < in.n_prims; ++p) {
         float c[3];
         centroid_of(in.prim_box[p], c);

@@ -216,8 +216,21 @@ inline bool build_device(hipStream_t stream, const Input &in, Output &out, std::
     if (n == 0) {
         return true;
     }
-    for (uint32_t p = 0; p < n; ++p) {
-        grow(out.bounds, in.prim_box[p]);
+    {
+        std::vector<Box> part(rayhip_host::host_threads() + 1, empty_box());
+        const size_t per = (size_t(n) + part.size() - 1) / part.size();
+        rayhip_host::parallel_blocks(part.size(), 1, [&](const size_t b, const size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                for (size_t p = k * per; p < std::min<size_t>(n, (k + 1) * per); ++p) {
+                    grow(part[k], in.prim_box[p]);
+                }
+            }
+        });
+        for (const Box &b : part) { // (min / max: the order of the parts does not matter)
+            if (b.lo[0] <= b.hi[0]) {
+                grow(out.bounds, b);
+            }
+        }
     }
     const std::vector<Box> cbox = centroid_boxes(in);
     DeviceBuilder B;

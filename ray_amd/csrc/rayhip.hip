@@ -21,6 +21,7 @@
 #include "kernels.hip.h" // first: it configures the profiling macros the rt_*.h headers expand
 #include "shade_launch.h"
 #include "bvh4_build.h"
+#include "bvh4_build.hip.h"
 #include "bvh8_build.h"
 #include "bvh_layout.h"
 #include "unet.h"
@@ -774,11 +775,16 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         return 1;                                                                                                      \
     }
     // HBM layout pass (bvh_layout.h): depth-first node order with sibling pairs in one 128-byte line, triangles in
-    // leaf-visit order.  RAYHIP_NO_LAYOUT=1 keeps the reference builder's order (A/B measurements).
+    // leaf-visit order.  Off by default since round 3 (RAYHIP_LAYOUT=1 switches it on): the kernels walk the 4-wide collapse,
+    // whose node order is the collapse's own, and the triangle records come out of the leaf refinement grouped leaf by leaf
+    // in the order of a depth-first walk already -- measured, Bistro-class scene: K2 2.11 ms per iteration with the pass,
+    // 2.13 without, Sponza-class 1.70 / 1.70 (profiles/r03/experiments/variants_layout_*.txt) -- for 181 ms of host time
+    // per upload.  Without leaf refinement (RAYHIP_REFINE_LEAVES=0) the pass still runs: the reference builder's order is poor.
     rayhip_layout::Result lay;
     {
-        const char *e = getenv("RAYHIP_NO_LAYOUT");
-        if (!(e && e[0] == '1')) {
+        const char *e = getenv("RAYHIP_LAYOUT"), *off = getenv("RAYHIP_NO_LAYOUT");
+        const bool want_layout = e ? e[0] == '1' : !rebuilt.ok;
+        if (want_layout && !(off && off[0] == '1')) {
             lay = rayhip_layout::optimize(*d);
         }
     }
@@ -848,13 +854,37 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             }
             wide = 8, blas_root4 = b8.blas_root8, wide_bytes = b8.nodes.size() * sizeof(Bvh8Node);
         } else if (want == 4 || want == 8) {
-            rayhip_bvh4::Result b4 = rayhip_bvh4::build(n2, n2_count, mis, d->mesh_instances_count, tlas_root);
-            if (b4.ok && !b4.nodes.empty()) {
-                if (upload(c, c->nodes4, b4.nodes.data(), b4.nodes.size() * sizeof(Bvh4Node)) ||
-                    upload(c, c->blas_root4, b4.blas_root4.data(), b4.blas_root4.size() * sizeof(uint32_t))) {
-                    return 1;
+            // the collapse runs on the device over the nodes just uploaded (bvh4_build.hip.h); RAYHIP_BVH_BUILD_ON_HOST=1: the host
+            // driver over the same element functions (A/B: the same tree in another node order)
+            const bool on_host = getenv("RAYHIP_BVH_BUILD_ON_HOST") != nullptr && atoi(getenv("RAYHIP_BVH_BUILD_ON_HOST")) != 0;
+            if (on_host) {
+                rayhip_bvh4::Result b4 = rayhip_bvh4::build(n2, n2_count, mis, d->mesh_instances_count, tlas_root);
+                if (b4.ok && !b4.nodes.empty()) {
+                    if (upload(c, c->nodes4, b4.nodes.data(), b4.nodes.size() * sizeof(Bvh4Node)) ||
+                        upload(c, c->blas_root4, b4.blas_root4.data(), b4.blas_root4.size() * sizeof(uint32_t))) {
+                        return 1;
+                    }
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    wide = 4, blas_root4 = b4.blas_root4, wide_bytes = b4.nodes.size() * sizeof(Bvh4Node);
                 }
-                wide = 4, blas_root4 = b4.blas_root4, wide_bytes = b4.nodes.size() * sizeof(Bvh4Node);
+            } else {
+                std::vector<uint32_t> roots;
+                uint32_t n_wide = 0;
+                std::string why;
+                if (rayhip_bvh4::collect_roots(n2, n2_count, mis, d->mesh_instances_count, tlas_root, roots, blas_root4) && !roots.empty()) {
+                    if (c->nodes4.alloc(size_t(n2_count) * sizeof(Bvh4Node))) {
+                        return 1;
+                    }
+                    if (!rayhip_bvh4::build_device(c->stream, c->nodes.as<rayhip_bvh2_node>(), n2_count, roots, c->nodes4.as<Bvh4Node>(), n_wide, why)) {
+                        return fail("4-wide collapse failed: %s", why.c_str());
+                    }
+                    if (upload(c, c->blas_root4, blas_root4.data(), blas_root4.size() * sizeof(uint32_t))) {
+                        return 1;
+                    }
+                    wide = 4, wide_bytes = size_t(n_wide) * sizeof(Bvh4Node);
+                } else {
+                    blas_root4.clear();
+                }
             }
             UPLOAD_TRACE(wide == 4 ? "bvh4 built" : "no wide BLAS")
         }

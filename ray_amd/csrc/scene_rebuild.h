@@ -13,6 +13,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "host_parallel.h"
 #include "lbvh.h"
 
 namespace rayhip_rebuild {
@@ -438,14 +439,17 @@ template <class Build> inline Rebuilt refine_with(const rayhip_scene_desc &d, co
         }
     }
     g.n_groups = uint32_t(sites.size());
-    for (uint32_t grp = 0; grp < g.n_groups; ++grp) {
+    // the unique triangles of every leaf (padding repeats triangles inside a leaf): counted, then written, both passes shared
+    // out over the host cores (3.9 M entries of the Bistro-class scene: the boxes alone are 9 M vertex gathers)
+    std::vector<uint32_t> first_prim(size_t(g.n_groups) + 1, 0);
+    std::vector<uint8_t> bad(g.n_groups, 0);
+    auto unique_entries = [&](const uint32_t grp, uint32_t uniq[8]) -> uint32_t {
         const uint32_t w = sites[grp].side ? d.nodes[sites[grp].node].right_child : d.nodes[sites[grp].node].left_child;
         const uint32_t first = w & INDEX_BITS, count = ((w & COUNT_BITS) >> 29) + 1;
         if (first + count > d.tris_count) {
-            out.why = "leaf range outside the triangle array";
-            return out;
+            return 0xffffffffu;
         }
-        uint32_t uniq[8], n_uniq = 0; // (padding repeats triangles inside a leaf)
+        uint32_t n_uniq = 0;
         for (uint32_t e = first; e < first + count; ++e) {
             bool dup = false;
             for (uint32_t k = 0; k < n_uniq; ++k) {
@@ -455,16 +459,43 @@ template <class Build> inline Rebuilt refine_with(const rayhip_scene_desc &d, co
                 uniq[n_uniq++] = e;
             }
         }
-        for (uint32_t k = 0; k < n_uniq; ++k) {
-            if (d.tri_indices[uniq[k]] >= d.vtx_indices_count / 3) {
-                out.why = "leaf entry outside the triangle arrays";
-                return out;
+        return n_uniq;
+    };
+    rayhip_host::parallel_blocks(g.n_groups, 4096, [&](const size_t b, const size_t e) {
+        for (size_t grp = b; grp < e; ++grp) {
+            uint32_t uniq[8];
+            const uint32_t n_uniq = unique_entries(uint32_t(grp), uniq);
+            if (n_uniq == 0xffffffffu) {
+                bad[grp] = 1;
+                continue;
             }
-            g.prim_box.push_back(triangle_box(d, d.tri_indices[uniq[k]]));
-            g.prim_group.push_back(grp);
-            g.prim_entry.push_back(uniq[k]);
+            for (uint32_t k = 0; k < n_uniq; ++k) {
+                bad[grp] |= d.tri_indices[uniq[k]] >= d.vtx_indices_count / 3 ? 2 : 0;
+            }
+            first_prim[grp + 1] = n_uniq;
         }
+    });
+    for (uint32_t grp = 0; grp < g.n_groups; ++grp) {
+        if (bad[grp]) {
+            out.why = (bad[grp] & 1) ? "leaf range outside the triangle array" : "leaf entry outside the triangle arrays";
+            return out;
+        }
+        first_prim[grp + 1] += first_prim[grp];
     }
+    const size_t n_prims_total = first_prim[g.n_groups];
+    g.prim_box.resize(n_prims_total), g.prim_group.resize(n_prims_total), g.prim_entry.resize(n_prims_total);
+    rayhip_host::parallel_blocks(g.n_groups, 4096, [&](const size_t b, const size_t e) {
+        for (size_t grp = b; grp < e; ++grp) {
+            uint32_t uniq[8];
+            const uint32_t n_uniq = unique_entries(uint32_t(grp), uniq);
+            for (uint32_t k = 0; k < n_uniq; ++k) {
+                const size_t at = size_t(first_prim[grp]) + k;
+                g.prim_box[at] = triangle_box(d, d.tri_indices[uniq[k]]);
+                g.prim_group[at] = uint32_t(grp);
+                g.prim_entry[at] = uniq[k];
+            }
+        }
+    });
     rayhip_lbvh::Input bi;
     bi.prim_box = g.prim_box.data(), bi.prim_group = g.prim_group.data(), bi.group_centroids = nullptr;
     bi.n_prims = uint32_t(g.prim_box.size()), bi.n_groups = g.n_groups, bi.leaf_max = leaf_max, bi.leaf_is_primitive = false,
@@ -474,16 +505,22 @@ template <class Build> inline Rebuilt refine_with(const rayhip_scene_desc &d, co
         return out;
     }
     // splice: the old nodes keep their indices, the subtrees follow them
-    out.nodes.assign(d.nodes, d.nodes + d.nodes_count);
     const uint32_t base = d.nodes_count;
-    for (rayhip_bvh2_node n : sub.nodes) {
-        for (uint32_t *link : {&n.left_child, &n.right_child}) {
-            if ((*link & COUNT_BITS) == 0) {
-                *link += base;
+    out.nodes.resize(size_t(d.nodes_count) + sub.nodes.size());
+    rayhip_host::parallel_blocks(d.nodes_count, 1 << 16, [&](const size_t b, const size_t e) {
+        memcpy(static_cast<void *>(out.nodes.data() + b), static_cast<const void *>(d.nodes + b), (e - b) * sizeof(rayhip_bvh2_node));
+    });
+    rayhip_host::parallel_blocks(sub.nodes.size(), 1 << 16, [&](const size_t b, const size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            rayhip_bvh2_node n = sub.nodes[i];
+            for (uint32_t *link : {&n.left_child, &n.right_child}) {
+                if ((*link & COUNT_BITS) == 0) {
+                    *link += base;
+                }
             }
+            out.nodes[size_t(base) + i] = n;
         }
-        out.nodes.push_back(n);
-    }
+    });
     for (uint32_t grp = 0; grp < g.n_groups; ++grp) {
         uint32_t link = sub.group_root[grp];
         if (link == NONE) {
@@ -496,10 +533,12 @@ template <class Build> inline Rebuilt refine_with(const rayhip_scene_desc &d, co
         (sites[grp].side ? out.nodes[sites[grp].node].right_child : out.nodes[sites[grp].node].left_child) = link;
     }
     out.tris.resize(sub.entries.size()), out.tri_indices.resize(sub.entries.size());
-    for (size_t k = 0; k < sub.entries.size(); ++k) {
-        const uint32_t e = g.prim_entry[sub.entries[k]];
-        out.tris[k] = d.tris[e], out.tri_indices[k] = d.tri_indices[e];
-    }
+    rayhip_host::parallel_blocks(sub.entries.size(), 1 << 16, [&](const size_t b, const size_t e2) {
+        for (size_t k = b; k < e2; ++k) {
+            const uint32_t e = g.prim_entry[sub.entries[k]];
+            out.tris[k] = d.tris[e], out.tri_indices[k] = d.tri_indices[e];
+        }
+    });
     out.mesh_instances.assign(d.mesh_instances, d.mesh_instances + d.mesh_instances_count);
     out.tlas_root = d.tlas_root;
     out.blas_nodes = uint32_t(sub.nodes.size()), out.unique_tris = uint32_t(g.prim_entry.size());

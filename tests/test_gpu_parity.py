@@ -100,22 +100,24 @@ def test_shadow_rays_on_reference_rays(gpu_lib, name):
 @pytest.mark.parametrize("name", SCENES)
 def test_traversal_work_counters_match_host(gpu_lib, hostsim_lib, name, monkeypatch):
     """the visit counts that feed the algorithmic-bytes formula are the same on device and in the host build"""
-    monkeypatch.setenv("HOSTSIM_REFINE", "2")  # the trees librayhip walks: leaves refined to <= 2 triangles (scene_rebuild.h)
-    monkeypatch.setenv("HOSTSIM_BVH8", "1")    # ... and the triangle order of its 8-wide collapse (bvh8_build.h)
+    monkeypatch.setenv("HOSTSIM_REFINE", "2")     # the trees librayhip walks: leaves refined to <= 2 triangles (scene_rebuild.h),
+    monkeypatch.setenv("HOSTSIM_NO_LAYOUT", "1")  # in the order the refinement leaves them (no layout pass since round 3),
+    monkeypatch.setenv("HOSTSIM_BVH4", "1")       # collapsed four wide (on the device there: bvh4_build.hip.h, here the host driver)
     g = util.golden_ref(name)
     gpu = util.make_context(gpu_lib, name)
     host = util.make_context(hostsim_lib, name)
     _, hg, tc_g = gpu.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1)
     _, hh, tc_h = host.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1)
     assert tc_g == tc_h
-    assert np.array_equal(hg["prim_index"], hh["prim_index"])  # same layout pass on both sides: equal even for misses
-    # the product walk (8-wide) with counters: its node visits and triangle tests, device against the host build
+    assert np.array_equal(hg["prim_index"], hh["prim_index"])  # same triangle order on both sides: equal even for misses
+    # the product walk (4-wide, its tree built by the device driver of the collapse) with counters: node visits and triangle
+    # tests, device against the host build (the host driver of the collapse: the same tree in another node order)
     _, hgw, tw_g = gpu.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=hip.FLAG_COUNT_WIDE)
     _, hhw, tw_h = host.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=hip.FLAG_COUNT_WIDE)
     assert tw_g == tw_h and tw_g["nodes4"] > 0
     assert hgw.tobytes() == hg.tobytes()
     # the shadow-ray hook walks the reference's BVH2 on the device; so does the host build when no wide form is selected
-    monkeypatch.setenv("HOSTSIM_BVH8", "0")
+    monkeypatch.setenv("HOSTSIM_BVH4", "0")
     host2 = util.make_context(hostsim_lib, name)
     _, sc_g = gpu.k_intersect_shadow(g["shadow_rays"], 1)
     _, sc_h = host2.k_intersect_shadow(g["shadow_rays"], 1)
