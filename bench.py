@@ -24,8 +24,8 @@ ranks on one device -- and the line says `"emulated_ranks": true`: a plumbing ch
 Timed region: barrier + stream sync | K iterations (+ the reduce at N>1) | stream sync + barrier; max over ranks.
 Inputs (scene, PMJ table) are resident in HBM before the region starts; nothing is copied to the host inside it.
 
-roofline (dominant kernel: the closest-hit traversal K2 -- k_trace_closest_refill for the secondary bounces,
-k_trace_closest<false,true> for the primary rays; "a launch" is a launch of either).  Its launches are bracketed by HIP
+roofline (dominant kernel: the closest-hit traversal K2 -- the persistent kernel k_trace_closest_refill, lane-by-lane refill
+for the secondary bounces, whole chunks for the primary rays; "a launch" is a launch of either).  Its launches are bracketed by HIP
 events on the context stream during the timed region (RAYHIP_FLAG_TIME_STAGES, no synchronisation).  Three byte counts,
 all per launch:
   traffic      HBM bytes that actually moved: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE of this kernel, from a profiled run of
@@ -36,8 +36,8 @@ all per launch:
                profile was taken; null when the workload was never profiled
   achieved     = traffic / launch time when traffic is known (the north star's figure: "achieved HBM GB/s from rocprof
                against the chip's memory roofline"), else the kernel's own algorithmic rate; frac = achieved / 8 TB/s
-  algorithmic  the kernel's OWN algorithmic bytes: 72+20+4 per ray + 64 per TLAS node + 80 per 8-wide node (64 per 4-wide
-               node with RAYHIP_BVH_WIDTH=4) + 48 per triangle + 144 per instance, counted by the instrumented product kernel (RAYHIP_FLAG_COUNT_WIDE) on iterations
+  algorithmic  the kernel's OWN algorithmic bytes: 72+20+4 per ray + 64 per TLAS node + 64 per 4-wide node (80 per 8-wide
+               node with RAYHIP_BVH_WIDTH=8) + 48 per triangle + 144 per instance, counted by the instrumented product kernel (RAYHIP_FLAG_COUNT_WIDE) on iterations
                of the same workload right after the timed region; next to it the same for the reference's BVH2 walk
                (SURVEY 8d's formula, RAYHIP_FLAG_COUNT_TRAVERSAL) -- what a cache-less machine would have to move
 cpu_baseline: the reference's own AVX2 backend (oracle/_ref, kind "reference"), one persistent pool of worker threads (as
@@ -465,7 +465,7 @@ def main():
                        "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 gather of the owned tiles per frame over RCCL)",
                        "iterations_per_pass": batch},
             "roofline": {
-                "bound": "hbm", "kernel": f"K2 closest-hit traversal over the {bvh_width}-wide BLAS: k_trace_closest_refill<{bvh_width}> (secondary bounces) + k_trace_closest<false,{bvh_width}> (primary rays)",
+                "bound": "hbm", "kernel": f"K2 closest-hit traversal over the {bvh_width}-wide BLAS: k_trace_closest_refill<{bvh_width}, 40> (secondary bounces, lanes refilled one by one) + <{bvh_width}, 64> (primary rays, whole chunks)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "achieved_is": (("HBM traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE of a profiled run of this command) / launch time"
                                  if traffic.get("exact") else

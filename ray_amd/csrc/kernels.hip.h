@@ -371,6 +371,19 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 // secondary bounces; WAVE for coherent primary rays -- the wavefront then finishes its 64 rays together and takes the next
 // chunk whole, i.e. the schedule of the plain kernel, with this kernel's flat register footprint (96 VGPRs, no spill stores
 // inside the walk, where the plain kernel's nested walks spill 60 VGPRs at 80: 7.8 GB of scratch writes per primary launch)
+// RT_REFILL_POSTPONE (4-wide walk): a lane that reaches a leaf does not wait for the wavefront's next leaf step -- it puts the leaf
+// aside (`pend`, one deep) and goes on with its next node, so the node steps -- 83 % of this kernel's vector instructions, issued
+// for 55 % of the lanes when leaves are tested in place -- keep the lanes that would otherwise stand at a leaf.  A lane waits only
+// when it meets a second leaf (or the end of its walk) with one still aside.  The leaves of a ray are tested in the order the
+// walk meets them, as before; what changes is that up to one leaf's result is missing when the next nodes are culled, i.e. a
+// SUPERSET of nodes is visited with a distance limit that is never smaller than the in-place walk's: same triangles accepted
+// in the same order, same hit bits.
+// MEASURED (profiles/r03/experiments/variants_postpone.txt, 20-layer passes): lanes busy in a node step 55.4 -> 58.5 %, in a
+// triangle test 36 -> 49 % -- but 6 % more lane-level node visits (the stale limit), the same number of wave-level node steps, and
+// K2 2.23 instead of 2.15 ms per iteration.  Off; kept as the record of the experiment.
+#ifndef RT_REFILL_POSTPONE
+#define RT_REFILL_POSTPONE 0
+#endif
 template <int WIDE, int MIN_WAIT = RT_REFILL_MIN>
 __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_refill(const SceneView sc, const TraceParams tp, const RaySoA rays,
                                                                const HitSoA hits, const RayQueue queue, const int init_hits,
@@ -392,13 +405,15 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
 
     enum : uint32_t { IDLE = 0, TLAS = 1, BLAS = 2 };
 #ifdef RT_PROFILE_TRACE
-    uint32_t st_a = 0, st_b = 0, st_iter = 0; // (uniform)
+    uint32_t st_a = 0, st_b = 0, st_iter = 0, st_serv = 0, st_serv_lanes = 0, st_tlas = 0; // (uniform)
 #endif
     // lane state.  4-wide: `cur` / `tos` are node words at both levels.  8-wide (rt_bvh8.h): inside an instance `cur` / `tos` are the
     // child_base of the current / topmost group and `cur_bits` / `tos_bits` their pending masks, (`tri_base`, `l0`, `l1`) the hit leaf
     // children of the node visited last; at the top level they are BVH2 node words as before.
     uint32_t lvl = IDLE, slot = 0, cur = BVH4_SENTINEL, tos = BVH4_SENTINEL, size = 0, mi_index = 0, ray_flags = 0;
     uint32_t cur_bits = 0, tos_bits = 0, tri_base = 0, l0 = 0, l1 = 0, oct_inv = 0;
+    constexpr bool POSTPONE = (WIDE == 4) && (RT_REFILL_POSTPONE != 0);
+    uint32_t pend = 0; // POSTPONE: the leaf word put aside (a leaf word is never 0: its count bits are set)
     bool res = false;
     f3 ro = {0.0f, 0.0f, 0.0f}, rd = {0.0f, 0.0f, 1.0f}; // world-space origin of the current transparency segment, direction
     f3 o = ro, d = rd, inv_d = rd;                        // object-space ray of the instance being walked
@@ -429,8 +444,15 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                 cur = st.read_at(--size); // the top-level `tos` saved at the entry of the instance
                 tos = st.read_at(--size);
             }
-        } else if (lvl == BLAS && cur == BVH4_SENTINEL) {
+        } else if (lvl == BLAS && cur == BVH4_SENTINEL && (!POSTPONE || pend == 0u)) {
             lvl = TLAS;
+            pop();
+        }
+    };
+    // POSTPONE: a leaf that became current is put aside when there is room, and the walk goes on with what the stack holds
+    auto stash = [&]() {
+        if (POSTPONE && lvl == BLAS && pend == 0u && (cur & BVH2_PRIM_COUNT_BITS) != 0) {
+            pend = cur;
             pop();
         }
     };
@@ -446,11 +468,21 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
         // as RT_REFILL_MIN lanes wait outside for the service part below
         for (;;) {
             const bool in_blas = (lvl == BLAS);
-            // (the sentinel never stays in `cur`: leave_blas)
-            const bool at_leaf = in_blas && (WIDE == 8 ? (l0 | l1) != 0u : (cur & BVH2_PRIM_COUNT_BITS) != 0);
-            const bool at_node = in_blas && !at_leaf;
-            const int n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf));
-            const int n_out = WAVE - n_node - n_leaf - int(n_dead);
+            // (the sentinel never stays in `cur`: leave_blas -- except, POSTPONE, under a leaf that is still aside)
+            bool at_leaf, at_node;
+            int n_node, n_leaf, n_out;
+            if (POSTPONE) {
+                at_node = in_blas && (cur & BVH2_PRIM_COUNT_BITS) == 0 && cur != BVH4_SENTINEL;
+                at_leaf = in_blas && pend != 0u;                           // takes part in a leaf step
+                const bool blocked = at_leaf && !at_node;                  // ... and cannot do anything else
+                n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(blocked));
+                n_out = WAVE - __popcll(__ballot(in_blas)) - int(n_dead);
+            } else {
+                at_leaf = in_blas && (WIDE == 8 ? (l0 | l1) != 0u : (cur & BVH2_PRIM_COUNT_BITS) != 0);
+                at_node = in_blas && !at_leaf;
+                n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf));
+                n_out = WAVE - n_node - n_leaf - int(n_dead);
+            }
 #ifdef RT_PROFILE_TRACE
             st_a += n_node, st_b += n_leaf, st_iter += 1;
 #endif
@@ -474,19 +506,23 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                         }
                     } else {
                         bvh4_visit(sc.nodes4, o, inv_d, h.t, st, cur, tos, size);
+                        stash();
                     }
                     leave_blas();
                 }
                 RT_PROF_T(19)
             } else {
                 if (at_leaf) {
-                    const uint32_t word = WIDE == 8 ? bvh8_take_leaf(tri_base, l0, l1) : cur;
+                    const uint32_t word = WIDE == 8 ? bvh8_take_leaf(tri_base, l0, l1) : (POSTPONE ? pend : cur);
                     const int tri_start = int(word & BVH2_PRIM_INDEX_BITS), tri_end = int(tri_start + ((word & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
-                    res |= intersect_tris_closest(o, d, sc.tris, tri_start, tri_end, int(mi_index), h);
+                    res |= intersect_tris_closest(o, d, tri_table(sc), tri_start, tri_end, int(mi_index), h);
                     if (WIDE == 8) {
                         if ((l0 | l1) == 0u && (cur_bits >> 8) == 0u) {
                             pop8();
                         }
+                    } else if (POSTPONE) {
+                        pend = 0u;
+                        stash(); // (a lane that stood at its next leaf puts that one aside now)
                     } else {
                         pop();
                     }
@@ -497,6 +533,9 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
         }
 
         // ---- service part, D: finish rays whose TLAS walk is over, hand idle lanes their next rays
+#ifdef RT_PROFILE_TRACE
+        st_serv += 1, st_serv_lanes += uint32_t(__popcll(__ballot(lvl != BLAS))) - n_dead;
+#endif
         {
             const bool in_fin = (lvl == TLAS) && (cur == BVH4_SENTINEL);
             if (in_fin) {
@@ -507,7 +546,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                     h.prim_index = int(sc.tri_indices[h.prim_index]);
                 }
                 bool again = false;
-                if (res) { // tail of the IntersectScene round: what does the hit mean
+                if (res && !hit_side_is_solid(sc, h)) { // tail of the IntersectScene round (rare: the hit is not on a solid surface): what does it mean
                     const float4 cc = rays.c_cs[slot];
                     const uint2 xd = rays.xy_depth[slot];
                     Ray r;
@@ -590,6 +629,9 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
             if (__builtin_amdgcn_readfirstlane(int(__ballot(in_c) == 0ull))) {
                 break;
             }
+#ifdef RT_PROFILE_TRACE
+            st_tlas += 1;
+#endif
             if (in_c) {
                 if ((cur & BVH2_PRIM_COUNT_BITS) == 0) { // TLAS node (reference BVH2): near child first, far child pushed
                     const f3 inv = safe_invert(rd);
@@ -632,6 +674,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                             cur = sc.blas_root4[mi];
                         }
                         lvl = BLAS;
+                        stash();      // (a BLAS whose root is a leaf)
                         leave_blas(); // (a BLAS whose root is the sentinel: nothing to walk)
                     } else {
                         pop();
@@ -649,6 +692,8 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
     if (lane == 0) {
         atomicAdd(&g_prof_acc[6], (unsigned long long)st_a), atomicAdd(&g_prof_acc[7], (unsigned long long)st_b);
         atomicAdd(&g_prof_acc[8], (unsigned long long)st_iter);
+        atomicAdd(&g_prof_acc[9], (unsigned long long)st_serv), atomicAdd(&g_prof_acc[10], (unsigned long long)st_serv_lanes);
+        atomicAdd(&g_prof_acc[11], (unsigned long long)st_tlas);
     }
 #endif
 }
@@ -863,6 +908,15 @@ __global__ void __launch_bounds__(256) k_pack_owned(const float4 *__restrict__ s
         dst[i] = pixel_owned(shard, w, i % w, i / w) ? src[i] : mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
+// triangle records re-pitched from 48 to 64 bytes (rt_isect.h: TriTable): thread = one 16-byte row of the padded table
+__global__ void __launch_bounds__(256) k_pad_tris(const float4 *__restrict__ src, float4 *__restrict__ dst, const size_t n_tris) {
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n_tris * 4) {
+        const size_t t = i >> 2, r = i & 3;
+        dst[i] = r < 3 ? src[t * 3 + r] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+}
+
 __global__ void __launch_bounds__(256) k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, const size_t n) {
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         dst[i] = src[i];

@@ -94,6 +94,10 @@ struct DevBuf {
         p = nullptr;
         bytes = 0;
     }
+    void swap(DevBuf &o) {
+        std::swap(p, o.p);
+        std::swap(bytes, o.bytes);
+    }
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 } // namespace
@@ -101,6 +105,7 @@ struct DevBuf {
 struct rayhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    uint32_t tri_pitch = 3; // 16-byte rows per record of `tris` as uploaded (SceneView::tri_pitch)
     hipDeviceProp_t props = {};
     int grid_waves = 0; // resident-ish grid for the wave-per-block kernels
     bool small_scene = false; // BLAS nodes + triangles fit one XCD's L2: traversal kernels with the smaller register footprint
@@ -647,7 +652,7 @@ static int upload_lights(rayhip_ctx *c, const rayhip_scene_desc *d) {
 // the kernels' view of what is on the device (SceneView), after a full upload or an instance update
 static void refresh_scene_view(rayhip_ctx *c, const rayhip_scene_desc *d, const uint32_t tlas_root, const rayhip_lbvh::Box &root_box) {
     SceneView &v = c->sc;
-    v.nodes = c->nodes.as<rayhip_bvh2_node>(), v.tris = c->tris.as<rayhip_tri_accel>();
+    v.nodes = c->nodes.as<rayhip_bvh2_node>(), v.tris = c->tris.as<rayhip_tri_accel>(), v.tri_pitch = c->tri_pitch;
     v.tri_indices = c->tri_indices.as<uint32_t>(), v.tri_materials = c->tri_materials.as<rayhip_tri_mat_data>();
     v.materials = c->materials.as<rayhip_material>(), v.vertices = c->vertices.as<rayhip_vertex>();
     v.vtx_indices = c->vtx_indices.as<uint32_t>(), v.mesh_instances = c->mesh_instances.as<rayhip_mesh_instance>();
@@ -845,6 +850,20 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             upload(c, c->tri_indices, tri_indices_in, n_tris * sizeof(uint32_t)) ||
             upload(c, c->mesh_instances, mis, size_t(d->mesh_instances_count) * sizeof(rayhip_mesh_instance))) {
             return 1;
+        }
+        // the walks' triangle table: every 48-byte record in its own 64-byte sector (RAYHIP_TRI_PITCH=48 keeps the reference's array)
+        c->tri_pitch = 3;
+        if (n_tris && !(getenv("RAYHIP_TRI_PITCH") && atoi(getenv("RAYHIP_TRI_PITCH")) == 48)) {
+            DevBuf padded;
+            if (padded.alloc(n_tris * 64)) {
+                return 1;
+            }
+            k_pad_tris<<<unsigned((n_tris * 4 + 255) / 256), 256, 0, c->stream>>>(c->tris.as<float4>(), padded.as<float4>(), n_tris);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->tris.swap(padded);
+            padded.release();
+            c->tri_pitch = 4;
         }
         size_t wide_bytes = 0;
         if (b8.ok && !b8.nodes.empty()) {

@@ -35,6 +35,15 @@
 
 namespace rt {
 
+// RT_BVH4_TEST_FOLDED: the slab test with the error bound folded into the plane padding (1) or with a relative slack per child (0, rounds 1-2)
+#ifndef RT_BVH4_TEST_FOLDED
+#define RT_BVH4_TEST_FOLDED 1
+#endif
+
+#ifndef RT_BVH4_PINNED_FETCH
+#define RT_BVH4_PINNED_FETCH 1
+#endif
+
 struct alignas(16) Bvh4Node {
     float org[3];
     uint32_t exps; // byte 0,1,2 = biased exponent of the x,y,z grid step
@@ -75,9 +84,32 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
     RT_PROF_T(16)
     RT_PROF_LANES(0)
     const float4 *np = reinterpret_cast<const float4 *>(nodes4 + cur);
+#if defined(__HIP_DEVICE_COMPILE__) && RT_BVH4_PINNED_FETCH
+    // the four loads of a node issued back to back, one wait.  Left to the scheduler, the folded test below came out as
+    // "load, load, load, WAIT for the first, compare, load the fourth, wait": two memory round trips per visit and K2 9 % slower
+    // with 10 % fewer instructions (round 3; the fourth load's destination overlapped the address registers, so it went last,
+    // and a compare on the first load's result was placed in front of it)
+    float4 w0, w1, w2, w3;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\tglobal_load_dwordx4 %2, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+                 : "v"(np)
+                 : "memory");
+#else
     const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+#endif
     RT_PROF_WAIT(w0, w1, w2, w3)
     RT_PROF_T(17)
+#if defined(RT_EXPERIMENT_DUMMY_VALU) && defined(__HIP_DEVICE_COMPILE__)
+    // tuning experiment: RT_EXPERIMENT_DUMMY_VALU extra full-rate vector instructions per node visit -- does the kernel's time follow
+    // its instruction count (bound by vector-ALU issue) or not (bound by latency)?
+    float dummy_ = t;
+#pragma unroll
+    for (int k_ = 0; k_ < RT_EXPERIMENT_DUMMY_VALU; ++k_) {
+        asm volatile("v_mul_f32 %0, %0, %0" : "+v"(dummy_));
+    }
+    asm volatile("" ::"v"(dummy_));
+#endif
     const uint32_t exps = float_as_uint(w0.w);
     const uint32_t child[4] = {float_as_uint(w1.x), float_as_uint(w1.y), float_as_uint(w1.z), float_as_uint(w1.w)};
 
@@ -90,7 +122,11 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
     for (int a = 0; a < 3; ++a) {
         k[a] = bvh4_scale(exps, a) * id[a];
         const float base = (org[a] - o[a]) * id[a];
+#if RT_BVH4_TEST_FOLDED
+        const float err = __builtin_fmaf(255.0f, fabsf(k[a]), fabsf(base)) * 9.5367431640625e-07f; // 2^-20: covers both sides' roundings (rt_bvh8.h)
+#else
         const float err = __builtin_fmaf(255.0f, fabsf(k[a]), fabsf(base)) * 2.384185791015625e-07f; // 2^-22
+#endif
         base_in[a] = base - err, base_out[a] = base + err;
         const bool forward = id[a] >= 0.0f;
         q_in[a] = forward ? qlo_w[a] : qhi_w[a], q_out[a] = forward ? qhi_w[a] : qlo_w[a];
@@ -106,9 +142,18 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
             t_in[a] = __builtin_fmaf(float((q_in[a] >> sh) & 0xffu), k[a], base_in[a]);
             t_out[a] = __builtin_fmaf(float((q_out[a] >> sh) & 0xffu), k[a], base_out[a]);
         }
+#if RT_BVH4_TEST_FOLDED
+        // the whole error budget sits in the padding of the planes (2^-20 M_a per plane, derivation in rt_bvh8.h: the same grid, the
+        // same arithmetic): no relative slack afterwards, and  max(tmin, 0) <= min(tmax, t)  -- implied by the reference's
+        // tmin <= tmax && tmin <= t && tmax > 0 -- is two 3-operand min / max and one compare instead of two fma and three compares
+        const float tmin = fmaxf(fmaxf(fmaxf(t_in[0], t_in[1]), t_in[2]), 0.0f), tmax = fminf(fminf(fminf(t_out[0], t_out[1]), t_out[2]), t);
+        const bool hit = tmin <= tmax && child[c] != BVH4_EMPTY;
+        (void)slack;
+#else
         const float tmin = fmaxf(fmaxf(t_in[0], t_in[1]), t_in[2]), tmax = fminf(fminf(t_out[0], t_out[1]), t_out[2]);
         const float tmin_c = __builtin_fmaf(-fabsf(tmin), slack, tmin), tmax_c = __builtin_fmaf(fabsf(tmax), slack, tmax);
         const bool hit = tmin_c <= tmax_c && tmin_c <= t && tmax_c > 0.0f && child[c] != BVH4_EMPTY;
+#endif
         dist[c] = hit ? tmin : none;
         ref[c] = child[c];
         n_hit += hit ? 1u : 0u;

@@ -26,12 +26,19 @@ struct ArrayStack {
 
 #define RT_SIGN_OF(f) (((f) >= 0) ? 1 : -1)
 
-// One triangle fetched as three 16-byte loads issued together (a single memory round trip per triangle).
+// One triangle fetched as three 16-byte loads issued together (a single memory round trip per triangle).  The table is the
+// reference's 48-byte tri_accel_t array, or -- on the device -- the same records padded to a pitch of 64 bytes, so that
+// a record never straddles two 64-byte sectors (half of the 48-byte records do; the walks are bound by the number of
+// sectors they miss on).
 struct TriData {
     float4 n, u, v;
 };
-RT_HD TriData load_tri(const rayhip_tri_accel *tris, const uint32_t i) {
-    const float4 *p = reinterpret_cast<const float4 *>(tris + i);
+struct TriTable {
+    const float4 *rows;
+    uint32_t pitch; // rows per record: 3 or 4
+};
+RT_HD TriData load_tri(const TriTable tris, const uint32_t i) {
+    const float4 *p = tris.rows + size_t(i) * tris.pitch;
     TriData t;
     t.n = p[0], t.u = p[1], t.v = p[2];
     return t;

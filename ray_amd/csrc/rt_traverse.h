@@ -99,8 +99,10 @@ RT_HD bool walk_bvh2(const rayhip_bvh2_node *nodes, const uint32_t root_index, c
     return false;
 }
 
+RT_HD TriTable tri_table(const SceneView &sc) { return TriTable{reinterpret_cast<const float4 *>(sc.tris), sc.tri_pitch}; }
+
 // CoreRef.cpp:1798-1817
-RT_HD bool intersect_tris_closest(const f3 ro, const f3 rd, const rayhip_tri_accel *tris, const int tri_start,
+RT_HD bool intersect_tris_closest(const f3 ro, const f3 rd, const TriTable tris, const int tri_start,
                                   const int tri_end, const int obj_index, Hit &out_inter) {
     Hit inter;
     inter.obj_index = obj_index;
@@ -130,7 +132,7 @@ RT_HD bool intersect_tris_closest(const f3 ro, const f3 rd, const rayhip_tri_acc
 }
 
 // CoreRef.cpp:1840-1863
-RT_HD bool intersect_tris_any(const f3 ro, const f3 rd, const rayhip_tri_accel *tris,
+RT_HD bool intersect_tris_any(const f3 ro, const f3 rd, const TriTable tris,
                               const rayhip_tri_mat_data *materials, const uint32_t *indices, const int tri_start,
                               const int tri_end, const int obj_index, Hit &out_inter) {
     Hit inter;
@@ -187,7 +189,7 @@ RT_HD bool traverse_closest(const SceneView &sc, const f3 ro, const f3 rd, const
                 if (cnt) {
                     cnt->tris += uint32_t(tri_end - tri_start);
                 }
-                res |= intersect_tris_closest(_ro, _rd, sc.tris, tri_start, tri_end, int(mi_index), inter);
+                res |= intersect_tris_closest(_ro, _rd, tri_table(sc), tri_start, tri_end, int(mi_index), inter);
                 return false;
             };
             if (WIDE == 8) {
@@ -233,7 +235,7 @@ RT_HD bool traverse_any(const SceneView &sc, const f3 ro, const f3 rd, const int
                 if (cnt) {
                     cnt->tris += uint32_t(tri_end - tri_start);
                 }
-                const bool hit_found = intersect_tris_any(_ro, _rd, sc.tris, sc.tri_materials, sc.tri_indices,
+                const bool hit_found = intersect_tris_any(_ro, _rd, tri_table(sc), sc.tri_materials, sc.tri_indices,
                                                           tri_start, tri_end, int(mi_index), inter);
                 if (hit_found) {
                     const bool is_backfacing = inter.prim_index < 0;

@@ -174,7 +174,7 @@ def run1(name, workload="sponza", K=16):
                      19: "K2 node: push/pop (LDS)", 20: "K2 leaf: before tri fetch", 21: "K2 leaf: wait for first tri",
                      22: "K2 leaf: tri tests (+prefetch waits)", 23: "K2 TLAS: instance transform", 24: "K2 chunk fetch",
                      25: "K2 ray load", 26: "K2 scene walk residue", 27: "K2 store + exit"}
-            if buf[11] + buf[12] + buf[13] + buf[14]:
+            if buf[9]:
                 names.update({24: "refill: phase selection", 19: "refill: phase A (node visits)", 26: "refill: phase B (leaves)", 23: "refill: phase C (TLAS)", 25: "refill: phase D (finish + refill)"})
             if buf[1] and "PROFILE_TRACE" in " ".join(VARIANTS[name]):
                 print(f"  lane utilisation: node visits {buf[0] / buf[1] / 64:.3f} ({buf[1]} wave-level visits), "
@@ -182,7 +182,9 @@ def run1(name, workload="sponza", K=16):
                 if buf[8]:
                     print(f"  majority loop: {buf[8]} iterations; lanes at a node {buf[6] / buf[8] / 64:.3f}, at a leaf {buf[7] / buf[8] / 64:.3f}, "
                           f"done or idle {1 - (buf[6] + buf[7]) / buf[8] / 64:.3f}")
-                if buf[11] + buf[12] + buf[13] + buf[14]:
+                if buf[9]:
+                    print(f"  refill kernel: {buf[9]} service rounds, {buf[10] / buf[9]:.1f} lanes served per round, {buf[11] / buf[9]:.2f} top-level steps per round")
+                if buf[12] + buf[13] + buf[14]:
                     print(f"  refill kernel: lanes at TLAS work {buf[9] / buf[8] / 64:.3f}, finishing or idle {buf[10] / buf[8] / 64:.3f}; "
                           f"phases A {buf[11]} B {buf[12]} C {buf[13]} D {buf[14]}")
                 for k in range(16):
