@@ -365,7 +365,8 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 #define RT_REFILL_MIN 40
 #endif
 #ifndef RT_REFILL_MIN_WAVES
-#define RT_REFILL_MIN_WAVES 5 // 96 VGPRs, no scratch (6 waves: 80 VGPRs with spills in the loop, slower)
+#define RT_REFILL_MIN_WAVES 6 // 80 VGPRs, 40 bytes of scratch.  Round 2: 5 (96 VGPRs; 6 spilled in the loop and lost).  With round 3's shorter node
+                              // test 6 wins: K2 1.92 against 2.02 ms per iteration; 7 (72 VGPRs, 76 bytes of scratch) 2.26
 #endif
 // MIN_WAIT: lanes that must be waiting before the wavefront leaves the BLAS loop to serve them.  RT_REFILL_MIN for the incoherent
 // secondary bounces; WAVE for coherent primary rays -- the wavefront then finishes its 64 rays together and takes the next
@@ -381,6 +382,9 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 // MEASURED (profiles/r03/experiments/variants_postpone.txt, 20-layer passes): lanes busy in a node step 55.4 -> 58.5 %, in a
 // triangle test 36 -> 49 % -- but 6 % more lane-level node visits (the stale limit), the same number of wave-level node steps, and
 // K2 2.23 instead of 2.15 ms per iteration.  Off; kept as the record of the experiment.
+#ifndef RT_REFILL_PREFETCH
+#define RT_REFILL_PREFETCH 0 // measured: K2 2.46 instead of 1.92 ms (profiles/r03/experiments/variants_prefetch.txt) -- the LDS-destination load is no cheap hint
+#endif
 #ifndef RT_REFILL_POSTPONE
 #define RT_REFILL_POSTPONE 0
 #endif
@@ -412,6 +416,29 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
     // children of the node visited last; at the top level they are BVH2 node words as before.
     uint32_t lvl = IDLE, slot = 0, cur = BVH4_SENTINEL, tos = BVH4_SENTINEL, size = 0, mi_index = 0, ray_flags = 0;
     uint32_t cur_bits = 0, tos_bits = 0, tri_base = 0, l0 = 0, l1 = 0, oct_inv = 0;
+    // RT_REFILL_PREFETCH (4-wide walk): the moment a lane knows its next node or leaf, one dword of it is requested into a 256-byte
+    // LDS sink nobody reads (global_load_lds: no destination register to keep alive) -- the line is on its way to L2 / L1 while the
+    // wavefront does its stack bookkeeping, votes, and waits its turn among the SIMD's other wavefronts: with six of them sharing
+    // the issue slots those ~80 instructions are ~0.7 us of wall clock, most of a miss's latency.
+    constexpr bool PREFETCH = (WIDE == 4) && (RT_REFILL_PREFETCH != 0);
+    __shared__ uint32_t pf_sink[PREFETCH ? WAVE : 1];
+    // (the sink's LDS offset for M0: the low half of its generic address; uniform)
+    const uint32_t pf_lds = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(reinterpret_cast<uintptr_t>(&pf_sink[0])))));
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_PREFETCH_CUR()                                                                                               \
+    if (PREFETCH && lvl == BLAS && cur != BVH4_SENTINEL) {                                                              \
+        const bool node_ = (cur & BVH2_PRIM_COUNT_BITS) == 0;                                                           \
+        const size_t off_ = node_ ? size_t(cur) * sizeof(Bvh4Node) : size_t(cur & BVH2_PRIM_INDEX_BITS) * size_t(sc.tri_pitch * 16u); \
+        const char *base_ = node_ ? reinterpret_cast<const char *>(sc.nodes4) : reinterpret_cast<const char *>(sc.tris); \
+        uint32_t m0_;                                                                                                   \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"           \
+                     : "=&s"(m0_)                                                                                       \
+                     : "v"(base_ + off_), "s"(pf_lds)                                                                   \
+                     : "memory");                                                                                       \
+    }
+#else
+#define RT_PREFETCH_CUR()
+#endif
     constexpr bool POSTPONE = (WIDE == 4) && (RT_REFILL_POSTPONE != 0);
     uint32_t pend = 0; // POSTPONE: the leaf word put aside (a leaf word is never 0: its count bits are set)
     bool res = false;
@@ -506,6 +533,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                         }
                     } else {
                         bvh4_visit(sc.nodes4, o, inv_d, h.t, st, cur, tos, size);
+                        RT_PREFETCH_CUR()
                         stash();
                     }
                     leave_blas();
@@ -525,6 +553,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                         stash(); // (a lane that stood at its next leaf puts that one aside now)
                     } else {
                         pop();
+                        RT_PREFETCH_CUR()
                     }
                     leave_blas();
                 }

@@ -851,9 +851,11 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             upload(c, c->mesh_instances, mis, size_t(d->mesh_instances_count) * sizeof(rayhip_mesh_instance))) {
             return 1;
         }
-        // the walks' triangle table: every 48-byte record in its own 64-byte sector (RAYHIP_TRI_PITCH=48 keeps the reference's array)
+        // the walks' triangle table: the reference's 48-byte array as it is; RAYHIP_TRI_PITCH=64 re-pitches it so that every record lies in
+        // its own 64-byte sector (half of the 48-byte records straddle two) -- measured neutral (K2 2.14 against 2.12 ms,
+        // profiles/r03/experiments/variants_tripitch.txt: the kernel is bound by instruction issue, not by sectors), so it stays an option
         c->tri_pitch = 3;
-        if (n_tris && !(getenv("RAYHIP_TRI_PITCH") && atoi(getenv("RAYHIP_TRI_PITCH")) == 48)) {
+        if (n_tris && getenv("RAYHIP_TRI_PITCH") && atoi(getenv("RAYHIP_TRI_PITCH")) == 64) {
             DevBuf padded;
             if (padded.alloc(n_tris * 64)) {
                 return 1;

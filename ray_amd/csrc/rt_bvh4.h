@@ -43,6 +43,9 @@ namespace rt {
 #ifndef RT_BVH4_PINNED_FETCH
 #define RT_BVH4_PINNED_FETCH 1
 #endif
+#ifndef RT_BVH4_SGPR_CSWAP
+#define RT_BVH4_SGPR_CSWAP 0 // (measured neutral in the kernel: K2 1.94 against 1.92 ms; the microbenchmark's penalty does not show up in context)
+#endif
 
 struct alignas(16) Bvh4Node {
     float org[3];
@@ -159,6 +162,24 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
         n_hit += hit ? 1u : 0u;
     }
     // sorting network on (dist, ref), ascending: (0,1) (2,3) (0,2) (1,3) (1,2); children that were not hit sort last
+#if defined(__HIP_DEVICE_COMPILE__) && RT_BVH4_SGPR_CSWAP
+    // The compare-and-swap with its lane mask in an SGPR pair.  Left to the compiler it becomes v_cmp (vcc), s_nop, 4 x v_cndmask_b32_e32
+    // reading vcc -- and on gfx950 a VOP2 v_cndmask that does not IMMEDIATELY follow the write of vcc occupies the SIMD for ~24 cycles
+    // instead of 4 (tools/valu_bench.hip: "cswap: vcc + nop + 4 cnd" 14-16 cycles per instruction against 3.6-3.9 with the mask in
+    // an SGPR pair): ~75 against ~19 cycles per compare-and-swap, five of them per node visit.  (s_nop 1: two wait states between a
+    // VALU write of an SGPR and a VALU read of it.)
+#define RT_CSWAP(a, b)                                                                                                  \
+    {                                                                                                                   \
+        float da_, db_;                                                                                                 \
+        uint32_t ra_, rb_;                                                                                              \
+        unsigned long long m_;                                                                                          \
+        asm("v_cmp_lt_f32_e64 %4, %6, %5\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %5, %6, %4\n\tv_cndmask_b32_e64 %1, %6, %5, %4\n\t"                    \
+            "v_cndmask_b32_e64 %2, %7, %8, %4\n\tv_cndmask_b32_e64 %3, %8, %7, %4"                                       \
+            : "=&v"(da_), "=&v"(db_), "=&v"(ra_), "=&v"(rb_), "=&s"(m_)                                                 \
+            : "v"(dist[a]), "v"(dist[b]), "v"(ref[a]), "v"(ref[b]));                                                   \
+        dist[a] = da_, dist[b] = db_, ref[a] = ra_, ref[b] = rb_;                                                       \
+    }
+#else
 #define RT_CSWAP(a, b)                                                                                                  \
     {                                                                                                                   \
         const bool sw = dist[b] < dist[a];                                                                              \
@@ -166,6 +187,7 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
         const uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];                                            \
         dist[a] = da, dist[b] = db, ref[a] = ra, ref[b] = rb;                                                           \
     }
+#endif
     RT_CSWAP(0, 1)
     RT_CSWAP(2, 3)
     RT_CSWAP(0, 2)

@@ -102,7 +102,16 @@ RT_HD void bvh8_test_node(const Bvh8Node *nodes8, const uint32_t node, const f3 
     RT_PROF_T(16)
     RT_PROF_LANES(0)
     const float4 *np = reinterpret_cast<const float4 *>(nodes8 + node);
+#if defined(__HIP_DEVICE_COMPILE__) && RT_BVH4_PINNED_FETCH
+    float4 w0, w1, w2, w3, w4; // (the five loads back to back, one wait: rt_bvh4.h)
+    asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %5, off offset:16\n\tglobal_load_dwordx4 %2, %5, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:48\n\tglobal_load_dwordx4 %4, %5, off offset:64\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4)
+                 : "v"(np)
+                 : "memory");
+#else
     const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3], w4 = np[4];
+#endif
     RT_PROF_WAIT(w0, w1, w2, w4)
     RT_PROF_T(17)
     const uint32_t exps = float_as_uint(w0.w);

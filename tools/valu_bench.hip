@@ -75,6 +75,10 @@
 #define I_CMP_CNDMASK_S(n) "v_cmp_lt_f32 s[20:21], %" #n ", %8\n v_cndmask_b32 %" #n ", %" #n ", %9, s[20:21]\n"
 // one compare feeding four selects (a compare-and-swap of the sorting network)
 #define I_CMP_4CND(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+// compare-and-swap of (key, payload) pairs, three ways: as compiled (one vcc, four selects), the mask in an SGPR pair, min / max for the keys
+#define I_CSWAP_VCC(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n s_nop 1\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define I_CSWAP_SGPR(n) "v_cmp_lt_f32_e64 s[20:21], %" #n ", %8\n s_nop 1\n v_cndmask_b32_e64 %" #n ", %" #n ", %9, s[20:21]\n v_cndmask_b32_e64 %" #n ", %" #n ", %8, s[20:21]\n v_cndmask_b32_e64 %" #n ", %" #n ", %9, s[20:21]\n v_cndmask_b32_e64 %" #n ", %" #n ", %8, s[20:21]\n"
+#define I_CSWAP_MINMAX(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n v_min_f32 %" #n ", %" #n ", %9\n v_max_f32 %" #n ", %" #n ", %8\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
 #define I_MAX_MIN(n) "v_max_f32 %" #n ", %" #n ", %8\n v_min_f32 %" #n ", %" #n ", %9\n"
 #define I_LSHL_ADD_U64(n) "v_lshl_add_u64 %" #n ", %" #n ", 4, %8\n"
 // the traversal's plane evaluation as the compiler emits it: byte -> float, then fma
@@ -83,15 +87,15 @@
 enum Op {
     FMA, FMAC, MUL, ADD, MAX, MAX3, MED3, CMP, CMP_S, CNDMASK, CNDMASK_S, CVT_UB, CVT_U32, AND, LSHR, BFE, AND_OR, LSHL_OR, PERM, MOV, ADD_U32, MUL_LO, MAD_U24,
     RCP, SQRT, BCNT, DPP, PK_FMA, PK_MUL, PK_ADD, CVT_FMA, MIN, SUB, XOR, OR, MAX_I32, MIN_U32, ADD3, LSHL_ADD, CMP_U32, ADD_CO, ADDC_CO,
-    CNDMASK_E64_VCC, CMP_CNDMASK, CMP_CNDMASK_S, CMP_4CND, MAX_MIN, LSHL_ADD_U64, N_OPS
+    CNDMASK_E64_VCC, CMP_CNDMASK, CMP_CNDMASK_S, CMP_4CND, MAX_MIN, LSHL_ADD_U64, CSWAP_VCC, CSWAP_SGPR, CSWAP_MINMAX, N_OPS
 };
 static const char *OP_NAME[N_OPS] = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_max_f32", "v_max3_f32", "v_med3_f32", "v_cmp_lt_f32 vcc", "v_cmp_lt_f32 sgpr",
                                      "v_cndmask_b32 vcc", "v_cndmask_b32 sgpr", "v_cvt_f32_ubyte1", "v_cvt_f32_u32", "v_and_b32", "v_lshrrev_b32", "v_bfe_u32",
                                      "v_and_or_b32", "v_lshl_or_b32", "v_perm_b32", "v_mov_b32", "v_add_u32", "v_mul_lo_u32", "v_mad_u32_u24", "v_rcp_f32",
                                      "v_sqrt_f32", "v_bcnt_u32_b32", "v_mov_b32 dpp", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "cvt_ubyte + fma (pair)", "v_min_f32", "v_sub_f32", "v_xor_b32", "v_or_b32", "v_max_i32", "v_min_u32",
                                      "v_add3_u32", "v_lshl_add_u32", "v_cmp_lt_u32 vcc", "v_add_co_u32", "v_addc_co_u32", "v_cndmask_b32_e64 vcc", "cmp vcc + cndmask (pair)",
-                                     "cmp sgpr + cndmask (pair)", "cmp vcc + 4 cndmask (5)", "max + min (pair)", "v_lshl_add_u64"};
-static const int OP_INSTRS[N_OPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 5, 2, 1};
+                                     "cmp sgpr + cndmask (pair)", "cmp vcc + 4 cndmask (5)", "max + min (pair)", "v_lshl_add_u64", "cswap: vcc + nop + 4 cnd (5)", "cswap: sgpr + nop + 4 cnd(5)", "cswap: cmp min max 2 cnd (5)"};
+static const int OP_INSTRS[N_OPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 5, 2, 1, 5, 5, 5};
 
 template <int OP> __global__ __launch_bounds__(64) void k_valu(float *out, const int iters, long long *cycles, const float fb, const float fc) {
     float a0 = threadIdx.x * 0.001f + 1.0f, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f, a4 = a0 + 4.0f, a5 = a0 + 5.0f, a6 = a0 + 6.0f, a7 = a0 + 7.0f;
@@ -150,6 +154,9 @@ template <int OP> __global__ __launch_bounds__(64) void k_valu(float *out, const
         if constexpr (OP == CMP_4CND) { RUN(I_CMP_4CND) }
         if constexpr (OP == MAX_MIN) { RUN(I_MAX_MIN) }
         if constexpr (OP == LSHL_ADD_U64) { RUN64(I_LSHL_ADD_U64) }
+        if constexpr (OP == CSWAP_VCC) { RUN(I_CSWAP_VCC) }
+        if constexpr (OP == CSWAP_SGPR) { RUN(I_CSWAP_SGPR) }
+        if constexpr (OP == CSWAP_MINMAX) { RUN(I_CSWAP_MINMAX) }
     }
     const long long t1 = clock64();
     out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + float(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
