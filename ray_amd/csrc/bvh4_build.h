@@ -54,7 +54,6 @@ RT_HD bool quantise(const Slot *slots, const int n_slots, rt::Bvh4Node &out) {
         }
     }
     out = rt::Bvh4Node{};
-    uint32_t exps = 0;
     float scale[3];
     for (int a = 0; a < 3; ++a) {
         out.org[a] = lo[a];
@@ -76,9 +75,8 @@ RT_HD bool quantise(const Slot *slots, const int n_slots, rt::Bvh4Node &out) {
             return false;
         }
         scale[a] = rt::uint_as_float(uint32_t(e) << 23);
-        exps |= uint32_t(e) << (8 * a);
     }
-    out.exps = exps;
+    out.step_x = scale[0], out.step_y = scale[1], out.step_z = scale[2];
     for (int c = 0; c < 4; ++c) {
         out.child[c] = rt::BVH4_EMPTY;
     }

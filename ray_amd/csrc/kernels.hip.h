@@ -513,10 +513,11 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
 #ifdef RT_PROFILE_TRACE
             st_a += n_node, st_b += n_leaf, st_iter += 1;
 #endif
-            if (__builtin_amdgcn_readfirstlane(int(n_node + n_leaf == 0 || n_out >= MIN_WAIT))) {
+            // (the counts come from ballots: uniform, the branches are scalar)
+            if (n_node + n_leaf == 0 || n_out >= MIN_WAIT) {
                 break;
             }
-            if (__builtin_amdgcn_readfirstlane(int(n_node >= n_leaf))) {
+            if (n_node >= n_leaf) {
                 if (at_node) {
                     if (WIDE == 8) {
                         const uint32_t node = bvh8_take_child(cur, cur_bits, oct_inv);

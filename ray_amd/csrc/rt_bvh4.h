@@ -25,10 +25,11 @@
 //
 // Node, 64 bytes, 16-byte aligned, fetched as 4 x global_load_dwordx4:
 //   [0]  org.xyz                float  grid origin = node box min
-//        scale exponents        3 x u8 biased exponent E of the per-axis grid step 2^(E-127), 1 pad byte
+//        step.x                 float  grid step of the x axis, a power of two (steps as floats since round 3: the kernel is bound by
+//                                      instruction issue, and three exponent bytes cost a shift and a mask each to unpack)
 //   [1]  child[4]               inner: bvh4 node index | leaf: (count-1)<<29 | first entry in tris[] (reference leaf word)
 //   [2]  qlo[x][4] qlo[y][4] qlo[z][4] qhi[x][4]     u8, [axis][child]
-//   [3]  qhi[y][4] qhi[z][4] pad pad                 (empty slot: child = BVH4_EMPTY)
+//   [3]  qhi[y][4] qhi[z][4] step.y step.z            (empty slot: child = BVH4_EMPTY)
 #pragma once
 
 #include "rt_isect.h"
@@ -49,19 +50,17 @@ namespace rt {
 
 struct alignas(16) Bvh4Node {
     float org[3];
-    uint32_t exps; // byte 0,1,2 = biased exponent of the x,y,z grid step
+    float step_x; // grid steps: powers of two
     uint32_t child[4];
     uint32_t qlo[3]; // byte c of qlo[a] = child c, axis a
     uint32_t qhi[3];
-    uint32_t _pad[2];
+    float step_y, step_z;
 };
 static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node must be one 64-byte fetch unit");
 
 constexpr uint32_t BVH4_SENTINEL = 0x1fffffffu; // same stack sentinel as the BVH2 walk (never a node index)
 constexpr uint32_t BVH4_EMPTY = 0xffffffffu;    // unused child slot
 
-// grid step of one axis from its biased exponent byte
-RT_HD float bvh4_scale(const uint32_t exps, const int axis) { return uint_as_float(((exps >> (8 * axis)) & 0xffu) << 23); }
 // one de-quantised box coordinate: a single fused multiply-add, the same operation on host (builder check) and device
 RT_HD float bvh4_dequant(const uint32_t q, const float scale, const float org) { return __builtin_fmaf(float(q), scale, org); }
 
@@ -113,7 +112,7 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
     }
     asm volatile("" ::"v"(dummy_));
 #endif
-    const uint32_t exps = float_as_uint(w0.w);
+    const float step[3] = {w0.w, w3.z, w3.w};
     const uint32_t child[4] = {float_as_uint(w1.x), float_as_uint(w1.y), float_as_uint(w1.z), float_as_uint(w1.w)};
 
     // the grid in ray-parameter space, per axis: t(q) = q * k + base, padded by the error bound on the side that matters
@@ -123,7 +122,7 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
     float k[3], base_in[3], base_out[3];
     uint32_t q_in[3], q_out[3]; // the four children's entry / exit plane indices of this axis, one byte each
     for (int a = 0; a < 3; ++a) {
-        k[a] = bvh4_scale(exps, a) * id[a];
+        k[a] = step[a] * id[a];
         const float base = (org[a] - o[a]) * id[a];
 #if RT_BVH4_TEST_FOLDED
         const float err = __builtin_fmaf(255.0f, fabsf(k[a]), fabsf(base)) * 9.5367431640625e-07f; // 2^-20: covers both sides' roundings (rt_bvh8.h)

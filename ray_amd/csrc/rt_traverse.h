@@ -110,16 +110,22 @@ RT_HD bool intersect_tris_closest(const f3 ro, const f3 rd, const TriTable tris,
     inter.t = out_inter.t;
     inter.u = 0.0f;
     inter.v = -1.0f;
-    // the next triangle's 48 bytes are requested before the current one is tested (one round trip in flight ahead)
+    // a leaf word carries count - 1 in bits that are non-zero for a leaf (rt_base.h), i.e. a leaf has at least TWO records (the
+    // reference's builder and lbvh.h duplicate a lone triangle): both are requested at once and tested back to back -- one round
+    // trip, and none of the register shuffling of a rotating "next triangle" (26 v_mov per triangle in round 2's loop); the
+    // refined trees have nothing but such leaves.  Longer leaves go on one record at a time.
     RT_PROF_T(20)
-    TriData cur_tri = load_tri(tris, uint32_t(tri_start));
-    RT_PROF_WAIT(cur_tri.n, cur_tri.u, cur_tri.v, cur_tri.v)
+    const TriData tri0 = load_tri(tris, uint32_t(tri_start)), tri1 = load_tri(tris, uint32_t(tri_start + 1));
+    RT_PROF_WAIT(tri0.n, tri0.u, tri1.n, tri1.v)
     RT_PROF_T(21)
-    for (int i = tri_start; i < tri_end; ++i) {
+    RT_PROF_LANES(2)
+    intersect_tri(ro, rd, tri0, uint32_t(tri_start), inter);
+    RT_PROF_LANES(2)
+    intersect_tri(ro, rd, tri1, uint32_t(tri_start + 1), inter);
+    for (int i = tri_start + 2; i < tri_end; ++i) {
         RT_PROF_LANES(2)
-        const TriData next_tri = (i + 1 < tri_end) ? load_tri(tris, uint32_t(i + 1)) : cur_tri;
-        intersect_tri(ro, rd, cur_tri, uint32_t(i), inter);
-        cur_tri = next_tri;
+        const TriData tri = load_tri(tris, uint32_t(i));
+        intersect_tri(ro, rd, tri, uint32_t(i), inter);
     }
     RT_PROF_T(22)
     const bool hit = inter.v >= 0.0f;
@@ -141,14 +147,23 @@ RT_HD bool intersect_tris_any(const f3 ro, const f3 rd, const TriTable tris,
     inter.t = out_inter.t;
     inter.u = 0.0f;
     inter.v = -1.0f;
-    TriData cur_tri = load_tri(tris, uint32_t(tri_start));
-    for (int i = tri_start; i < tri_end; ++i) {
-        const TriData next_tri = (i + 1 < tri_end) ? load_tri(tris, uint32_t(i + 1)) : cur_tri;
-        intersect_tri(ro, rd, cur_tri, uint32_t(i), inter);
-        cur_tri = next_tri;
-        if (inter.v >= 0.0f && ((inter.prim_index > 0 && (materials[indices[i]].front_mi & MATERIAL_SOLID_BIT)) ||
-                                (inter.prim_index < 0 && (materials[indices[i]].back_mi & MATERIAL_SOLID_BIT)))) {
-            break;
+    // (the reference's loop, CoreRef.cpp:1846-1856, with the first two records -- a leaf has at least two, see above -- requested together)
+    const auto solid_hit = [&](const int i) {
+        return inter.v >= 0.0f && ((inter.prim_index > 0 && (materials[indices[i]].front_mi & MATERIAL_SOLID_BIT)) ||
+                                   (inter.prim_index < 0 && (materials[indices[i]].back_mi & MATERIAL_SOLID_BIT)));
+    };
+    const TriData tri0 = load_tri(tris, uint32_t(tri_start)), tri1 = load_tri(tris, uint32_t(tri_start + 1));
+    intersect_tri(ro, rd, tri0, uint32_t(tri_start), inter);
+    if (!solid_hit(tri_start)) {
+        intersect_tri(ro, rd, tri1, uint32_t(tri_start + 1), inter);
+        if (!solid_hit(tri_start + 1)) {
+            for (int i = tri_start + 2; i < tri_end; ++i) {
+                const TriData tri = load_tri(tris, uint32_t(i));
+                intersect_tri(ro, rd, tri, uint32_t(i), inter);
+                if (solid_hit(i)) {
+                    break;
+                }
+            }
         }
     }
     const bool hit = inter.v >= 0.0f;
