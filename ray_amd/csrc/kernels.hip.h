@@ -382,6 +382,11 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 // MEASURED (profiles/r03/experiments/variants_postpone.txt, 20-layer passes): lanes busy in a node step 55.4 -> 58.5 %, in a
 // triangle test 36 -> 49 % -- but 6 % more lane-level node visits (the stale limit), the same number of wave-level node steps, and
 // K2 2.23 instead of 2.15 ms per iteration.  Off; kept as the record of the experiment.
+// the vote between a node step and a leaf step: a node step while  n_node * DEN >= n_leaf * NUM  (1 / 1: plain majority)
+#ifndef RT_REFILL_VOTE_NUM
+#define RT_REFILL_VOTE_NUM 1
+#define RT_REFILL_VOTE_DEN 1
+#endif
 #ifndef RT_REFILL_PREFETCH
 #define RT_REFILL_PREFETCH 0 // measured: K2 2.46 instead of 1.92 ms (profiles/r03/experiments/variants_prefetch.txt) -- the LDS-destination load is no cheap hint
 #endif
@@ -517,7 +522,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
             if (n_node + n_leaf == 0 || n_out >= MIN_WAIT) {
                 break;
             }
-            if (n_node >= n_leaf) {
+            if (n_node * RT_REFILL_VOTE_DEN >= n_leaf * RT_REFILL_VOTE_NUM) {
                 if (at_node) {
                     if (WIDE == 8) {
                         const uint32_t node = bvh8_take_child(cur, cur_bits, oct_inv);

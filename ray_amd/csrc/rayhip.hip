@@ -159,16 +159,16 @@ struct rayhip_ctx {
     PixelBuffers px = {};
 
     // wavefront state, sized w*h
-    DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3], deferred_planes[2], point_planes[7];
+    DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3], deferred_planes[2], point_planes[7], nee_index;
     PointSoA points = {};
     // how the shade stage is cut into launches (kernels.hip.h): bit 0 = the light pick as its own kernel, bit 1 = next-event
     // estimation and continuation as two scatter launches.  RAYHIP_SHADE_SPLIT overrides (A/B measurements).
-    int shade_split = 1;
+    int shade_split = 5; // shade_launch.h: bit 0 pick as its own kernel, bit 1 NEE / continuation as two launches, bit 2 NEE over the compacted queue of points that got a light
     RaySoA rays[2] = {};
     HitSoA hits = {};
     ShadowSoA shadow = {};
     DeferredSoA deferred = {};
-    DevBuf counters;      // uint32 [MAX_BOUNCE_SLOTS][4: rays, shadow rays, deferred emitters, shade points][QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE]
+    DevBuf counters;      // uint32 [MAX_BOUNCE_SLOTS][5: rays, shadow rays, deferred emitters, shade points, points with a light][QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE]
     DevBuf trav_counters; // u64 [2][TRAV_COUNTER_WORDS]
     DevBuf stack_spill;   // per-wave overflow slabs of the traversal stack
     DevBuf sort_keys[2], sort_idx[2], sort_temp;
@@ -189,10 +189,12 @@ struct rayhip_ctx {
     double stage_us[11] = {};
 
     static constexpr size_t QUEUE_WORDS = size_t(QUEUE_MAX_STRIPES) * QUEUE_COUNTER_STRIDE;
-    uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + size_t(4 * b) * QUEUE_WORDS; }
-    uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + size_t(4 * b + 1) * QUEUE_WORDS; }
-    uint32_t *deferred_count(int b) const { return counters.as<uint32_t>() + size_t(4 * b + 2) * QUEUE_WORDS; }
-    uint32_t *point_count(int b) const { return counters.as<uint32_t>() + size_t(4 * b + 3) * QUEUE_WORDS; }
+    static constexpr int QUEUES_PER_BOUNCE = 5;
+    uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b) * QUEUE_WORDS; }
+    uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 1) * QUEUE_WORDS; }
+    uint32_t *deferred_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 2) * QUEUE_WORDS; }
+    uint32_t *point_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 3) * QUEUE_WORDS; }
+    uint32_t *nee_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 4) * QUEUE_WORDS; }
     // queue geometry for a frame of `items` pixels split over `stripes` stripes
     static RayQueue make_queue(uint32_t *counts, size_t items, uint32_t stripes) {
         const size_t chunks = (items + WAVE - 1) / WAVE;
@@ -202,8 +204,9 @@ struct rayhip_ctx {
     RayQueue shadow_queue(int b, size_t items, uint32_t stripes) const { return make_queue(shadow_count(b), items, stripes); }
     RayQueue deferred_queue(int b, size_t items, uint32_t stripes) const { return make_queue(deferred_count(b), items, stripes); }
     RayQueue point_queue(int b, size_t items, uint32_t stripes) const { return make_queue(point_count(b), items, stripes); }
+    RayQueue nee_queue(int b, size_t items, uint32_t stripes) const { return make_queue(nee_count(b), items, stripes); }
     int clear_queues(int bounces, hipStream_t s) const {
-        return hipMemsetAsync(counters.p, 0, size_t(4 * bounces) * QUEUE_WORDS * sizeof(uint32_t), s) == hipSuccess ? 0 : 1;
+        return hipMemsetAsync(counters.p, 0, size_t(QUEUES_PER_BOUNCE * bounces) * QUEUE_WORDS * sizeof(uint32_t), s) == hipSuccess ? 0 : 1;
     }
 };
 
@@ -314,6 +317,10 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
     c->points.b_gy = c->point_planes[2].as<float4>(), c->points.base_gz = c->point_planes[3].as<float4>();
     c->points.scalars = c->point_planes[4].as<float4>(), c->points.misc = c->point_planes[5].as<float4>();
     c->points.light = c->point_planes[6].as<float4>();
+    if (c->nee_index.alloc(n * 4)) {
+        return 1;
+    }
+    c->points.nee_index = c->nee_index.as<uint32_t>();
     // the ray sort only runs on single-iteration passes
     const size_t n_sort = tile_slots(w, h) + size_t(WAVE) * QUEUE_MAX_STRIPES;
     size_t temp_bytes = 0;
@@ -457,7 +464,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         c->sort_key_mode = std::max(0, std::min(3, atoi(e)));
     }
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
-        c->shade_split = atoi(e) & 3;
+        c->shade_split = atoi(e) & 7;
     }
     // The persistent ray-refill form of the closest-hit kernel (kernels.hip.h): lanes whose ray is finished fetch the next one
     // instead of idling until the longest walk of their wavefront ends.  RAYHIP_REFILL: 2 = for the secondary
@@ -490,7 +497,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         delete c;
         return 1;
     }
-    if (c->counters.alloc(sizeof(uint32_t) * 4 * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS)) {
+    if (c->counters.alloc(sizeof(uint32_t) * rayhip_ctx::QUEUES_PER_BOUNCE * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS)) {
         delete c;
         return 1;
     }
@@ -535,6 +542,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
     for (DevBuf &b : c->point_planes) {
         b.release();
     }
+    c->nee_index.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1172,7 +1180,7 @@ static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration,
     a.hits = c->hits, a.shadow = c->shadow, a.deferred = c->deferred, a.points = c->points;
     a.in = c->ray_queue(bounce, nslots, stripes), a.pts = c->point_queue(bounce, nslots, stripes);
     a.out_rays = c->ray_queue(bounce + 1, nslots, stripes), a.out_shadow = c->shadow_queue(bounce, nslots, stripes);
-    a.out_deferred = c->deferred_queue(bounce, nslots, stripes);
+    a.out_deferred = c->deferred_queue(bounce, nslots, stripes), a.nee = c->nee_queue(bounce, nslots, stripes);
     a.px = c->px, a.layers = layers, a.vw = vw, a.mix_factor = mix_factor;
     a.bounce = bounce, a.grid = gtrace, a.split = c->shade_split, a.stream = c->stream;
     shade::launch(a);

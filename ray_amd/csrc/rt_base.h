@@ -20,6 +20,11 @@
 #ifndef RT_PROF
 #define RT_PROF(k)
 #endif
+// RT_PROF_SHADE_LANES(k): lane census of the shade-kernel profile build (shade_kernels.hip, -DRT_PROFILE_SHADE): active lanes into
+// slot k, wave-level executions into slot k + 1
+#ifndef RT_PROF_SHADE_LANES
+#define RT_PROF_SHADE_LANES(k)
+#endif
 // same for the traversal-kernel profile build (-DRT_PROFILE_TRACE); RT_PROF_WAIT forces the loads just issued to land
 // before the next marker so that "waiting for memory" becomes its own section
 #ifndef RT_PROF_T

@@ -16,6 +16,21 @@
 
 #include <algorithm>
 
+#ifdef RT_PROFILE_SHADE
+// tuning build (tools/variants.py "+shade:-DRT_PROFILE_SHADE"): which branches of the scatter stage run, and with how many lanes
+namespace rt {
+__device__ unsigned long long g_prof_shade[64];
+}
+#define RT_PROF_SHADE_LANES(k)                                                                                          \
+    {                                                                                                                   \
+        const unsigned long long m_ = __ballot(1);                                                                      \
+        if (int(__lane_id()) == __ffsll((long long)m_) - 1) {                                                           \
+            atomicAdd(&::rt::g_prof_shade[k], (unsigned long long)__popcll(m_));                                        \
+            atomicAdd(&::rt::g_prof_shade[(k) + 1], 1ull);                                                              \
+        }                                                                                                               \
+    }
+#endif
+
 #include "shade_launch.h"
 
 namespace rt {
@@ -146,30 +161,65 @@ __global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const Sc
     }
 }
 
+// COMPACT: the points whose descent ended at a light (inv_prob != 0: the only ones the next-event estimation has work for -- 18 % of
+// the points of the Bistro-class scene) are listed densely in the `nee` queue of their stripe, for k_scatter<true, false, true>
+template <bool COMPACT>
 __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
-                                                                       const PointSoA points, const RayQueue queue, const Layering layers) {
+                                                                       const PointSoA points, const RayQueue queue, const RayQueue nee,
+                                                                       const Layering layers) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_live_chunks = queue.live_chunks();
     ChunkWalk walk(n_live_chunks);
     for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
-        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
+        if (!queue.chunk(c, stripe, slot0, n_live)) {
             continue;
         }
         const uint32_t i = slot0 + lane;
-        const float4 ps = points.p_slot[i];
-        const uint2 xd = rays_in.xy_depth[float_as_uint(ps.w)];
-        const uint32_t layer = xy_layer(xd.x, layers);
-        const ShadeParams spl = layer_params(sp, layer);
-        store_pick(points, i, pick_light(sc, f3{ps.x, ps.y, ps.z}, light_pick_random(sc, spl, xy_real(xd.x, layers, layer), xd.y)));
+        bool usable = false;
+        if (lane < n_live) {
+            const float4 ps = points.p_slot[i];
+            const uint2 xd = rays_in.xy_depth[float_as_uint(ps.w)];
+            const uint32_t layer = xy_layer(xd.x, layers);
+            const ShadeParams spl = layer_params(sp, layer);
+            const LightPick pk = pick_light(sc, f3{ps.x, ps.y, ps.z}, light_pick_random(sc, spl, xy_real(xd.x, layers, layer), xd.y));
+            store_pick(points, i, pk);
+            usable = pk.inv_prob != 0.0f;
+        }
+        if (COMPACT) {
+            const uint32_t slot = nee.alloc(stripe, usable);
+            if (usable) {
+                points.nee_index[slot] = i;
+            }
+        }
     }
 }
 
-template <bool NEE, bool CONTINUE>
+// Which form of stage 3 runs is decided on the device, from the two fill counts k_light_pick left behind, by every wavefront of
+// the three candidate launches in the same way (wavefront-collective: all 64 lanes active): the split form when fewer than half
+// of the points have a light to sample -- otherwise the work both launches repeat (frame, lobe set-up, loads) costs more than
+// the idle lanes (03_principled, every point lit: 2.70 against 2.47 ms).  The launches of the form that lost return at once.
+__device__ __forceinline__ uint32_t queue_fill(const RayQueue &q) {
+    const uint32_t lane = __lane_id();
+    uint32_t n = lane < q.stripes ? q.counts[lane * QUEUE_COUNTER_STRIDE] : 0u;
+    for (int m = 32; m >= 1; m >>= 1) {
+        n += uint32_t(__shfl_xor(int(n), m));
+    }
+    return uint32_t(__builtin_amdgcn_readfirstlane(int(n)));
+}
+__device__ __forceinline__ bool lit_points_are_sparse(const RayQueue &pts, const RayQueue &nee) { return 2u * queue_fill(nee) < queue_fill(pts); }
+
+// INDEXED: `in` is the queue of points that got a light (k_light_pick<true>); its slots name the point slots.
+// MODE: 0 = runs unconditionally; 1 = only if the lit points are sparse (the split form); 2 = only if they are not
+template <bool NEE, bool CONTINUE, bool INDEXED = false, int MODE = 0>
 __global__ void __launch_bounds__(WAVE, RT_SCATTER_MIN_WAVES) k_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
                                                                        const PointSoA points, const RayQueue in, const RaySoA rays_out,
                                                                        const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
-                                                                       const PixelBuffers px, const int img_w, const Layering layers) {
+                                                                       const PixelBuffers px, const int img_w, const Layering layers,
+                                                                       const RayQueue all_points, const RayQueue lit_points) {
+    if (MODE != 0 && lit_points_are_sparse(all_points, lit_points) != (MODE == 1)) {
+        return;
+    }
     const uint32_t n_live_chunks = in.live_chunks();
     ChunkWalk walk(n_live_chunks);
     for (uint32_t c; walk.next(c);) {
@@ -183,8 +233,9 @@ __global__ void __launch_bounds__(WAVE, RT_SCATTER_MIN_WAVES) k_scatter(const Sc
         uint32_t xy = 0;
         if (active) {
             uint32_t ray_slot;
-            const ShadePoint pt = load_point(points, slot0 + threadIdx.x, ray_slot);
-            const LightPick pick = (NEE && sc.light_cwnodes_count != 0) ? load_pick(points, slot0 + threadIdx.x) : no_light_pick();
+            const uint32_t point_slot = INDEXED ? points.nee_index[slot0 + threadIdx.x] : slot0 + threadIdx.x;
+            const ShadePoint pt = load_point(points, point_slot, ray_slot);
+            const LightPick pick = (NEE && sc.light_cwnodes_count != 0) ? load_pick(points, point_slot) : no_light_pick();
             Ray ray;
             {
                 const float4 d = rays_in.d_cw[ray_slot], cc = rays_in.c_cs[ray_slot], io = rays_in.ior[ray_slot];
@@ -277,17 +328,40 @@ void launch(const ShadeLaunch &a) {
     // emitter hits whose MIS weight was deferred; an empty queue costs a few microseconds
     k_shade_emissive<<<std::min(g, 2048), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.deferred, a.out_deferred, a.px, a.vw);
     // stage 2: which light
-    if (pick_apart) {
-        k_light_pick<<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.layers);
+    const bool nee_compact = pick_apart && (a.split & 4) != 0;
+    if (nee_compact) {
+        k_light_pick<true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
+    } else if (pick_apart) {
+        k_light_pick<false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
     }
     // stage 3: shadow ray + continuation
-    if ((a.split & 2) != 0) {
-        k_scatter<true, false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers);
-        k_scatter<false, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers);
+    if (nee_compact) {
+        // the next-event estimation runs over the points that have a light to sample -- full wavefronts instead of the 11 of 64
+        // lanes that take that branch in the combined kernel (Bistro-class scene) -- the continuation over all points; or, when
+        // most points are lit, the combined kernel (lit_points_are_sparse)
+        k_scatter<true, false, true, 1><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.nee, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
+        k_scatter<false, true, false, 1><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
+        k_scatter<true, true, false, 2><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
+    } else if ((a.split & 2) != 0) {
+        k_scatter<true, false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
+        k_scatter<false, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
     } else {
-        k_scatter<true, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers);
+        k_scatter<true, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
     }
 }
 
 } // namespace shade
 } // namespace rt
+
+#ifdef RT_PROFILE_SHADE
+extern "C" __attribute__((visibility("default"))) int rayhip_tuning_read_shade_profile(unsigned long long out[64], int reset) {
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_prof_shade), 64 * sizeof(unsigned long long)) != hipSuccess) {
+        return 1;
+    }
+    if (reset) {
+        unsigned long long z[64] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(rt::g_prof_shade), z, sizeof(z)) != hipSuccess;
+    }
+    return 0;
+}
+#endif

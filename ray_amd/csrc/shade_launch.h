@@ -16,6 +16,7 @@ struct PointSoA {
     float4 *scalars; // roughness, metallic, specular, mix_weight
     float4 *misc;    // mix_pick, material | backfacing << 31, cone_width, -
     float4 *light;   // written by k_light_pick: light index, 1 / pick probability, rest of the random number, -
+    uint32_t *nee_index; // written by k_light_pick: the points that got a light, densely (slots of the `nee` queue -> point slots)
 };
 
 // one bounce of K5: shade the rays of queue `in` (ray buffer rays_in + hits) -> shade points (pts) -> secondary rays into
@@ -28,13 +29,14 @@ struct ShadeLaunch {
     ShadowSoA shadow;
     DeferredSoA deferred;
     PointSoA points;
-    RayQueue in, pts, out_rays, out_shadow, out_deferred;
+    RayQueue in, pts, out_rays, out_shadow, out_deferred, nee;
     PixelBuffers px;
     Layering layers;
     int vw;           // row pitch of the per-iteration pixel buffers (virtual frame width)
     float mix_factor; // 1 / iteration: blend of the first-hit feature images (single-layer passes)
     int bounce, grid;
-    int split;        // bit 0: the light pick as its own kernel; bit 1: next-event estimation and continuation as two launches
+    int split;        // bit 0: the light pick as its own kernel; bit 1: next-event estimation and continuation as two launches;
+                      // bit 2 (with bit 0): next-event estimation as its own launch over the points that GOT a light, densely packed
     hipStream_t stream;
 };
 namespace shade {

@@ -734,6 +734,7 @@ RT_HD LightSample sample_light(const SceneView &sc, const LightPick &pick, const
     if (pick.inv_prob == 0.0f) {
         return s;
     }
+    RT_PROF_SHADE_LANES(2)
     const rayhip_light &l = sc.lights[pick.light];
     s.radiance = mk3(l.col);
     s.casts_shadow = light_cast_shadow(l);
@@ -754,9 +755,11 @@ RT_HD LightSample sample_light(const SceneView &sc, const LightPick &pick, const
         sample_line_light(l, P, u, s);
         break;
     case LIGHT_TYPE_TRI:
+        RT_PROF_SHADE_LANES(4)
         sample_triangle_light(sc, l, pick.light, P, u, tex_jitter, s);
         break;
     case LIGHT_TYPE_ENV:
+        RT_PROF_SHADE_LANES(6)
         sample_env_light(sc, l, P, T, B, N, pick.u_left, u, tex_jitter, s);
         break;
     default:

@@ -327,6 +327,7 @@ RT_HD void principled_continue(const ScatterFrame &fr, const ShadePoint &pt, con
     f3 dir;
     if (pick < L.p_diffuse) {
         if (n_diff < ps.max_diff_depth && budget) {
+            RT_PROF_SHADE_LANES(14)
             const f3 d = to_world(fr, cosine_hemisphere_draw(u));
             LobeValue v = disney_diffuse_eval(-fr.I, fr.N, d, pt.roughness, pt.base, L.sheen);
             v.f *= L.diffuse_scale;
@@ -339,6 +340,7 @@ RT_HD void principled_continue(const ScatterFrame &fr, const ShadePoint &pt, con
         }
     } else if (pick < L.p_diffuse + L.p_gloss) {
         if (n_spec < ps.max_spec_depth && budget) {
+            RT_PROF_SHADE_LANES(16)
             const LobeValue v = gloss_draw(fr, L.gloss, u, dir);
             const float pdf = v.pdf * L.p_gloss;
             count_bounce(next, depth_in, BOUNCE_SPECULAR);
@@ -350,6 +352,7 @@ RT_HD void principled_continue(const ScatterFrame &fr, const ShadePoint &pt, con
         }
     } else if (pick < L.p_diffuse + L.p_gloss + L.p_coat) {
         if (n_spec < ps.max_spec_depth && budget) {
+            RT_PROF_SHADE_LANES(18)
             const LobeValue v = coat_draw(fr, L.coat_alpha, L.coat_ior, L.coat_f0, u, dir);
             const float pdf = v.pdf * L.p_coat;
             count_bounce(next, depth_in, BOUNCE_SPECULAR);
@@ -365,6 +368,7 @@ RT_HD void principled_continue(const ScatterFrame &fr, const ShadePoint &pt, con
         pick = safe_div_pos(pick, L.p_transmit);
         const bool reflect = pick < L.fresnel;
         if (((!reflect && n_refr < ps.max_refr_depth) || (reflect && n_spec < ps.max_spec_depth)) && budget) {
+            RT_PROF_SHADE_LANES(20)
             LobeValue v;
             if (reflect) {
                 v = gloss_draw(fr, L.clear_gloss, u, dir);
@@ -394,6 +398,7 @@ RT_HD void principled_continue(const ScatterFrame &fr, const ShadePoint &pt, con
 // `ray`: the ray that produced the shade point (direction, throughput, ior stack, cone, pixel, depth counters)
 template <bool NEE = true, bool CONTINUE = true>
 RT_HD void scatter_stage(const SceneView &sc, const ShadeParams &sp, const Ray &ray, const ShadePoint &pt, const LightPick &pick, Scatter &out) {
+    RT_PROF_SHADE_LANES(0)
     const PassLimits &ps = sp.ps;
     const rayhip_material &mat = sc.materials[pt.material];
     const PathRandom rnd = path_random(sc, sp, ray.xy, ray.depth);
@@ -438,20 +443,26 @@ RT_HD void scatter_stage(const SceneView &sc, const ShadeParams &sp, const Ray &
     const float outside_ior = peek_ior_stack(ray.ior, pt.backfacing);
     switch (mat.type) {
     case NODE_DIFFUSE:
+        RT_PROF_SHADE_LANES(22)
         scatter_diffuse(fr, pt, ls, light_usable, CONTINUE && n_diff < ps.max_diff_depth && budget, ray.depth, u, out);
         break;
     case NODE_GLOSSY:
+        RT_PROF_SHADE_LANES(24)
         scatter_glossy(fr, pt, ls, light_usable, CONTINUE && n_spec < ps.max_spec_depth && budget, ray.depth, u, out);
         break;
     case NODE_REFRACTIVE:
+        RT_PROF_SHADE_LANES(26)
         scatter_refractive(fr, pt, mat.ior, outside_ior, ls, light_usable, CONTINUE && n_refr < ps.max_refr_depth && budget, ray.depth, u, out);
         break;
     case NODE_PRINCIPLED: {
+        RT_PROF_SHADE_LANES(8)
         const PrincipledLobes L = principled_lobes(fr, pt, mat, outside_ior);
         if (light_usable) {
+            RT_PROF_SHADE_LANES(10)
             principled_nee(fr, pt, L, ls, out);
         }
         if (CONTINUE) {
+            RT_PROF_SHADE_LANES(12)
             principled_continue(fr, pt, L, ps, ray.depth, u, pt.mix_pick, out);
         }
     } break;
@@ -465,6 +476,7 @@ RT_HD void scatter_stage(const SceneView &sc, const ShadeParams &sp, const Ray &
         const float survive_u = rnd.get(RAND_DIM_BSDF_PICK).y;
         const float q = (n_total > ps.min_total_depth) ? fmaxf(0.05f, 1.0f - brightest) : 0.0f;
         if (survive_u >= q && brightest > 0.0f && next.pdf > 0.0f) {
+            RT_PROF_SHADE_LANES(28)
             next.pdf = fminf(next.pdf, 1e6f);
             next.c.x /= (1.0f - q);
             next.c.y /= (1.0f - q);
@@ -475,6 +487,7 @@ RT_HD void scatter_stage(const SceneView &sc, const ShadeParams &sp, const Ray &
     if (NEE) {
         shadow.c *= ray.c;
         if (fmaxf(shadow.c.x, fmaxf(shadow.c.y, shadow.c.z)) > 0.0f) {
+            RT_PROF_SHADE_LANES(30)
             // direction and length between the two nudged end points; a negative length marks "towards the environment"
             shadow.d = normalize_len(ls.point - shadow.o, shadow.dist);
             shadow.dist *= ls.reach;

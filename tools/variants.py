@@ -149,6 +149,19 @@ def run1(name, workload="sponza", K=16):
               f"shade {(st['primary_shade'] + st['secondary_shade']) / K / 1e3:5.2f} ms gen {st['primary_ray_gen'] / K / 1e3:4.2f} sort {st['secondary_sort'] / K / 1e3:4.2f} | "
               f"vs first: max|d| {d.max():.2e} frac>1e-3 {(d.max(axis=-1) > 1e-3).mean():.2e} | max_stack {c2['max_stack']}/{c3['max_stack']}",
               flush=True)
+        if hasattr(L.lib, "rayhip_tuning_read_shade_profile"):
+            import ctypes
+            f = L.lib.rayhip_tuning_read_shade_profile
+            f.argtypes, f.restype = [ctypes.POINTER(ctypes.c_ulonglong * 64), ctypes.c_int], ctypes.c_int
+            buf = (ctypes.c_ulonglong * 64)()
+            f(ctypes.byref(buf), 1)
+            names = {0: "scatter stage", 2: "sample_light", 4: "  triangle light", 6: "  environment light", 8: "principled: lobes", 10: "principled: NEE",
+                     12: "principled: continuation", 14: "  diffuse draw", 16: "  gloss draw", 18: "  coat draw", 20: "  transmission draw", 22: "diffuse material",
+                     24: "glossy material", 26: "refractive material", 28: "roulette survivors", 30: "shadow ray set-up"}
+            print("  shade-stage lane census (all passes so far): section, wave-level executions, share of the stage's executions, active lanes")
+            for k in sorted(names):
+                if buf[k + 1]:
+                    print(f"    {names[k]:28s} {buf[k + 1]:12d} {buf[k + 1] / max(buf[1], 1):6.3f} {buf[k] / buf[k + 1]:6.1f}")
         if hasattr(L.lib, "rayhip_tuning_read_profile"):
             import ctypes
             f = L.lib.rayhip_tuning_read_profile
