@@ -44,6 +44,9 @@ namespace rt {
 #ifndef RT_BVH4_PINNED_FETCH
 #define RT_BVH4_PINNED_FETCH 1
 #endif
+#ifndef RT_BVH4_PACKED_FMA
+#define RT_BVH4_PACKED_FMA 0
+#endif
 #ifndef RT_BVH4_SGPR_CSWAP
 #define RT_BVH4_SGPR_CSWAP 0 // (measured neutral in the kernel: K2 1.94 against 1.92 ms; the microbenchmark's penalty does not show up in context)
 #endif
@@ -141,8 +144,16 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
         const int sh = 8 * c;
         float t_in[3], t_out[3];
         for (int a = 0; a < 3; ++a) {
+#if defined(__HIP_DEVICE_COMPILE__) && RT_BVH4_PACKED_FMA
+            // entry and exit plane of an axis in one v_pk_fma_f32 (two fma for the issue slot of one: tools/valu_bench.hip)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            const f2v q2 = {float((q_in[a] >> sh) & 0xffu), float((q_out[a] >> sh) & 0xffu)};
+            const f2v t2 = __builtin_elementwise_fma(q2, f2v{k[a], k[a]}, f2v{base_in[a], base_out[a]});
+            t_in[a] = t2.x, t_out[a] = t2.y;
+#else
             t_in[a] = __builtin_fmaf(float((q_in[a] >> sh) & 0xffu), k[a], base_in[a]);
             t_out[a] = __builtin_fmaf(float((q_out[a] >> sh) & 0xffu), k[a], base_out[a]);
+#endif
         }
 #if RT_BVH4_TEST_FOLDED
         // the whole error budget sits in the padding of the planes (2^-20 M_a per plane, derivation in rt_bvh8.h: the same grid, the

@@ -55,6 +55,13 @@ namespace shade {
 #ifndef RT_SCATTER_MIN_WAVES
 #define RT_SCATTER_MIN_WAVES 4
 #endif
+// the two halves of the split form hold less than the combined kernel: their own budgets
+#ifndef RT_SCATTER_NEE_MIN_WAVES
+#define RT_SCATTER_NEE_MIN_WAVES 4
+#endif
+#ifndef RT_SCATTER_CONT_MIN_WAVES
+#define RT_SCATTER_CONT_MIN_WAVES 4
+#endif
 
 __device__ __forceinline__ void store_point(const PointSoA &s, const uint32_t i, const ShadePoint &pt, const uint32_t ray_slot) {
     s.p_slot[i] = mkfloat4(pt.P.x, pt.P.y, pt.P.z, uint_as_float(ray_slot));
@@ -212,7 +219,7 @@ __device__ __forceinline__ bool lit_points_are_sparse(const RayQueue &pts, const
 // INDEXED: `in` is the queue of points that got a light (k_light_pick<true>); its slots name the point slots.
 // MODE: 0 = runs unconditionally; 1 = only if the lit points are sparse (the split form); 2 = only if they are not
 template <bool NEE, bool CONTINUE, bool INDEXED = false, int MODE = 0>
-__global__ void __launch_bounds__(WAVE, RT_SCATTER_MIN_WAVES) k_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
+__global__ void __launch_bounds__(WAVE, (NEE && CONTINUE) ? RT_SCATTER_MIN_WAVES : (NEE ? RT_SCATTER_NEE_MIN_WAVES : RT_SCATTER_CONT_MIN_WAVES)) k_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
                                                                        const PointSoA points, const RayQueue in, const RaySoA rays_out,
                                                                        const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
                                                                        const PixelBuffers px, const int img_w, const Layering layers,
@@ -305,6 +312,12 @@ __global__ void __launch_bounds__(WAVE) k_shade_emissive(const SceneView sc, con
         add_secondary_pixel(res, xy, img_w, px.temp);
     }
 }
+
+// (Round 3 also tried the pick with EIGHT lanes per shade point -- lane j fetches and evaluates child j, the group exchanges the
+// importances and every lane runs light_level_choice; the table is row-type major for it, 128 consecutive bytes per group and
+// load.  Bit-identical picks, an eighth of the L1 traffic -- and 0.73 instead of 0.34 ms per iteration: only the importance
+// (40 of the ~110 instructions of a level) is shared out, the selection, the exchange and the per-point set-up run once per
+// eight points instead of once per sixty-four.  profiles/r03/experiments/variants_pick_*.txt; the kernel was removed.)
 
 // ---- launcher ---------------------------------------------------------------------------------------------------------------
 void launch(const ShadeLaunch &a) {

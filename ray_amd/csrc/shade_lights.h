@@ -207,8 +207,7 @@ RT_HD void light_child_box(const rayhip_light_cwbvh_node &n, const int i, float 
 // node only -- box centre and half-diagonal, the decoded emission-cone axis and its two cosines: 8 divisions and 3 square
 // roots per child -- and a part that depends on the shade point.  The first is evaluated ONCE per scene into the
 // `light_children` table (fill_light_children, run on the host at upload with these very functions: same IEEE operations,
-// same bits), LIGHT_CHILDREN_STRIDE float4 per node: [0..1] the eight fluxes -- an empty or black slot needs nothing else,
-// and the 8-wide tree is sparsely filled -- then three float4 per child.
+// same bits), LIGHT_CHILDREN_STRIDE float4 per node (layout: fill_light_children).
 struct LightChild {
     float4 axis_extent;  // emission-cone axis (unit), half-diagonal of the box
     float4 centre_valid; // box centre, 1 if the box is finite (else importance = flux)
@@ -249,13 +248,25 @@ RT_HD LightChild decode_light_child(const rayhip_light_cwbvh_node &n, const int 
     }
     return c;
 }
+// Rows [0..1]: the eight child links (what the descent follows: no second table in the loop); rows [2 + 8 r + i]: row r (axis +
+// extent, centre + valid, cosines + flux) of child i -- row-type major, so that eight lanes fetching the same row of the eight
+// children of a node (k_light_pick: one child per lane) read 128 consecutive bytes.
 RT_HD void fill_light_children(const rayhip_light_cwbvh_node &n, float4 *out /* [LIGHT_CHILDREN_STRIDE] */) {
-    out[0] = mkfloat4(n.flux[0], n.flux[1], n.flux[2], n.flux[3]);
-    out[1] = mkfloat4(n.flux[4], n.flux[5], n.flux[6], n.flux[7]);
+    out[0] = mkfloat4(uint_as_float(n.child[0]), uint_as_float(n.child[1]), uint_as_float(n.child[2]), uint_as_float(n.child[3]));
+    out[1] = mkfloat4(uint_as_float(n.child[4]), uint_as_float(n.child[5]), uint_as_float(n.child[6]), uint_as_float(n.child[7]));
     for (int i = 0; i < 8; ++i) {
         const LightChild c = decode_light_child(n, i);
-        out[2 + 3 * i + 0] = c.axis_extent, out[2 + 3 * i + 1] = c.centre_valid, out[2 + 3 * i + 2] = c.cosines;
+        out[2 + 0 * 8 + i] = c.axis_extent, out[2 + 1 * 8 + i] = c.centre_valid, out[2 + 2 * 8 + i] = c.cosines;
     }
+}
+RT_HD LightChild load_light_child(const SceneView &sc, const uint32_t node, const int i) {
+    const float4 *t = sc.light_children + size_t(node) * LIGHT_CHILDREN_STRIDE + 2;
+    LightChild c;
+    c.axis_extent = t[0 * 8 + i], c.centre_valid = t[1 * 8 + i], c.cosines = t[2 * 8 + i];
+    return c;
+}
+RT_HD uint32_t light_child_link(const SceneView &sc, const uint32_t node, const int i) {
+    return reinterpret_cast<const uint32_t *>(sc.light_children + size_t(node) * LIGHT_CHILDREN_STRIDE)[i];
 }
 
 // Division and square root of the importance heuristic.  A child's importance only steers WHICH light is sampled and with
@@ -307,10 +318,9 @@ RT_HD float light_child_importance(const LightChild &c, const f3 P) {
 }
 // the eight importances of a node (their sum is taken in the oracle's SSE association order, sum8_sse_order)
 RT_HD void light_node_importances(const SceneView &sc, const uint32_t node, const f3 P, float imp[8]) {
-    const float4 *t = sc.light_children + size_t(node) * LIGHT_CHILDREN_STRIDE + 2; // (rows 0-1: the fluxes again, for host-side tools)
     LightChild c[8];
     for (int i = 0; i < 8; ++i) {
-        c[i].axis_extent = t[3 * i + 0], c[i].centre_valid = t[3 * i + 1], c[i].cosines = t[3 * i + 2];
+        c[i] = load_light_child(sc, node, i);
     }
     for (int i = 0; i < 8; ++i) {
         imp[i] = light_child_importance(c[i], P);
@@ -327,6 +337,37 @@ struct LightPick {
 // Descend from the root: at every node the children's importances form a discrete distribution, the running random number
 // selects a child and is re-stretched to [0, 1) inside its interval (CoreRef.cpp:3273-3312).  Everything is kept in
 // registers: the selection is a chain of selects, not an indexed local array.
+// one level of the descent, given the eight importances: the child the running random number selects (u is re-stretched inside
+// its interval, prob multiplied by its share); false when nothing below this node can light the point
+RT_HD bool light_level_choice(const float imp[8], float &u, float &prob, int &chosen) {
+    const float total = sum8_sse_order(imp);
+    if (total == 0.0f) {
+        return false;
+    }
+    float share[8], upper[9];
+    upper[0] = 0.0f;
+    for (int j = 0; j < 8; ++j) {
+        share[j] = steer_div(imp[j], total);
+        upper[j + 1] = upper[j] + share[j];
+    }
+    for (int j = 0; j < 8; ++j) { // the trailing entries that already equal the total become 1.01: u < 1 never passes them
+        if (upper[j + 1] == upper[8]) {
+            upper[j + 1] = 1.01f;
+        }
+    }
+    chosen = 0;
+    for (int j = 1; j < 9; ++j) {
+        chosen += (upper[j] <= u) ? 1 : 0;
+    }
+    float lower = upper[0], width = share[0];
+    for (int j = 1; j < 8; ++j) {
+        lower = (chosen == j) ? upper[j] : lower;
+        width = (chosen == j) ? share[j] : width;
+    }
+    u = fractf((u - lower) / width);
+    prob *= width;
+    return true;
+}
 RT_HD LightPick pick_light(const SceneView &sc, const f3 P, float u) {
     LightPick pick;
     pick.light = 0, pick.inv_prob = 0.0f, pick.u_left = u;
@@ -335,33 +376,11 @@ RT_HD LightPick pick_light(const SceneView &sc, const f3 P, float u) {
     while ((cur & LEAF_NODE_BIT) == 0) {
         float imp[8];
         light_node_importances(sc, cur, P, imp);
-        const float total = sum8_sse_order(imp);
-        if (total == 0.0f) {
+        int chosen;
+        if (!light_level_choice(imp, u, prob, chosen)) {
             return pick; // nothing in this subtree can light P
         }
-        float share[8], upper[9];
-        upper[0] = 0.0f;
-        for (int j = 0; j < 8; ++j) {
-            share[j] = steer_div(imp[j], total);
-            upper[j + 1] = upper[j] + share[j];
-        }
-        for (int j = 0; j < 8; ++j) { // the trailing entries that already equal the total become 1.01: u < 1 never passes them
-            if (upper[j + 1] == upper[8]) {
-                upper[j + 1] = 1.01f;
-            }
-        }
-        int chosen = 0;
-        for (int j = 1; j < 9; ++j) {
-            chosen += (upper[j] <= u) ? 1 : 0;
-        }
-        float lower = upper[0], width = share[0];
-        for (int j = 1; j < 8; ++j) {
-            lower = (chosen == j) ? upper[j] : lower;
-            width = (chosen == j) ? share[j] : width;
-        }
-        u = fractf((u - lower) / width);
-        cur = sc.light_cwnodes[cur].child[chosen];
-        prob *= width;
+        cur = light_child_link(sc, cur, chosen);
     }
     pick.light = (cur & PRIM_INDEX_BITS);
     pick.inv_prob = 1.0f / prob;
