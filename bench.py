@@ -151,6 +151,9 @@ def measured_traffic(workload, steps, batch, world=1):
                "exact": bool(exact), "table": os.path.relpath(traffic_table_path(), ROOT),
                # the profile belongs to the kernels it was taken with: anything else is a stale figure
                "stale": e.get("csrc_hash") != csrc_hash(), "profiled_csrc_hash": e.get("csrc_hash")}
+        if "valu_wave_instructions_per_launch" in e:  # (the third profile of tools/k2_traffic.py: SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU)
+            out["valu_wave_instructions_per_launch"] = float(e["valu_wave_instructions_per_launch"]) * k
+            out["valu_active_lanes"] = e.get("valu_active_lanes")
         if not exact:
             out["scaled_by"] = k
             out["scaled_from"] = {"steps": e["steps"], "iterations_per_pass": e["iterations_per_pass"], "n_gpus": 1}
@@ -477,6 +480,15 @@ def main():
                 "traffic_is_stale": bool(traffic and traffic.get("stale")),  # profile taken with other kernel sources: re-profile (tools/k2_traffic.py)
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
                 "traffic_detail": traffic,
+                # the kernel's BINDING resource is the issue rate of the vector ALU: vector instructions per launch from the
+                # committed PMC profile / the live launch time, against what tools/valu_bench.hip measures for one instruction class
+                # (all full-rate: mul / add / logic; all half-rate: compares, selects, min / max, conversions, 3-operand integer)
+                "valu_issue": ({"wave_instructions_per_s": traffic["valu_wave_instructions_per_launch"] * launches / k2_s,
+                                "peak_full_rate_class": 1.09e12, "peak_half_rate_class": 0.59e12,
+                                "frac_of_half_rate_class": traffic["valu_wave_instructions_per_launch"] * launches / k2_s / 0.59e12,
+                                "active_lanes_of_64": traffic.get("valu_active_lanes"),
+                                "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU of this command / live launch time; peaks: profiles/r03/valu_bench.txt"}
+                               if (traffic and traffic.get("valu_wave_instructions_per_launch") and k2_s > 0) else None),
                 "avg_launch_ms": k2_ms / launches, "launches": k2_launches,
                 "algorithmic": {
                     "bytes_per_launch": k2_bytes / launches, "GBps": alg_gbs, "frac_of_peak": alg_gbs / HBM_PEAK_GBS,

@@ -106,6 +106,7 @@ struct rayhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t tri_pitch = 3; // 16-byte rows per record of `tris` as uploaded (SceneView::tri_pitch)
+    uint32_t all_solid = 0; // SceneView::all_solid
     hipDeviceProp_t props = {};
     int grid_waves = 0; // resident-ish grid for the wave-per-block kernels
     bool small_scene = false; // BLAS nodes + triangles fit one XCD's L2: traversal kernels with the smaller register footprint
@@ -660,7 +661,7 @@ static int upload_lights(rayhip_ctx *c, const rayhip_scene_desc *d) {
 // the kernels' view of what is on the device (SceneView), after a full upload or an instance update
 static void refresh_scene_view(rayhip_ctx *c, const rayhip_scene_desc *d, const uint32_t tlas_root, const rayhip_lbvh::Box &root_box) {
     SceneView &v = c->sc;
-    v.nodes = c->nodes.as<rayhip_bvh2_node>(), v.tris = c->tris.as<rayhip_tri_accel>(), v.tri_pitch = c->tri_pitch;
+    v.nodes = c->nodes.as<rayhip_bvh2_node>(), v.tris = c->tris.as<rayhip_tri_accel>(), v.tri_pitch = c->tri_pitch, v.all_solid = getenv("RAYHIP_NO_ALL_SOLID") ? 0u : c->all_solid;
     v.tri_indices = c->tri_indices.as<uint32_t>(), v.tri_materials = c->tri_materials.as<rayhip_tri_mat_data>();
     v.materials = c->materials.as<rayhip_material>(), v.vertices = c->vertices.as<rayhip_vertex>();
     v.vtx_indices = c->vtx_indices.as<uint32_t>(), v.mesh_instances = c->mesh_instances.as<rayhip_mesh_instance>();
@@ -925,6 +926,14 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     }
     UPLOAD_TRACE("bvh uploaded")
     UP(tri_materials)
+    { // is there a triangle side that is not plainly solid?  (the closest-hit kernels skip the per-hit material fetch when not)
+        const uint32_t n = d->tri_materials_count;
+        bool all_solid = n != 0;
+        for (uint32_t i = 0; i < n && all_solid; ++i) {
+            all_solid = (d->tri_materials[i].front_mi & MATERIAL_SOLID_BIT) != 0 && (d->tri_materials[i].back_mi & MATERIAL_SOLID_BIT) != 0;
+        }
+        c->all_solid = all_solid ? 1u : 0u;
+    }
     UP(materials)
     UP(vertices)
     UP(vtx_indices)

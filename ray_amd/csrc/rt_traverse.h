@@ -371,6 +371,9 @@ RT_HD_RARE bool closest_resolve_transparency(const SceneView &sc, const TracePar
 // is the surface the hit landed on opaque for the transparency loop?  (the first test of closest_resolve_transparency,
 // CoreRef.cpp:3071-3079 -- true for almost every hit, and it needs nothing of the ray)
 RT_HD bool hit_side_is_solid(const SceneView &sc, const Hit &inter) {
+    if (sc.all_solid != 0u) { // (scene-wide flag set at upload: no per-hit fetch of the material word)
+        return true;
+    }
     const bool is_backfacing = (inter.prim_index < 0);
     const uint32_t tri_index = is_backfacing ? uint32_t(-inter.prim_index - 1) : uint32_t(inter.prim_index);
     const rayhip_tri_mat_data md = sc.tri_materials[tri_index];

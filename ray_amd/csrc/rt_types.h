@@ -26,6 +26,7 @@ struct SceneView {
     const Bvh8Node *nodes8;     // 8-wide quantised BLAS trees (rt_bvh8.h), or null; at most one of the two wide forms is set
     const uint32_t *blas_root4; // per mesh instance: root of its tree in the wide form that is set (nodes4 or nodes8)
     const rayhip_tri_accel *tris;
+    uint32_t all_solid; // 1: every triangle side of the scene carries MATERIAL_SOLID_BIT -- the transparency round of IntersectScene has nothing to ask the materials
     uint32_t tri_pitch; // 16-byte rows per triangle record as the walks fetch it: 3 = the reference's 48-byte array, 4 = padded to one 64-byte sector each (rt_isect.h: load_tri)
     const uint32_t *tri_indices;
     const rayhip_tri_mat_data *tri_materials;

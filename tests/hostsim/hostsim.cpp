@@ -260,7 +260,7 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     c->nodes_used = uint32_t(s.nodes.size());
     c->have_scene = true;
     SceneView &v = c->sc;
-    v.nodes = s.nodes.data(), v.tris = s.tris.data(), v.tri_pitch = 3, v.tri_indices = s.tri_indices.data();
+    v.nodes = s.nodes.data(), v.tris = s.tris.data(), v.tri_pitch = 3, v.all_solid = 0, v.tri_indices = s.tri_indices.data();
     v.nodes4 = s.nodes4.empty() ? nullptr : s.nodes4.data(), v.blas_root4 = s.blas_root4.empty() ? nullptr : s.blas_root4.data();
     v.nodes8 = s.nodes8.empty() ? nullptr : s.nodes8.data();
     v.tri_materials = s.tri_materials.data(), v.materials = s.materials.data(), v.vertices = s.vertices.data();

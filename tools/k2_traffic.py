@@ -2,7 +2,7 @@
 """rocprofv3 counter CSVs -> profiles/<round>/k2_traffic.json (HBM-side bytes per launch of the closest-hit kernel) and a
 per-kernel HBM table of the whole timed region.
 
-    python tools/k2_traffic.py <out.json> <workload> <steps> <warmup> <iterations_per_pass> <fetch_dir> <write_dir> [<table.txt>]
+    python tools/k2_traffic.py <out.json> <workload> <steps> <warmup> <iterations_per_pass> <fetch_dir> <write_dir> [<table.txt> [<valu_dir>]]
 
 fetch_dir / write_dir: output directories of two `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of
 `bench.py --steps <steps> --warmup <warmup> --no-cpu-baseline` (separate passes: the two counters do not fit one).
@@ -69,6 +69,16 @@ def main():
              "launches_sampled": len(f), "launches_per_pass": per_pass,
              "fetch_bytes_per_launch": fsum / max(len(f), 1), "write_bytes_per_launch": wsum / max(len(w), 1),
              "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) -- python bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline"}
+    # optional third profile, `--pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU`: vector instructions per launch and the lanes they ran with --
+    # the kernel is bound by vector-ALU issue, this is its other roofline
+    valu_dir = sys.argv[9] if len(sys.argv) > 9 else None
+    if valu_dir:
+        insts = [(i, k, v / 1024.0) for i, k, v in counters(valu_dir, "SQ_INSTS_VALU") if is_k2(k)][-take:]
+        lanes = [(i, k, v / 1024.0) for i, k, v in counters(valu_dir, "SQ_THREAD_CYCLES_VALU") if is_k2(k)][-take:]
+        if insts:
+            entry["valu_wave_instructions_per_launch"] = sum(v for _, _, v in insts) / len(insts)
+            if lanes:
+                entry["valu_active_lanes"] = sum(v for _, _, v in lanes) / max(sum(v for _, _, v in insts), 1.0)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     entry["csrc_hash"] = bench.csrc_hash()  # the kernels this profile belongs to (bench.py marks it stale for any other)
