@@ -382,7 +382,7 @@ def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
 @pytest.mark.parametrize("name", SCENES)
 def test_wide_forms_agree_bit_for_bit(gpu_lib, name, monkeypatch):
     """the three acceleration-structure forms the kernels can walk -- the reference's BVH2 (RAYHIP_BVH_WIDTH=2), the 4-wide
-    collapse (4) and the 8-wide one (8, the default: its own child order, its own triangle order, one stack entry per level)
+    collapse (4, the default) and the 8-wide one (8: its own child order, its own triangle order, one stack entry per level)
     -- cull differently and find the same hits: hit records and frames are the same bits, through the plain kernels and
     through the persistent one"""
     g = util.golden_ref(name)
@@ -402,6 +402,60 @@ def test_wide_forms_agree_bit_for_bit(gpu_lib, name, monkeypatch):
         assert np.array_equal(frame, ref[2]), key
     # shadow visibilities are taken by the instrumented BVH2 kernel in every mode (test hook): equal by construction
     assert np.array_equal(out[("8", "2")][1], ref[1])
+
+
+@pytest.mark.parametrize("name", ["cornell_lights", "cornell_principled", "cornell_env"])
+def test_shade_forms_agree_bit_for_bit(gpu_lib, name, monkeypatch):
+    """the shade stage's launch forms (RAYHIP_SHADE_SPLIT: pick folded into the surface kernel / its own kernel, next-event
+    estimation and continuation as one launch / two / two with the NEE over the compacted list of lit points, the form then
+    chosen on the device) group the same per-point arithmetic differently: frames, aux images and the kernel-level shade
+    outputs must be the same bits"""
+    frames = {}
+    for split in ("0", "1", "3", "5"):
+        monkeypatch.setenv("RAYHIP_SHADE_SPLIT", split)
+        ctx = util.make_context(gpu_lib, name)
+        ctx.render_batch(1, 5)
+        frames[split] = (ctx.readback(hip.BUF_RAW), ctx.readback(hip.BUF_BASE_COLOR), ctx.readback(hip.BUF_DEPTH_NORMALS))
+    for split, f in frames.items():
+        for a, b in zip(f, frames["0"]):
+            assert np.array_equal(a, b), (name, split)
+
+
+def test_sparse_lights_take_the_split_form(gpu_lib, monkeypatch):
+    """a scene where most shade points end their light-tree descent without a light (small emitters facing away from most
+    of the scene): the device picks the split form; same frame as the combined kernel"""
+    from functools import partial
+    from ray_amd import api, scenes
+
+    s = api.CreateSceneHIP(use_tex_compression=False)
+    scenes.atrium(s, 0.02)
+    blob = api.export_scene_blob(s)
+    frames = {}
+    for split in ("1", "5"):
+        monkeypatch.setenv("RAYHIP_SHADE_SPLIT", split)
+        ctx = hip.Context(0, gpu_lib)
+        ctx.upload_static(util.pmj())
+        ctx.resize(160, 90)
+        ctx.upload_scene_blob(blob)
+        ctx.render_batch(1, 4)
+        frames[split] = ctx.readback(hip.BUF_RAW)
+    assert np.array_equal(frames["1"], frames["5"])
+    assert float(frames["5"].sum()) > 0.0
+
+
+def test_triangle_pitch_is_invisible(gpu_lib, monkeypatch):
+    """RAYHIP_TRI_PITCH=64 re-pitches the triangle records on the device (one 64-byte sector each): same hits, same frame"""
+    name = "cornell_instances"
+    g = util.golden_ref(name)
+    out = {}
+    for pitch in ("48", "64"):
+        monkeypatch.setenv("RAYHIP_TRI_PITCH", pitch)
+        ctx = util.make_context(gpu_lib, name)
+        _, hits, _ = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
+        ctx.render_batch(1, 4)
+        out[pitch] = (hits, ctx.readback(hip.BUF_RAW))
+    util.assert_hits_identical(out["64"][0], out["48"][0])
+    assert np.array_equal(out["64"][1], out["48"][1])
 
 
 def test_maximal_batch_and_row_limit_split(gpu_lib):
