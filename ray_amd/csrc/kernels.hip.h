@@ -372,26 +372,13 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 // secondary bounces; WAVE for coherent primary rays -- the wavefront then finishes its 64 rays together and takes the next
 // chunk whole, i.e. the schedule of the plain kernel, with this kernel's flat register footprint (96 VGPRs, no spill stores
 // inside the walk, where the plain kernel's nested walks spill 60 VGPRs at 80: 7.8 GB of scratch writes per primary launch)
-// RT_REFILL_POSTPONE (4-wide walk): a lane that reaches a leaf does not wait for the wavefront's next leaf step -- it puts the leaf
-// aside (`pend`, one deep) and goes on with its next node, so the node steps -- 83 % of this kernel's vector instructions, issued
-// for 55 % of the lanes when leaves are tested in place -- keep the lanes that would otherwise stand at a leaf.  A lane waits only
-// when it meets a second leaf (or the end of its walk) with one still aside.  The leaves of a ray are tested in the order the
-// walk meets them, as before; what changes is that up to one leaf's result is missing when the next nodes are culled, i.e. a
-// SUPERSET of nodes is visited with a distance limit that is never smaller than the in-place walk's: same triangles accepted
-// in the same order, same hit bits.
-// MEASURED (profiles/r03/experiments/variants_postpone.txt, 20-layer passes): lanes busy in a node step 55.4 -> 58.5 %, in a
-// triangle test 36 -> 49 % -- but 6 % more lane-level node visits (the stale limit), the same number of wave-level node steps, and
-// K2 2.23 instead of 2.15 ms per iteration.  Off; kept as the record of the experiment.
+// Tried on top of this schedule and dropped (round 3, numbers in DESIGN.md section 3a): putting a leaf aside and going on with the next
+// node ("postponed leaves": busier lanes, but a stale distance limit -- 6 % more node visits, slower); requesting the next node
+// into an LDS sink the moment it is known (global_load_lds as a prefetch: much slower); other vote weights (flat).
 // the vote between a node step and a leaf step: a node step while  n_node * DEN >= n_leaf * NUM  (1 / 1: plain majority)
 #ifndef RT_REFILL_VOTE_NUM
 #define RT_REFILL_VOTE_NUM 1
 #define RT_REFILL_VOTE_DEN 1
-#endif
-#ifndef RT_REFILL_PREFETCH
-#define RT_REFILL_PREFETCH 0 // measured: K2 2.46 instead of 1.92 ms (profiles/r03/experiments/variants_prefetch.txt) -- the LDS-destination load is no cheap hint
-#endif
-#ifndef RT_REFILL_POSTPONE
-#define RT_REFILL_POSTPONE 0
 #endif
 template <int WIDE, int MIN_WAIT = RT_REFILL_MIN>
 __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_refill(const SceneView sc, const TraceParams tp, const RaySoA rays,
@@ -421,31 +408,6 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
     // children of the node visited last; at the top level they are BVH2 node words as before.
     uint32_t lvl = IDLE, slot = 0, cur = BVH4_SENTINEL, tos = BVH4_SENTINEL, size = 0, mi_index = 0, ray_flags = 0;
     uint32_t cur_bits = 0, tos_bits = 0, tri_base = 0, l0 = 0, l1 = 0, oct_inv = 0;
-    // RT_REFILL_PREFETCH (4-wide walk): the moment a lane knows its next node or leaf, one dword of it is requested into a 256-byte
-    // LDS sink nobody reads (global_load_lds: no destination register to keep alive) -- the line is on its way to L2 / L1 while the
-    // wavefront does its stack bookkeeping, votes, and waits its turn among the SIMD's other wavefronts: with six of them sharing
-    // the issue slots those ~80 instructions are ~0.7 us of wall clock, most of a miss's latency.
-    constexpr bool PREFETCH = (WIDE == 4) && (RT_REFILL_PREFETCH != 0);
-    __shared__ uint32_t pf_sink[PREFETCH ? WAVE : 1];
-    // (the sink's LDS offset for M0: the low half of its generic address; uniform)
-    const uint32_t pf_lds = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(reinterpret_cast<uintptr_t>(&pf_sink[0])))));
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RT_PREFETCH_CUR()                                                                                               \
-    if (PREFETCH && lvl == BLAS && cur != BVH4_SENTINEL) {                                                              \
-        const bool node_ = (cur & BVH2_PRIM_COUNT_BITS) == 0;                                                           \
-        const size_t off_ = node_ ? size_t(cur) * sizeof(Bvh4Node) : size_t(cur & BVH2_PRIM_INDEX_BITS) * size_t(sc.tri_pitch * 16u); \
-        const char *base_ = node_ ? reinterpret_cast<const char *>(sc.nodes4) : reinterpret_cast<const char *>(sc.tris); \
-        uint32_t m0_;                                                                                                   \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"           \
-                     : "=&s"(m0_)                                                                                       \
-                     : "v"(base_ + off_), "s"(pf_lds)                                                                   \
-                     : "memory");                                                                                       \
-    }
-#else
-#define RT_PREFETCH_CUR()
-#endif
-    constexpr bool POSTPONE = (WIDE == 4) && (RT_REFILL_POSTPONE != 0);
-    uint32_t pend = 0; // POSTPONE: the leaf word put aside (a leaf word is never 0: its count bits are set)
     bool res = false;
     f3 ro = {0.0f, 0.0f, 0.0f}, rd = {0.0f, 0.0f, 1.0f}; // world-space origin of the current transparency segment, direction
     f3 o = ro, d = rd, inv_d = rd;                        // object-space ray of the instance being walked
@@ -476,15 +438,8 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                 cur = st.read_at(--size); // the top-level `tos` saved at the entry of the instance
                 tos = st.read_at(--size);
             }
-        } else if (lvl == BLAS && cur == BVH4_SENTINEL && (!POSTPONE || pend == 0u)) {
+        } else if (lvl == BLAS && cur == BVH4_SENTINEL) {
             lvl = TLAS;
-            pop();
-        }
-    };
-    // POSTPONE: a leaf that became current is put aside when there is room, and the walk goes on with what the stack holds
-    auto stash = [&]() {
-        if (POSTPONE && lvl == BLAS && pend == 0u && (cur & BVH2_PRIM_COUNT_BITS) != 0) {
-            pend = cur;
             pop();
         }
     };
@@ -500,21 +455,11 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
         // as RT_REFILL_MIN lanes wait outside for the service part below
         for (;;) {
             const bool in_blas = (lvl == BLAS);
-            // (the sentinel never stays in `cur`: leave_blas -- except, POSTPONE, under a leaf that is still aside)
-            bool at_leaf, at_node;
-            int n_node, n_leaf, n_out;
-            if (POSTPONE) {
-                at_node = in_blas && (cur & BVH2_PRIM_COUNT_BITS) == 0 && cur != BVH4_SENTINEL;
-                at_leaf = in_blas && pend != 0u;                           // takes part in a leaf step
-                const bool blocked = at_leaf && !at_node;                  // ... and cannot do anything else
-                n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(blocked));
-                n_out = WAVE - __popcll(__ballot(in_blas)) - int(n_dead);
-            } else {
-                at_leaf = in_blas && (WIDE == 8 ? (l0 | l1) != 0u : (cur & BVH2_PRIM_COUNT_BITS) != 0);
-                at_node = in_blas && !at_leaf;
-                n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf));
-                n_out = WAVE - n_node - n_leaf - int(n_dead);
-            }
+            // (the sentinel never stays in `cur`: leave_blas)
+            const bool at_leaf = in_blas && (WIDE == 8 ? (l0 | l1) != 0u : (cur & BVH2_PRIM_COUNT_BITS) != 0);
+            const bool at_node = in_blas && !at_leaf;
+            const int n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf));
+            const int n_out = WAVE - n_node - n_leaf - int(n_dead);
 #ifdef RT_PROFILE_TRACE
             st_a += n_node, st_b += n_leaf, st_iter += 1;
 #endif
@@ -539,27 +484,21 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                         }
                     } else {
                         bvh4_visit(sc.nodes4, o, inv_d, h.t, st, cur, tos, size);
-                        RT_PREFETCH_CUR()
-                        stash();
                     }
                     leave_blas();
                 }
                 RT_PROF_T(19)
             } else {
                 if (at_leaf) {
-                    const uint32_t word = WIDE == 8 ? bvh8_take_leaf(tri_base, l0, l1) : (POSTPONE ? pend : cur);
+                    const uint32_t word = WIDE == 8 ? bvh8_take_leaf(tri_base, l0, l1) : cur;
                     const int tri_start = int(word & BVH2_PRIM_INDEX_BITS), tri_end = int(tri_start + ((word & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
                     res |= intersect_tris_closest(o, d, tri_table(sc), tri_start, tri_end, int(mi_index), h);
                     if (WIDE == 8) {
                         if ((l0 | l1) == 0u && (cur_bits >> 8) == 0u) {
                             pop8();
                         }
-                    } else if (POSTPONE) {
-                        pend = 0u;
-                        stash(); // (a lane that stood at its next leaf puts that one aside now)
                     } else {
                         pop();
-                        RT_PREFETCH_CUR()
                     }
                     leave_blas();
                 }
@@ -709,7 +648,6 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                             cur = sc.blas_root4[mi];
                         }
                         lvl = BLAS;
-                        stash();      // (a BLAS whose root is a leaf)
                         leave_blas(); // (a BLAS whose root is the sentinel: nothing to walk)
                     } else {
                         pop();

@@ -36,19 +36,9 @@
 
 namespace rt {
 
-// RT_BVH4_TEST_FOLDED: the slab test with the error bound folded into the plane padding (1) or with a relative slack per child (0, rounds 1-2)
-#ifndef RT_BVH4_TEST_FOLDED
-#define RT_BVH4_TEST_FOLDED 1
-#endif
 
 #ifndef RT_BVH4_PINNED_FETCH
 #define RT_BVH4_PINNED_FETCH 1
-#endif
-#ifndef RT_BVH4_PACKED_FMA
-#define RT_BVH4_PACKED_FMA 0
-#endif
-#ifndef RT_BVH4_SGPR_CSWAP
-#define RT_BVH4_SGPR_CSWAP 0 // (measured neutral in the kernel: K2 1.94 against 1.92 ms; the microbenchmark's penalty does not show up in context)
 #endif
 
 struct alignas(16) Bvh4Node {
@@ -75,13 +65,15 @@ RT_HD float bvh4_dequant(const uint32_t q, const float scale, const float org) {
 // byte-to-float conversion and one fma per plane instead of de-quantise, subtract, multiply, and the sign of inv_d_a says
 // which of (qlo, qhi) is the entry plane -- no min / max per axis.  The box test only CULLS, so it does not have to be the
 // reference's arithmetic, it has to be CONSERVATIVE against it: whenever the reference's bbox_test (rt_isect.h) accepts the
-// exact fp32 child box, this test accepts the quantised box that contains it.  Error budget (eps = 2^-24):
-//   * base_a = fl(fl(org_a - o_a) * inv_d_a): relative 2 eps;  step_a * inv_d_a: exact (step is a power of two);  the fma:
-//     relative eps of its result  ->  |computed - real| <= (3 |base_a| + 255 |k_a|) eps  <  E_a = (|base_a| + 255 |k_a|) 2^-22.
-//     Entry planes are moved back by E_a, exit planes forward (folded into the fma's addend: one more rounding of the same
-//     size, inside the same bound);
-//   * the reference's own result is within relative 3 eps of the real value for ITS box and it multiplies tmax by 1 + 2^-22
-//     (rt_isect.h: bbox_test); the final tmin / tmax here get a relative slack of 2^-21 = 8 eps;
+// exact fp32 child box, this test accepts the quantised box that contains it.  Error budget (eps = 2^-24, M_a = |base_a| + 255 |k_a|:
+// every plane of the node's grid is crossed at a |t| <= M_a):
+//   * base_a = fl(fl(org_a - o_a) * inv_d_a): two roundings;  step_a * inv_d_a: exact (step is a power of two);  the fma: one;  the
+//     padding folded into the addend: one more  ->  |computed - real plane parameter| <= 4 eps M_a;
+//   * the reference's own value is within 3 eps M_a of the real one for ITS plane, and it stretches tmax by 1 + 2^-22 (4 eps)
+//     (rt_isect.h: bbox_test);
+//   => entry planes moved back / exit planes moved forward by E_a = 2^-20 M_a = 16 eps M_a cover both sides (7 and 11 eps) with
+//      room to spare; no relative slack on tmin / tmax afterwards (rounds 1-2 used 2^-22 M_a plus a slack of 2^-21: two fma and two
+//      compares more per child);
 //   * the quantised box contains the child box in REAL arithmetic (bvh4_build.h checks org + q * step in double).
 // Checked by the bit-exact frame / hit tests of the wide walk against the BVH2 walk and the oracle.
 RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 ro, const f3 inv_d, const float t, uint32_t ref[4],
@@ -105,16 +97,6 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
 #endif
     RT_PROF_WAIT(w0, w1, w2, w3)
     RT_PROF_T(17)
-#if defined(RT_EXPERIMENT_DUMMY_VALU) && defined(__HIP_DEVICE_COMPILE__)
-    // tuning experiment: RT_EXPERIMENT_DUMMY_VALU extra full-rate vector instructions per node visit -- does the kernel's time follow
-    // its instruction count (bound by vector-ALU issue) or not (bound by latency)?
-    float dummy_ = t;
-#pragma unroll
-    for (int k_ = 0; k_ < RT_EXPERIMENT_DUMMY_VALU; ++k_) {
-        asm volatile("v_mul_f32 %0, %0, %0" : "+v"(dummy_));
-    }
-    asm volatile("" ::"v"(dummy_));
-#endif
     const float step[3] = {w0.w, w3.z, w3.w};
     const uint32_t child[4] = {float_as_uint(w1.x), float_as_uint(w1.y), float_as_uint(w1.z), float_as_uint(w1.w)};
 
@@ -127,69 +109,33 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
     for (int a = 0; a < 3; ++a) {
         k[a] = step[a] * id[a];
         const float base = (org[a] - o[a]) * id[a];
-#if RT_BVH4_TEST_FOLDED
         const float err = __builtin_fmaf(255.0f, fabsf(k[a]), fabsf(base)) * 9.5367431640625e-07f; // 2^-20: covers both sides' roundings (rt_bvh8.h)
-#else
-        const float err = __builtin_fmaf(255.0f, fabsf(k[a]), fabsf(base)) * 2.384185791015625e-07f; // 2^-22
-#endif
         base_in[a] = base - err, base_out[a] = base + err;
         const bool forward = id[a] >= 0.0f;
         q_in[a] = forward ? qlo_w[a] : qhi_w[a], q_out[a] = forward ? qhi_w[a] : qlo_w[a];
     }
 
-    const float none = 3.402823466e+38f, slack = 4.76837158203125e-07f; // 2^-21
+    const float none = 3.402823466e+38f;
     float dist[4];
     n_hit = 0;
     for (int c = 0; c < 4; ++c) {
         const int sh = 8 * c;
         float t_in[3], t_out[3];
         for (int a = 0; a < 3; ++a) {
-#if defined(__HIP_DEVICE_COMPILE__) && RT_BVH4_PACKED_FMA
-            // entry and exit plane of an axis in one v_pk_fma_f32 (two fma for the issue slot of one: tools/valu_bench.hip)
-            typedef float f2v __attribute__((ext_vector_type(2)));
-            const f2v q2 = {float((q_in[a] >> sh) & 0xffu), float((q_out[a] >> sh) & 0xffu)};
-            const f2v t2 = __builtin_elementwise_fma(q2, f2v{k[a], k[a]}, f2v{base_in[a], base_out[a]});
-            t_in[a] = t2.x, t_out[a] = t2.y;
-#else
             t_in[a] = __builtin_fmaf(float((q_in[a] >> sh) & 0xffu), k[a], base_in[a]);
             t_out[a] = __builtin_fmaf(float((q_out[a] >> sh) & 0xffu), k[a], base_out[a]);
-#endif
         }
-#if RT_BVH4_TEST_FOLDED
         // the whole error budget sits in the padding of the planes (2^-20 M_a per plane, derivation in rt_bvh8.h: the same grid, the
         // same arithmetic): no relative slack afterwards, and  max(tmin, 0) <= min(tmax, t)  -- implied by the reference's
-        // tmin <= tmax && tmin <= t && tmax > 0 -- is two 3-operand min / max and one compare instead of two fma and three compares
+        // tmin <= tmax && tmin <= t && tmax > 0 -- is two 3-operand min / max and one compare (rounds 1-2: a relative slack of
+        // 2^-21 on tmin / tmax, two fma and three compares per child)
         const float tmin = fmaxf(fmaxf(fmaxf(t_in[0], t_in[1]), t_in[2]), 0.0f), tmax = fminf(fminf(fminf(t_out[0], t_out[1]), t_out[2]), t);
         const bool hit = tmin <= tmax && child[c] != BVH4_EMPTY;
-        (void)slack;
-#else
-        const float tmin = fmaxf(fmaxf(t_in[0], t_in[1]), t_in[2]), tmax = fminf(fminf(t_out[0], t_out[1]), t_out[2]);
-        const float tmin_c = __builtin_fmaf(-fabsf(tmin), slack, tmin), tmax_c = __builtin_fmaf(fabsf(tmax), slack, tmax);
-        const bool hit = tmin_c <= tmax_c && tmin_c <= t && tmax_c > 0.0f && child[c] != BVH4_EMPTY;
-#endif
         dist[c] = hit ? tmin : none;
         ref[c] = child[c];
         n_hit += hit ? 1u : 0u;
     }
     // sorting network on (dist, ref), ascending: (0,1) (2,3) (0,2) (1,3) (1,2); children that were not hit sort last
-#if defined(__HIP_DEVICE_COMPILE__) && RT_BVH4_SGPR_CSWAP
-    // The compare-and-swap with its lane mask in an SGPR pair.  Left to the compiler it becomes v_cmp (vcc), s_nop, 4 x v_cndmask_b32_e32
-    // reading vcc -- and on gfx950 a VOP2 v_cndmask that does not IMMEDIATELY follow the write of vcc occupies the SIMD for ~24 cycles
-    // instead of 4 (tools/valu_bench.hip: "cswap: vcc + nop + 4 cnd" 14-16 cycles per instruction against 3.6-3.9 with the mask in
-    // an SGPR pair): ~75 against ~19 cycles per compare-and-swap, five of them per node visit.  (s_nop 1: two wait states between a
-    // VALU write of an SGPR and a VALU read of it.)
-#define RT_CSWAP(a, b)                                                                                                  \
-    {                                                                                                                   \
-        float da_, db_;                                                                                                 \
-        uint32_t ra_, rb_;                                                                                              \
-        unsigned long long m_;                                                                                          \
-        asm("v_cmp_lt_f32_e64 %4, %6, %5\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %5, %6, %4\n\tv_cndmask_b32_e64 %1, %6, %5, %4\n\t"                    \
-            "v_cndmask_b32_e64 %2, %7, %8, %4\n\tv_cndmask_b32_e64 %3, %8, %7, %4"                                       \
-            : "=&v"(da_), "=&v"(db_), "=&v"(ra_), "=&v"(rb_), "=&s"(m_)                                                 \
-            : "v"(dist[a]), "v"(dist[b]), "v"(ref[a]), "v"(ref[b]));                                                   \
-        dist[a] = da_, dist[b] = db_, ref[a] = ra_, ref[b] = rb_;                                                       \
-    }
-#else
 #define RT_CSWAP(a, b)                                                                                                  \
     {                                                                                                                   \
         const bool sw = dist[b] < dist[a];                                                                              \
@@ -197,7 +143,6 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
         const uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];                                            \
         dist[a] = da, dist[b] = db, ref[a] = ra, ref[b] = rb;                                                           \
     }
-#endif
     RT_CSWAP(0, 1)
     RT_CSWAP(2, 3)
     RT_CSWAP(0, 2)
