@@ -88,6 +88,12 @@ def test_bench_roofline_traffic_lookup():
     assert "stale" in exact and exact["profiled_csrc_hash"] == runs[0].get("csrc_hash")
     assert exact["stale"] == (exact["profiled_csrc_hash"] != bench.csrc_hash())
     assert bench.measured_traffic("no_such_workload", 20, 20, 1) is None
+    # the third profile (round 3): vector instructions per launch and the lanes they ran with -- the kernel's binding resource
+    if "valu_wave_instructions_per_launch" in runs[0]:
+        assert exact["valu_wave_instructions_per_launch"] > 1e6 and 1.0 <= exact["valu_active_lanes"] <= 64.0
+        rate = exact["valu_wave_instructions_per_launch"] / (exact["profiled_avg_launch_ms"] * 1e-3)
+        assert 0.2e12 < rate < 1.2e12  # (between a fifth of the half-rate class's peak and the full-rate class's: tools/valu_bench.hip)
+        assert abs(rank["valu_wave_instructions_per_launch"] * 8 - exact["valu_wave_instructions_per_launch"]) < 1.0
 
 
 def build_c_host(tmp_path):
