@@ -719,7 +719,10 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_shadow(const SceneView sc,
 // (CoreRef.cpp:4847-4849).  Only launched when the scene has visible lights.
 __global__ void __launch_bounds__(WAVE) k_intersect_area_lights(const SceneView sc, const RaySoA rays, const HitSoA hits,
                                                                const RayQueue queue) {
+    __shared__ uint32_t lds_light_stack[LIGHT_STACK_LDS_WORDS]; // 36 KiB: (index, distance, factor) x 48 entries x 64 lanes, depth-major
     const uint32_t lane = threadIdx.x;
+    LightStackT<LightStackLds> st;
+    st.s.lane_base = &lds_light_stack[lane];
     const uint32_t n_live_chunks = queue.live_chunks();
     ChunkWalk walk(n_live_chunks);
     for (uint32_t c; walk.next(c);) {
@@ -733,7 +736,7 @@ __global__ void __launch_bounds__(WAVE) k_intersect_area_lights(const SceneView 
         const uint32_t depth = rays.xy_depth[i].y;
         Hit h = load_hit(hits, i);
         const Hit before = h;
-        intersect_area_lights(sc, r.o, r.d, depth, h);
+        intersect_area_lights(sc, r.o, r.d, depth, h, st);
         if (h.obj_index != before.obj_index || h.t != before.t || h.u != before.u || h.v != before.v) {
             store_hit(hits, i, h);
         }
@@ -744,7 +747,10 @@ __global__ void __launch_bounds__(WAVE) k_intersect_area_lights(const SceneView 
 // applied to the ray's throughput BEFORE K3 instead of to K3's result: a blocked ray carries c = 0 through the
 // any-hit walk and adds 0 to its pixel, bit for bit what the reference adds.
 __global__ void __launch_bounds__(WAVE) k_shadow_blockers(const SceneView sc, const ShadowSoA shadow, const RayQueue queue) {
+    __shared__ uint32_t lds_light_stack[LIGHT_STACK_LDS_WORDS];
     const uint32_t lane = threadIdx.x;
+    LightStackT<LightStackLds> st;
+    st.s.lane_base = &lds_light_stack[lane];
     const uint32_t n_live_chunks = queue.live_chunks();
     ChunkWalk walk(n_live_chunks);
     for (uint32_t c; walk.next(c);) {
@@ -754,7 +760,7 @@ __global__ void __launch_bounds__(WAVE) k_shadow_blockers(const SceneView sc, co
         }
         const uint32_t i = slot0 + lane;
         const ShadowRay r = load_shadow(shadow, i);
-        if (intersect_area_lights_shadow(sc, r) == 0.0f) {
+        if (intersect_area_lights_shadow(sc, r, st) == 0.0f) {
             float4 cx = shadow.c_xy[i];
             cx.x = cx.y = cx.z = 0.0f;
             shadow.c_xy[i] = cx;

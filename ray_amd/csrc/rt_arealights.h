@@ -12,8 +12,8 @@
 //   bbox_test_oct(cwbvh_node_t)   CoreRef.cpp:393-477      TraversalStack::sort_top3/4/N   CoreRef.cpp:508-590
 //   quadratic                     CoreRef.cpp:750-764
 //
-// The per-ray stack is a private array (scratch memory on the GPU): light trees are 8-wide and a few levels deep,
-// and this kernel only runs when the scene has visible / blocker analytic lights.
+// The per-ray stack lives in LDS in the kernels (LightStackLds, round 3; a private array before: scratch memory) and in a plain
+// array on the host build; this stage only runs when the scene has visible / blocker analytic lights.
 #pragma once
 
 #include "shade_lights.h"
@@ -27,63 +27,85 @@ struct LightStackEntry {
     float factor;
 };
 
-struct LightStack {
+// Where the entries live.  Private: an array of the caller (the host build; scratch memory if a kernel used it).  Lds: three
+// depth-major planes of the wavefront's shared memory, plane[depth][lane] -- bank == lane at any mix of depths, conflict-free,
+// the layout of the traversal stacks (kernels.hip.h); the reference's shader keeps the same 48 entries per invocation in
+// shared memory (shaders/intersect_area_lights.comp.glsl:52-53).
+struct LightStackPrivate {
     LightStackEntry e[MAX_STACK_SIZE];
+    RT_HD LightStackEntry get(const uint32_t i) const { return e[i]; }
+    RT_HD void set(const uint32_t i, const LightStackEntry &v) { e[i] = v; }
+    RT_HD float dist(const uint32_t i) const { return e[i].dist; }
+};
+constexpr int LIGHT_STACK_LDS_WORDS = 3 * MAX_STACK_SIZE * 64; // per wavefront
+struct LightStackLds {
+    uint32_t *lane_base; // &planes[0][0][lane]
+    RT_HD LightStackEntry get(const uint32_t i) const {
+        return LightStackEntry{lane_base[i * 64u], uint_as_float(lane_base[(MAX_STACK_SIZE + i) * 64u]), uint_as_float(lane_base[(2 * MAX_STACK_SIZE + i) * 64u])};
+    }
+    RT_HD void set(const uint32_t i, const LightStackEntry &v) {
+        lane_base[i * 64u] = v.index, lane_base[(MAX_STACK_SIZE + i) * 64u] = float_as_uint(v.dist), lane_base[(2 * MAX_STACK_SIZE + i) * 64u] = float_as_uint(v.factor);
+    }
+    RT_HD float dist(const uint32_t i) const { return uint_as_float(lane_base[(MAX_STACK_SIZE + i) * 64u]); }
+};
+
+template <class Store> struct LightStackT {
+    Store s;
     uint32_t size = 0;
     RT_HD void push(uint32_t index, float dist, float factor) {
         if (size < uint32_t(MAX_STACK_SIZE)) { // (the reference asserts)
-            e[size] = LightStackEntry{index, dist, factor};
+            s.set(size, LightStackEntry{index, dist, factor});
         }
         ++size;
     }
     RT_HD LightStackEntry pop() {
         --size;
-        return size < uint32_t(MAX_STACK_SIZE) ? e[size] : LightStackEntry{0u, 3.402823466e+38f, 0.0f}; // overflowed entries are dropped
+        return size < uint32_t(MAX_STACK_SIZE) ? s.get(size) : LightStackEntry{0u, 3.402823466e+38f, 0.0f}; // overflowed entries are dropped
     }
     RT_HD void swap(uint32_t a, uint32_t b) {
-        const LightStackEntry t = e[a];
-        e[a] = e[b];
-        e[b] = t;
+        const LightStackEntry t = s.get(a);
+        s.set(a, s.get(b));
+        s.set(b, t);
     }
     // order the three topmost entries by descending distance (nearest is popped first); same decision tree, i.e.
     // same result for equal distances, as TraversalStack::sort_top3
     RT_HD void sort_top3() {
         const uint32_t i = size - 3;
-        const LightStackEntry a = e[i], b = e[i + 1], c = e[i + 2];
+        const LightStackEntry a = s.get(i), b = s.get(i + 1), c = s.get(i + 2);
         if (a.dist > b.dist) {
             if (b.dist > c.dist) {
                 // a b c
             } else if (a.dist > c.dist) {
-                e[i + 1] = c, e[i + 2] = b; // a c b
+                s.set(i + 1, c), s.set(i + 2, b); // a c b
             } else {
-                e[i] = c, e[i + 1] = a, e[i + 2] = b; // c a b
+                s.set(i, c), s.set(i + 1, a), s.set(i + 2, b); // c a b
             }
         } else {
             if (a.dist > c.dist) {
-                e[i] = b, e[i + 1] = a; // b a c
+                s.set(i, b), s.set(i + 1, a); // b a c
             } else if (c.dist > b.dist) {
-                e[i] = c, e[i + 2] = a; // c b a
+                s.set(i, c), s.set(i + 2, a); // c b a
             } else {
-                e[i] = b, e[i + 1] = c, e[i + 2] = a; // b c a
+                s.set(i, b), s.set(i + 1, c), s.set(i + 2, a); // b c a
             }
         }
     }
     // five compare-exchanges: (0,1) (2,3) (0,2) (1,3) (1,2)
     RT_HD void sort_top4() {
         const uint32_t i = size - 4;
-        if (e[i + 0].dist < e[i + 1].dist) {
+        if (s.dist(i + 0) < s.dist(i + 1)) {
             swap(i + 0, i + 1);
         }
-        if (e[i + 2].dist < e[i + 3].dist) {
+        if (s.dist(i + 2) < s.dist(i + 3)) {
             swap(i + 2, i + 3);
         }
-        if (e[i + 0].dist < e[i + 2].dist) {
+        if (s.dist(i + 0) < s.dist(i + 2)) {
             swap(i + 0, i + 2);
         }
-        if (e[i + 1].dist < e[i + 3].dist) {
+        if (s.dist(i + 1) < s.dist(i + 3)) {
             swap(i + 1, i + 3);
         }
-        if (e[i + 1].dist < e[i + 2].dist) {
+        if (s.dist(i + 1) < s.dist(i + 2)) {
             swap(i + 1, i + 2);
         }
     }
@@ -91,16 +113,17 @@ struct LightStack {
     RT_HD void sort_topN(const int count) {
         const int start = int(size) - count;
         for (int i = start + 1; i < int(size); ++i) {
-            const LightStackEntry key = e[i];
+            const LightStackEntry key = s.get(uint32_t(i));
             int j = i - 1;
-            while (j >= start && e[j].dist < key.dist) {
-                e[j + 1] = e[j];
+            while (j >= start && s.dist(uint32_t(j)) < key.dist) {
+                s.set(uint32_t(j + 1), s.get(uint32_t(j)));
                 --j;
             }
-            e[j + 1] = key;
+            s.set(uint32_t(j + 1), key);
         }
     }
 };
+typedef LightStackT<LightStackPrivate> LightStack;
 
 // slab test of the eight quantised child boxes; bit i of the result = child i is hit within [0, t]
 RT_HD uint32_t bbox_test_oct(const f3 o, const f3 inv_d, const float t, const rayhip_light_cwbvh_node &n, float out_dist[8]) {
@@ -143,8 +166,9 @@ RT_HD bool quadratic(const float a, const float b, const float c, float &t0, flo
 
 // Push the children selected by `mask` the way all of the reference's 8-wide walks do (1 hit: descend; 2: nearer
 // first; 3, 4, 5+: push all, sort the top, pop).  Returns false when no child was hit.
+template <class Stack>
 RT_HD bool light_tree_descend(const rayhip_light_cwbvh_node &n, uint32_t mask, const float dist[8], const float factors[8],
-                              LightStack &st, LightStackEntry &cur) {
+                              Stack &st, LightStackEntry &cur) {
     if (mask == 0) {
         return false;
     }
@@ -200,11 +224,13 @@ RT_HD bool light_tree_descend(const rayhip_light_cwbvh_node &n, uint32_t mask, c
 }
 
 // CoreRef.cpp:3616-3860
-RT_HD void intersect_area_lights(const SceneView &sc, const f3 ro, const f3 rd, const uint32_t ray_depth, Hit &inter) {
+// (`st`: an empty stack -- LightStack on the host, LightStackT<LightStackLds> in the kernel)
+template <class Stack>
+RT_HD void intersect_area_lights(const SceneView &sc, const f3 ro, const f3 rd, const uint32_t ray_depth, Hit &inter, Stack &st) {
     const uint32_t ray_flags = (1u << get_ray_type(ray_depth));
     const f3 inv_d = safe_invert(rd);
 
-    LightStack st;
+    st.size = 0;
     st.push(0u, 0.0f, 1.0f);
 
     while (st.size != 0) {
@@ -360,13 +386,14 @@ RT_HD void intersect_area_lights(const SceneView &sc, const f3 ro, const f3 rd, 
 }
 
 // CoreRef.cpp:4451-4592: 0 if a rect / disk blocker light lies between the shadow ray's ends, else 1
-RT_HD float intersect_area_lights_shadow(const SceneView &sc, const ShadowRay &r) {
+template <class Stack>
+RT_HD float intersect_area_lights_shadow(const SceneView &sc, const ShadowRay &r, Stack &st) {
     const float rdist = fabsf(r.dist);
     const f3 ro = r.o, rd = r.d;
     const f3 inv_d = safe_invert(rd);
     const float ones[8] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
 
-    LightStack st;
+    st.size = 0;
     st.push(0u, 0.0f, 1.0f);
 
     while (st.size != 0) {

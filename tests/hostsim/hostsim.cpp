@@ -475,7 +475,8 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
                 }
                 // K4 (TraceRays(..., trace_lights = true), CoreRef.cpp:4847-4849)
                 if (c->sc.visible_lights_count != 0) {
-                    intersect_area_lights(c->sc, rays[i].o, rays[i].d, rays[i].depth, hits[i]);
+                    LightStack lst;
+                    intersect_area_lights(c->sc, rays[i].o, rays[i].d, rays[i].depth, hits[i], lst);
                 }
             }
         }
@@ -508,7 +509,8 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
                 add_counters(c->counters[1], tc);
             }
             if (c->sc.blocker_lights_count != 0) { // CoreRef.cpp:4868-4870
-                rc *= intersect_area_lights_shadow(c->sc, shadow[i]);
+                LightStack lst;
+                rc *= intersect_area_lights_shadow(c->sc, shadow[i], lst);
             }
             add_shadow_pixel(rc, limit, shadow[i].xy, w, c->temp.data());
         }
