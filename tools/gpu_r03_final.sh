@@ -11,7 +11,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20_warmup5.j
 timeout 600 python bench.py --steps 64 --warmup 64 > $OUT/bench_steps64_warmup64.json 2> $OUT/bench_steps64.err; echo "bench64 exit $?"
 for f in bench_steps20_warmup5 bench_steps64_warmup64; do python3 -c "
 import json; d=json.load(open('$OUT/$f.json')); print('$f', round(d['value'],1), 'Msamples/s', round(d['ms_per_step'],3), 'ms/spp', {k: round(v) for k,v in d['stage_us_per_step'].items()}, 'cpu', (d.get('cpu_baseline') or {}).get('value'), 'parity', (d.get('parity') or {}).get('pass'))"; done
-timeout 1500 python -m pytest tests -m gpu -q --durations=8 > $OUT/gputest_final.log 2>&1
+timeout 600 python -m pytest tests -m gpu -q --durations=8 > $OUT/gputest_final.log 2>&1
 echo "pytest exit $?"; grep "passed\|failed" $OUT/gputest_final.log | tail -2
 cd /tmp
 for cfg in "20 5" "64 64"; do
@@ -42,7 +42,7 @@ for w in bistro_tex sponza cornell principled; do
   python3 -c "
 import json; d=json.load(open('$OUT/bench_${w}_steps64_warmup64.json')); print('$w', round(d['value'],1), 'Msamples/s')"
 done
-timeout 900 python tools/shard_emulation.py bistro 64 20 > $OUT/shard_emulation.txt 2>&1; tail -12 $OUT/shard_emulation.txt
+timeout 200 python tools/shard_emulation.py bistro 64 20 > $OUT/shard_emulation.txt 2>&1; tail -12 $OUT/shard_emulation.txt
 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_2ranks_emulated_steps20.json 2> $OUT/b2.err; echo "2 ranks exit $?"
 timeout 300 tools/_build/valu_bench > $OUT/valu_bench.txt 2>&1
 find $OUT -name '*.csv' -size +6M -delete; find $OUT -name '*.db' -delete
