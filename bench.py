@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the HIP path-tracer core loop on N MI355X (BASELINE.json metric), one JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bistro|sponza|cornell|principled]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp S] [--workload bistro|sponza|cornell|principled]
 
-A "step" is ONE RenderScene iteration (one sample per pixel over the whole frame: ray gen -> trace -> shade ->
-shadow -> [trace -> shade -> shadow] x bounces -> accumulate).  K steps = K spp.  Msamples/s = W*H*K / time.
+A "step" is ONE FRAME of the BASELINE configuration: Clear, S = 64 samples per pixel over the whole frame (RenderScene
+iterations 1..S: ray gen -> trace -> shade -> shadow -> [trace -> shade -> shadow] x bounces -> accumulate; the iterations of a
+frame go through the device as one layered pass), and the finished frame leaving the GPU (N = 1: read-back
+to the host; N > 1: the exchange that assembles it on rank 0).  K steps = K frames of S spp.  Msamples/s = W*H*S*K / time.
+(Rounds 1-3 called one iteration a step, so the driver's `--steps 20` timed a 20-spp frame; since round 4 the driver's
+command times twenty 64-spp frames -- the configuration BASELINE.json quotes the metric on.)
 
 Workloads (BASELINE.json configs; no real Sponza/Bistro asset exists offline, see ray_amd/scenes.py):
   bistro      default.  synthetic atrium, ~3.0 M triangles, 1920x1080   (config 4: the scene the metric is quoted on)
@@ -21,15 +25,16 @@ time is reported separately (`exchange_ms`).  Total work is fixed -> "scaling": 
 (a 1-GPU box) the ranks share devices and the packed tiles travel through host memory over gloo -- RCCL cannot put two
 ranks on one device -- and the line says `"emulated_ranks": true`: a plumbing check, not a scaling measurement.
 
-Timed region: barrier + stream sync | K iterations (+ the reduce at N>1) | stream sync + barrier; max over ranks.
-Inputs (scene, PMJ table) are resident in HBM before the region starts; nothing is copied to the host inside it.
+Timed region: barrier + stream sync | K frames (each: clear, S iterations, read-back or exchange) | stream sync + barrier; max
+over ranks.  Inputs (scene, PMJ table) are resident in HBM before the region starts; the only host traffic inside it is the
+finished frame (33 MB once per frame at 1080p).
 
 roofline (dominant kernel: the closest-hit traversal K2 -- the persistent kernel k_trace_closest_refill, lane-by-lane refill
 for the secondary bounces, whole chunks for the primary rays; "a launch" is a launch of either).  Its launches are bracketed by HIP
 events on the context stream during the timed region (RAYHIP_FLAG_TIME_STAGES, no synchronisation).  Three byte counts,
 all per launch:
   traffic      HBM bytes that actually moved: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE of this kernel, from a profiled run of
-               THIS command line (profiles/r03/k2_traffic.json, keyed by workload / steps / iterations per pass; written by
+               THIS command line (profiles/r04/k2_traffic.json, keyed by workload / spp / iterations per pass; written by
                tools/k2_traffic.py from the rocprofv3 output and stamped with a hash of ray_amd/csrc); for another pass size
                or N > 1 the profiled run of the same workload with the nearest pass size, scaled by rays per launch
                (traffic_detail.exact = false says so); traffic_detail.stale = true when the kernel sources changed since the
@@ -122,14 +127,14 @@ def csrc_hash():
 
 
 def traffic_table_path():
-    for r in ("r03", "r02"):
+    for r in ("r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", r, "k2_traffic.json")
         if os.path.exists(p):
             return p
-    return os.path.join(ROOT, "profiles", "r03", "k2_traffic.json")
+    return os.path.join(ROOT, "profiles", "r04", "k2_traffic.json")
 
 
-def measured_traffic(workload, steps, batch, world=1):
+def measured_traffic(workload, spp, batch, world=1):
     """HBM bytes per K2 launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 PMC passes (profiles/r02/k2_traffic.json,
     written by tools/k2_traffic.py).  Exact when this very command line was profiled (same workload, steps, iterations per
     pass, one GPU); otherwise SCALED from the profiled run of the same workload with the nearest pass size -- K2's traffic
@@ -141,7 +146,9 @@ def measured_traffic(workload, steps, batch, world=1):
         runs = [e for e in table.get("runs", []) if e["workload"] == workload]
         if not runs:
             return None
-        exact = [e for e in runs if world == 1 and e["steps"] == steps and e["iterations_per_pass"] == batch]
+        # (a launch of a 64-layer pass is the same launch whatever the number of frames: the key is the shape of the pass.  Entries of
+        # rounds 2-3 have no "spp": their frame was `steps` iterations long)
+        exact = [e for e in runs if world == 1 and e.get("spp", e["steps"]) == spp and e["iterations_per_pass"] == batch]
         e = exact[0] if exact else min(runs, key=lambda r: abs(r["iterations_per_pass"] - batch))
         k = 1.0 if exact else (batch / e["iterations_per_pass"]) / world
         out = {"bytes_per_launch": float(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]) * k,
@@ -156,7 +163,7 @@ def measured_traffic(workload, steps, batch, world=1):
             out["valu_active_lanes"] = e.get("valu_active_lanes")
         if not exact:
             out["scaled_by"] = k
-            out["scaled_from"] = {"steps": e["steps"], "iterations_per_pass": e["iterations_per_pass"], "n_gpus": 1}
+            out["scaled_from"] = {"spp": e.get("spp", e["steps"]), "iterations_per_pass": e["iterations_per_pass"], "n_gpus": 1}
         return out
     except (OSError, ValueError, KeyError, ZeroDivisionError):
         pass
@@ -250,8 +257,9 @@ def parity_check(ctx, wl):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=480)  # 4 passes of 120 iterations on one GPU, 1 pass of 480 on each of 8
-    ap.add_argument("--warmup", type=int, default=120)  # one full pass of 120 iterations (1080p), the shape of the timed passes
+    ap.add_argument("--steps", type=int, default=8)   # frames of --spp samples per pixel (8 x 0.2 s at 1080p / 64 spp on one GPU)
+    ap.add_argument("--warmup", type=int, default=2)  # frames, untimed
+    ap.add_argument("--spp", type=int, default=64)    # samples per pixel of a frame: BASELINE.json quotes the metric at 64
     ap.add_argument("--workload", default=os.environ.get("RAY_AMD_WORKLOAD", "bistro"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -314,7 +322,7 @@ def main():
     from ray_amd import api, hip, multigpu
 
     wl = WORKLOADS[args.workload]
-    W, H, K, Wm = wl["w"], wl["h"], args.steps, args.warmup
+    W, H, K, Wm, SPP = wl["w"], wl["h"], args.steps, args.warmup, max(1, args.spp)
     blob, info = get_scene_blob(args.workload, wl, rank, world, barrier)
 
     ctx = hip.Context(local_rank)
@@ -333,7 +341,7 @@ def main():
         if dist is not None:
             multigpu.exchange_frame(ctx, rank, world, comm=comm, dist=dist, what=hip.REDUCE_RADIANCE, via_host=emulated)
 
-    batch = int(os.environ.get("RAY_AMD_BATCH", "0")) or multigpu.batch_size(W * H // world, ctx.max_batch(), K)
+    batch = int(os.environ.get("RAY_AMD_BATCH", "0")) or multigpu.batch_size(W * H // world, ctx.max_batch(), SPP)
     ctx.reserve_batch(batch)  # (the shard is set: a rank's buffers are sized for its share of the frame)
     # Host memory the HIP runtime pinned for a copy (the scene blob, the PMJ table, a read-back frame) must not be unmapped
     # while the GPU works: the kernel driver answers the unmap by stopping and restarting this process's GPU queues, and the
@@ -349,78 +357,75 @@ def main():
         host_frame.fill(0.0)
     gc.collect()
     gc.disable()
-    it = 0
-    # set-up, not warm-up: one pass of exactly the shape and flags of the timed passes, so that nothing in the timed region
+    t_render = t_out = 0.0
+
+    def render_frame(flags, timed=False):
+        """one step: Clear, iterations 1..SPP of this rank's tiles, the finished frame out of the GPU (read-back / exchange)"""
+        nonlocal t_render, t_out
+        ta = time.perf_counter()
+        ctx.clear()
+        multigpu.render_sharded(ctx, range(1, SPP + 1), rank, world, dist=None, frame=None, flags=flags, tile=TILE, batch=batch)
+        ctx.sync()
+        tb = time.perf_counter()
+        if dist is None:  # what the exchange is at N > 1: the finished frame leaves the GPU once per image (SURVEY 8d)
+            ctx.readback(hip.BUF_RAW, out=host_frame)
+        else:
+            exchange()
+        ctx.sync()
+        if timed:
+            t_render, t_out = t_render + (tb - ta), t_out + (time.perf_counter() - tb)
+            ctx.stage_times(reset=False)  # (resolves this frame's stage events into the running sums: the event pool stays small)
+
+    # set-up, not warm-up: one frame of exactly the shape and flags of the timed ones, so that nothing in the timed region
     # is the first of its kind in this process (measured: the first timed pass of the first process on a fresh box spent
     # 15-30 ms before its first kernel finished when the warm-up passes were shorter than the timed ones)
-    ctx.render_batch(it + 1, batch, flags=hip.FLAG_TIME_STAGES)
-    it += batch
-    ctx.sync()
-    if Wm > 0:  # the W untimed warm-up steps
-        done = 0
-        while done < Wm:
-            n = min(batch, Wm - done)
-            ctx.render_batch(it + 1, n)
-            it, done = it + n, done + n
-    exchange()  # warm the communicator too
-    ctx.sync()
+    render_frame(hip.FLAG_TIME_STAGES)
+    for _ in range(Wm):  # the W untimed warm-up steps
+        render_frame(0)
+    torch.cuda.synchronize()
     ctx.trav_timing(reset=True)
     ctx.stage_times(reset=True)
 
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # K iterations of this rank's tiles + (N>1) the one exchange step of the path: the frame reduce over RCCL/xGMI
-    multigpu.render_sharded(ctx, range(it + 1, it + 1 + K), rank, world, dist=None, frame=None,
-                            flags=hip.FLAG_TIME_STAGES, tile=TILE, batch=batch)
-    it += K
-    ctx.sync()
-    t_rendered = time.perf_counter()
-    if dist is None:  # what the exchange is at N > 1: the finished frame leaves the GPU once per image
-        ctx.readback(hip.BUF_RAW, out=host_frame)
-    t_readback = time.perf_counter()
-    exchange()
-    ctx.sync()
+    for _ in range(K):
+        render_frame(hip.FLAG_TIME_STAGES, timed=True)
     torch.cuda.synchronize()
-    t_exchanged = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
     del blob
+    it = SPP
     rank_times = None
     if dist is not None:
         # (after the timed region) every rank's own render time and the exchange as rank 0 saw it -- the wait for the
         # slowest rank included -- and the maximum of the region over the ranks
-        mine = [dt, t_rendered - t0, t_exchanged - t_rendered]
+        mine = [dt, t_render, t_out]
         every = [None] * world
         dist.all_gather_object(every, mine)
         dt = max(e[0] for e in every)
-        rank_times = {"render_ms": [round(e[1] * 1e3, 3) for e in every], "exchange_ms_rank0": round(every[0][2] * 1e3, 3)}
+        rank_times = {"render_ms": [round(e[1] * 1e3 / K, 3) for e in every], "exchange_ms_rank0": round(every[0][2] * 1e3 / K, 3)}
 
     (k2_ms, k2_launches), (k3_ms, k3_launches) = ctx.trav_timing(reset=True)
     stages = ctx.stage_times(reset=True)
-    for rep in range(int(os.environ.get("RAY_AMD_BENCH_REPEAT", "0"))):  # diagnostics: the same warm-up + timed sequence again
-        if Wm > 0:
-            ctx.render_batch(it + 1, min(batch, Wm))
-            it += min(batch, Wm)
-        ctx.sync()
+    for rep in range(int(os.environ.get("RAY_AMD_BENCH_REPEAT", "0"))):  # diagnostics: the same timed sequence again
         ctx.stage_times(reset=True)
         torch.cuda.synchronize()
         t_rep = time.perf_counter()
-        multigpu.render_sharded(ctx, range(it + 1, it + 1 + K), rank, world, dist=None, frame=None, flags=hip.FLAG_TIME_STAGES, tile=TILE, batch=batch)
-        it += K
-        ctx.readback(hip.BUF_RAW, out=host_frame)
+        for _ in range(K):
+            render_frame(hip.FLAG_TIME_STAGES)
         ctx.sync()
         st_rep = ctx.stage_times(reset=True)
         ctx.trav_timing(reset=True)
-        print(f"repeat {rep}: {W * H * K / (time.perf_counter() - t_rep) / 1e6:.1f} Msamples/s, ray gen {st_rep['primary_ray_gen'] / K:.0f} us/step, "
-              f"primary trace {st_rep['primary_trace'] / K:.0f} us/step (first timed region of this process: {W * H * K / dt / 1e6:.1f}, "
+        print(f"repeat {rep}: {W * H * SPP * K / (time.perf_counter() - t_rep) / 1e6:.1f} Msamples/s, ray gen {st_rep['primary_ray_gen'] / K:.0f} us/frame, "
+              f"primary trace {st_rep['primary_trace'] / K:.0f} us/frame (first timed region of this process: {W * H * SPP * K / dt / 1e6:.1f}, "
               f"ray gen {stages['primary_ray_gen'] / K:.0f}, primary trace {stages['primary_trace'] / K:.0f})", file=sys.stderr)
 
     # algorithmic bytes of the traversal kernels: instrumented variants on the next iterations of the same workload --
     # first the product kernels with counters (their own bytes), then the reference's BVH2 walk on the same rays
-    n_count = max(1, min(K, 2))
-    scale = K / n_count
+    n_count = 2
+    scale = K * SPP / n_count  # (counted iterations -> all iterations of the timed region)
 
     def count_pass(flag):
         nonlocal it
@@ -442,11 +447,11 @@ def main():
     k2_bytes_ref, k3_bytes_ref = alg_bytes(c2, 72 + 20 + 4), alg_bytes(c3, 48 + 32)  # the reference algorithm's
 
     if rank == 0:
-        samples = W * H * K
+        samples = W * H * SPP * K
         launches = max(k2_launches, 1)
         k2_s = k2_ms / 1e3
         alg_gbs = (k2_bytes / 1e9) / k2_s if k2_s > 0 else 0.0          # the kernel's own algorithmic bytes per second
-        traffic = measured_traffic(args.workload, K, batch, world)
+        traffic = measured_traffic(args.workload, SPP, batch, world)
         hbm_gbs = (traffic["bytes_per_launch"] * launches / 1e9) / k2_s if (traffic and k2_s > 0) else None
         achieved = hbm_gbs if hbm_gbs is not None else alg_gbs
         out = {
@@ -462,13 +467,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['label']}, {W}x{H}, {K} spp", "width": W, "height": H,
-                       "spp": K, "unique_tris": info["tris"], "bvh_tris": info["bvh_tris"], "bvh2_nodes": info["nodes"],
+            "step": f"one {SPP}-spp frame: clear, {SPP} iterations ({-(-SPP // batch)} layered pass(es) of {batch}), " +
+                    ("read-back of the frame to the host" if world == 1 else "exchange of the owned tiles to rank 0"),
+            "config": {"workload": f"{args.workload}: {wl['label']}, {W}x{H}, {SPP} spp", "width": W, "height": H,
+                       "spp": SPP, "frames": K, "unique_tris": info["tris"], "bvh_tris": info["bvh_tris"], "bvh2_nodes": info["nodes"],
                        "max_depth": int(cam.pass_settings.max_total_depth),
                        "parallelism": f"tile-shard x{world} (64x64 tiles round-robin, 1 gather of the owned tiles per frame over RCCL)",
                        "iterations_per_pass": batch},
             "roofline": {
-                "bound": "hbm", "kernel": f"K2 closest-hit traversal over the {bvh_width}-wide BLAS: k_trace_closest_refill<{bvh_width}, 40> (secondary bounces, lanes refilled one by one) + <{bvh_width}, 64> (primary rays, whole chunks)",
+                "bound": "hbm", "kernel": f"K2 closest-hit traversal over the {bvh_width}-wide BLAS: " +
+                ("k_trace_closest_pool (secondary bounces: finished lanes take prepared rays from a per-wavefront pool in LDS)" if ctx.closest_hit_form() == 2
+                 else f"k_trace_closest_refill<{bvh_width}, 40> (secondary bounces, lanes refilled one by one)") +
+                f" + k_trace_closest_refill<{bvh_width}, 64> (primary rays, whole chunks)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "achieved_is": (("HBM traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE of a profiled run of this command) / launch time"
                                  if traffic.get("exact") else
@@ -507,11 +517,12 @@ def main():
                                   "rays_per_sample": c3["rays"] / (n_count * W * H / world)},
             },
             "stage_us_per_step": {k: v / K for k, v in stages.items() if v},
+            "stage_us_per_spp": {k: v / (K * SPP) for k, v in stages.items() if v},
             "scene_build_s": info["build_s"],
         }
-        out["render_ms"] = (t_rendered - t0) * 1e3   # the K iterations, stream drained
+        out["render_ms"] = t_render * 1e3 / K   # per frame: clear + the SPP iterations, stream drained
         if dist is None:
-            out["readback_ms"] = (t_readback - t_rendered) * 1e3  # the finished frame to (page-locked) host memory, once per image
+            out["readback_ms"] = t_out * 1e3 / K  # per frame: the finished frame to (page-locked) host memory
         if rank_times is not None:
             out["exchange_ms"] = rank_times["exchange_ms_rank0"]
             out["rank_render_ms"] = rank_times["render_ms"]

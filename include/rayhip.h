@@ -337,11 +337,17 @@ RAYHIP_API int rayhip_scene_upload(rayhip_ctx *ctx, const rayhip_scene_desc *des
  * but instance / light arrays may already be the new ones: re-send the scene with rayhip_scene_upload. */
 RAYHIP_API int rayhip_scene_update_instances(rayhip_ctx *ctx, const rayhip_scene_desc *desc);
 
-/* which acceleration-structure form the traversal kernels walk for the uploaded scene: 8 = the 8-wide quantised BLAS
- * (ray_amd/csrc/rt_bvh8.h, the default), 4 = the 4-wide one (rt_bvh4.h; RAYHIP_BVH_WIDTH=4, or the 8-wide collapse was not
- * possible), 2 = the reference's BVH2 as handed over; 0 = no scene.  (What the algorithmic-bytes figure of bench.py prices a
- * node visit with: 80 / 64 / 64 bytes.) */
+/* which acceleration-structure form the traversal kernels walk for the uploaded scene: 4 = the 4-wide quantised BLAS
+ * (ray_amd/csrc/rt_bvh4.h, the default), 8 = the 8-wide one (rt_bvh8.h; RAYHIP_BVH_WIDTH=8), 2 = the reference's BVH2 as handed
+ * over (RAYHIP_BVH_WIDTH=2, or a child box that cannot be quantised); 0 = no scene.  (What the algorithmic-bytes figure of
+ * bench.py prices a node visit with: 64 / 80 / 64 bytes.) */
 RAYHIP_API int rayhip_scene_bvh_width(rayhip_ctx *ctx);
+
+/* which form of the closest-hit kernel rayhip_render[_batch] launches for the secondary bounces of the uploaded scene: 0 = one ray
+ * per lane to completion (k_trace_closest), 1 = persistent wavefronts that refill finished lanes from the queue
+ * (k_trace_closest_refill), 2 = ... from a pool of prepared rays in LDS (k_trace_closest_pool: scenes with one instance, 4-wide
+ * BLAS; RAYHIP_REFILL selects).  All forms find the same hits bit for bit; this is what bench.py names in its roofline block. */
+RAYHIP_API int rayhip_closest_hit_form(rayhip_ctx *ctx);
 
 /* Same upload from a serialised scene (ray_amd/csrc/scene_blob.h; written by the reference-side SceneHIP or by
  * tests/golden/make_fixtures.py): uploads the arrays AND the filter table stored in the blob and returns the

@@ -84,49 +84,51 @@ constexpr int LDS_STACK_DEPTH = RT_LDS_STACK_DEPTH;
 constexpr int STACK_TOTAL_DEPTH = 2 * MAX_STACK_SIZE; // TLAS + BLAS, 48 each in the reference
 constexpr int STACK_SPILL_DEPTH = STACK_TOTAL_DEPTH - LDS_STACK_DEPTH;
 
-// Depth-major per-wavefront stack: entries [0, LDS_STACK_DEPTH) live in LDS, deeper ones in a per-wave HBM slab.
-struct LdsStack {
+// Depth-major per-wavefront stack: entries [0, DEPTH) live in LDS, deeper ones in a per-wave HBM slab (DEPTH = LDS_STACK_DEPTH for
+// every kernel but the pooled closest-hit kernel, which trades stack entries for its pool of prepared rays).
+template <int DEPTH>
+struct LdsStackT {
     uint32_t *lane_base;  // &lds[0][lane]
     uint32_t *spill_base; // &slab[wave][0][lane]
     uint32_t size;
     __device__ __forceinline__ void push(uint32_t v) {
-        if (size < uint32_t(LDS_STACK_DEPTH)) {
+        if (size < uint32_t(DEPTH)) {
             lane_base[size * WAVE] = v;
         } else if (size < uint32_t(STACK_TOTAL_DEPTH)) {
-            spill_base[(size - LDS_STACK_DEPTH) * WAVE] = v;
+            spill_base[(size - DEPTH) * WAVE] = v;
         }
         ++size;
     }
     __device__ __forceinline__ uint32_t pop() {
         --size;
-        if (size < uint32_t(LDS_STACK_DEPTH)) {
+        if (size < uint32_t(DEPTH)) {
             return lane_base[size * WAVE];
         }
-        return size < uint32_t(STACK_TOTAL_DEPTH) ? spill_base[(size - LDS_STACK_DEPTH) * WAVE] : 0x1fffffffu;
+        return size < uint32_t(STACK_TOTAL_DEPTH) ? spill_base[(size - DEPTH) * WAVE] : 0x1fffffffu;
     }
     // slot access for the 4-wide walk (rt_bvh4.h): three consecutive slots are one address + immediate offsets
-    __device__ __forceinline__ bool fast_range(const uint32_t idx_end) const { return idx_end <= uint32_t(LDS_STACK_DEPTH); }
+    __device__ __forceinline__ bool fast_range(const uint32_t idx_end) const { return idx_end <= uint32_t(DEPTH); }
     __device__ __forceinline__ void write3_fast(const uint32_t idx, const uint32_t a, const uint32_t b, const uint32_t c) {
         uint32_t *p = lane_base + idx * WAVE;
         p[0] = a, p[WAVE] = b, p[2 * WAVE] = c;
     }
     __device__ __forceinline__ void write_at(const uint32_t idx, const uint32_t v) {
-        if (idx < uint32_t(LDS_STACK_DEPTH)) {
+        if (idx < uint32_t(DEPTH)) {
             lane_base[idx * WAVE] = v;
         } else if (idx < uint32_t(STACK_TOTAL_DEPTH)) {
-            spill_base[(idx - LDS_STACK_DEPTH) * WAVE] = v;
+            spill_base[(idx - DEPTH) * WAVE] = v;
         }
     }
     __device__ __forceinline__ uint32_t read_at(const uint32_t idx) const {
-        if (idx < uint32_t(LDS_STACK_DEPTH)) {
+        if (idx < uint32_t(DEPTH)) {
             return lane_base[idx * WAVE];
         }
-        return idx < uint32_t(STACK_TOTAL_DEPTH) ? spill_base[(idx - LDS_STACK_DEPTH) * WAVE] : 0x1fffffffu;
+        return idx < uint32_t(STACK_TOTAL_DEPTH) ? spill_base[(idx - DEPTH) * WAVE] : 0x1fffffffu;
     }
     // two-word entries of the 8-wide walk (rt_bvh8.h): slots idx and idx + 1 (one address, two immediate offsets -> a single
     // ds_write2st64_b32 / ds_read2st64_b32 while both are in the LDS part)
     __device__ __forceinline__ void write2_at(const uint32_t idx, const uint32_t a, const uint32_t b) {
-        if (idx + 2 <= uint32_t(LDS_STACK_DEPTH)) {
+        if (idx + 2 <= uint32_t(DEPTH)) {
             uint32_t *p = lane_base + idx * WAVE;
             p[0] = a, p[WAVE] = b;
         } else {
@@ -134,7 +136,7 @@ struct LdsStack {
         }
     }
     __device__ __forceinline__ void read2_at(const uint32_t idx, uint32_t &a, uint32_t &b) const {
-        if (idx + 2 <= uint32_t(LDS_STACK_DEPTH)) {
+        if (idx + 2 <= uint32_t(DEPTH)) {
             const uint32_t *p = lane_base + idx * WAVE;
             a = p[0], b = p[WAVE];
         } else if (idx + 2 <= uint32_t(STACK_TOTAL_DEPTH)) {
@@ -144,6 +146,7 @@ struct LdsStack {
         }
     }
 };
+using LdsStack = LdsStackT<LDS_STACK_DEPTH>;
 
 // (wave_alloc, RayQueue, the SoA / pixel-buffer structs: wavefront.hip.h; the shade kernels K5: shade_kernels.hip)
 
@@ -667,6 +670,399 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
         atomicAdd(&g_prof_acc[8], (unsigned long long)st_iter);
         atomicAdd(&g_prof_acc[9], (unsigned long long)st_serv), atomicAdd(&g_prof_acc[10], (unsigned long long)st_serv_lanes);
         atomicAdd(&g_prof_acc[11], (unsigned long long)st_tlas);
+    }
+#endif
+}
+
+// ---- K2, pooled form (round 4; the secondary bounces of 4-wide scenes by default, rayhip.hip: RAYHIP_REFILL=4) ---------------------
+// What round 3's counters said about the refill kernel above: it issues vector instructions at ~90 % of what the ALU can take for its
+// instruction mix -- with 35 of 64 lanes.  A third of a wavefront's lanes stand OUTSIDE the walk: a finished lane waits until
+// RT_REFILL_MIN (40) lanes wait, because the service part (finish a ray, fetch the next one, top-level walk, instance transform: ~300
+// instructions and four dependent memory round trips) costs the same whether it serves 4 lanes or 40.
+//
+// Here the expensive half of the service part always runs with FULL wavefronts, and a finished lane is back in the walk after a short
+// swap.  Every wavefront keeps a POOL of prepared rays in LDS -- rays that are already through the top level and the instance
+// transform (slot, object-space origin and direction, instance | ray type, BLAS root: 9 words, SoA, 64 entries):
+//   * batch prepare (pool empty, a lane wants a ray): all 64 lanes take one ray of the next chunk each -- whatever ray they carry in
+//     their registers stays there -- walk the top level with it up to its first visible instance, transform it and write it to the
+//     pool; the scratch entries of that top-level walk live ABOVE the lane's own stack top;
+//   * swap (RT_POOL_SWAP_MIN lanes wait, default 16): finished lanes store their hit and read the next pool entry: ~70 instructions;
+//   * the walk itself, the finish of a ray (index indirection, transparency round) and the top-level steps of rays that need them are
+//     the refill kernel's, statement for statement -- per ray the same visits in the same order, so the same hits bit for bit
+//     (test_gpu_parity.py::test_refill_kernel_is_bit_identical runs all forms).
+// A pool entry stands for a ray whose top-level walk has nothing pending when it enters its first instance (the stack holds the two
+// sentinels only): true for every ray of a single-instance scene.  A ray that enters its first instance with top-level nodes pending
+// cannot hand that stack to another lane; its entry is marked UNPREPARED and the lane that takes it walks the top level itself, as in
+// the refill kernel (the pooled form is therefore chosen per scene: rayhip.hip).  Rays that miss the top level altogether are
+// finished by the batch (the miss record is stored, no pool entry).
+// LDS per wavefront: RT_POOL_STACK_DEPTH x 256 B of stack + 2304 B of pool; 16 entries -> 6400 B -> 6 waves per SIMD as before
+// (deeper stacks spill to the HBM slab as in every traversal kernel; the headline scene's deepest walk uses 17).
+#ifndef RT_POOL_SWAP_MIN
+#define RT_POOL_SWAP_MIN 16
+#endif
+#ifndef RT_POOL_STACK_DEPTH
+#define RT_POOL_STACK_DEPTH 16
+#endif
+#ifndef RT_POOL_MIN_WAVES
+#define RT_POOL_MIN_WAVES 6
+#endif
+constexpr int POOL_STACK_DEPTH = RT_POOL_STACK_DEPTH;
+constexpr int POOL_FIELDS = 9;                   // slot | o.xyz | d.xyz | instance + (ray type << 24) | BLAS root
+constexpr uint32_t POOL_UNPREPARED = 0xfffffffeu; // in the root field: the taker walks the top level itself (never a node word)
+template <int MIN_WAIT = RT_POOL_SWAP_MIN>
+__global__ void __launch_bounds__(WAVE, RT_POOL_MIN_WAVES) k_trace_closest_pool(const SceneView sc, const TraceParams tp, const RaySoA rays,
+                                                                                const HitSoA hits, const RayQueue queue, const int init_hits,
+                                                                                uint32_t *__restrict__ stack_spill, const Layering layers) {
+    __shared__ uint32_t lds_stack[POOL_STACK_DEPTH * WAVE];
+    __shared__ uint32_t lds_pool[POOL_FIELDS * WAVE];
+    const uint32_t lane = threadIdx.x;
+#ifdef RT_PROFILE_TRACE
+    if (threadIdx.x < 32) {
+        s_prof_acc[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) {
+        s_prof_last = __builtin_readcyclecounter();
+    }
+    uint32_t st_a = 0, st_b = 0, st_iter = 0, st_serv = 0, st_serv_lanes = 0, st_tlas = 0, st_prep = 0, st_prep_lanes = 0; // (uniform)
+#endif
+    LdsStackT<POOL_STACK_DEPTH> st;
+    st.lane_base = &lds_stack[lane];
+    st.spill_base = stack_spill + size_t(blockIdx.x) * size_t((STACK_TOTAL_DEPTH - POOL_STACK_DEPTH) * WAVE) + lane;
+    st.size = 0;
+
+    enum : uint32_t { IDLE = 0, TLAS = 1, BLAS = 2 };
+    // lane state (as in the refill kernel); `world`: ro / rd hold the ray's world-space origin and direction (a ray taken from the
+    // pool arrives in object space and fetches them only if it meets a non-solid surface)
+    uint32_t lvl = IDLE, slot = 0, cur = BVH4_SENTINEL, tos = BVH4_SENTINEL, size = 0, mi_index = 0, ray_flags = 0;
+    bool res = false, world = false;
+    f3 ro = {0.0f, 0.0f, 0.0f}, rd = {0.0f, 0.0f, 1.0f};
+    f3 o = ro, d = rd, inv_d = rd;
+    Hit h = make_hit();
+    float t_val = 0.0f;
+    // wavefront state (uniform)
+    uint32_t pool_head = 0, pool_n = 0;
+    bool exhausted = false;
+    ChunkWalk walk(queue.live_chunks());
+
+    auto begin_round = [&]() { // IntersectScene loop head + walk prologue at TLAS level
+        t_val = h.t;
+        res = false;
+        size = 0;
+        st.write_at(size++, BVH4_SENTINEL);
+        tos = BVH4_SENTINEL;
+        cur = tp.root_index;
+        lvl = TLAS;
+    };
+    auto pop = [&]() {
+        cur = tos;
+        tos = st.read_at(--size);
+    };
+    auto leave_blas = [&]() {
+        if (lvl == BLAS && cur == BVH4_SENTINEL) {
+            lvl = TLAS;
+            pop();
+        }
+    };
+
+    uint32_t n_dead = 0; // idle lanes that can no longer be refilled (uniform)
+    for (;;) {
+        // ---- BLAS part: the majority-scheduled walk, left as soon as MIN_WAIT lanes wait outside
+        for (;;) {
+            const bool in_blas = (lvl == BLAS);
+            const bool at_leaf = in_blas && (cur & BVH2_PRIM_COUNT_BITS) != 0;
+            const bool at_node = in_blas && !at_leaf;
+            const int n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf));
+            const int n_out = WAVE - n_node - n_leaf - int(n_dead);
+#ifdef RT_PROFILE_TRACE
+            st_a += n_node, st_b += n_leaf, st_iter += 1;
+#endif
+            if (n_node + n_leaf == 0 || n_out >= MIN_WAIT) {
+                break;
+            }
+            if (n_node * RT_REFILL_VOTE_DEN >= n_leaf * RT_REFILL_VOTE_NUM) {
+                if (at_node) {
+                    bvh4_visit(sc.nodes4, o, inv_d, h.t, st, cur, tos, size);
+                    leave_blas();
+                }
+                RT_PROF_T(19)
+            } else {
+                if (at_leaf) {
+                    const int tri_start = int(cur & BVH2_PRIM_INDEX_BITS), tri_end = int(tri_start + ((cur & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
+                    res |= intersect_tris_closest(o, d, tri_table(sc), tri_start, tri_end, int(mi_index), h);
+                    pop();
+                    leave_blas();
+                }
+                RT_PROF_T(26)
+            }
+        }
+
+        // ---- swap, first half: finish rays whose top-level walk is over (the refill kernel's part D)
+#ifdef RT_PROFILE_TRACE
+        st_serv += 1, st_serv_lanes += uint32_t(__popcll(__ballot(lvl != BLAS))) - n_dead;
+#endif
+        if ((lvl == TLAS) && (cur == BVH4_SENTINEL)) {
+            if (h.prim_index < 0) { // end of Traverse_TLAS_WithStack_ClosestHit: primitive index indirection (runs on misses too)
+                h.prim_index = -int(sc.tri_indices[-h.prim_index - 1]) - 1;
+            } else {
+                h.prim_index = int(sc.tri_indices[h.prim_index]);
+            }
+            bool again = false;
+            if (res && !hit_side_is_solid(sc, h)) { // tail of the IntersectScene round (rare)
+                if (!world) {
+                    const float4 a = rays.o_pdf[slot], b = rays.d_cw[slot];
+                    ro = {a.x, a.y, a.z};
+                    rd = {b.x, b.y, b.z};
+                    world = true;
+                }
+                const float4 cc = rays.c_cs[slot];
+                const uint2 xd = rays.xy_depth[slot];
+                Ray r;
+                r.c = {cc.x, cc.y, cc.z};
+                r.cone_spread = cc.w;
+                r.xy = xd.x, r.depth = xd.y;
+                const uint32_t xy_virtual = r.xy, layer = xy_layer(xy_virtual, layers);
+                TraceParams tpl = tp;
+                if (layer != 0) { // a later iteration of the batch: its own sample index / seed, keyed by the real pixel
+                    tpl.iteration = tp.iteration + int(layer);
+                    tpl.rand_seed = layer_rand_seed(tpl.iteration);
+                    r.xy = xy_real(xy_virtual, layers, layer);
+                }
+                const uint32_t rand_hash = hash_combine(hash(r.xy), tpl.rand_seed);
+                uint32_t rand_dim = RAND_DIM_BASE_COUNT + get_total_depth(r.depth) * RAND_DIM_BOUNCE_COUNT;
+                const uint32_t depth_in = r.depth;
+                const f3 c_in = r.c;
+                again = closest_resolve_transparency(sc, tpl, r, h, t_val, rd, ro, rand_dim, rand_hash);
+                if (r.depth != depth_in || r.c.x != c_in.x || r.c.y != c_in.y || r.c.z != c_in.z) {
+                    rays.c_cs[slot] = mkfloat4(r.c.x, r.c.y, r.c.z, r.cone_spread);
+                    uint2 xo;
+                    xo.x = xy_virtual, xo.y = r.depth;
+                    rays.xy_depth[slot] = xo;
+                }
+            }
+            if (again) {
+                begin_round();
+            } else {
+                if (world) { // (a ray that never left object space has ro == its origin: the reference's  t += length(o - ro)  adds 0)
+                    const float4 o0 = rays.o_pdf[slot];
+                    h.t += length(f3{o0.x, o0.y, o0.z} - ro);
+                }
+                store_hit(hits, slot, h);
+                lvl = IDLE;
+            }
+        }
+        // ---- swap, second half: idle lanes take the next pool entries; an empty pool is refilled by the whole wavefront
+        for (;;) {
+            const unsigned long long idle_mask = __ballot(lvl == IDLE);
+            if (idle_mask == 0ull) {
+                break;
+            }
+            if (__builtin_amdgcn_readfirstlane(int(pool_n)) == 0) {
+                if (exhausted) {
+                    break;
+                }
+                // -- batch prepare: one fresh ray per lane, through the top level, into the pool
+                int found = 0;
+                uint32_t chunk_slot0 = 0, chunk_live = 0;
+                {
+                    uint32_t next_chunk;
+                    while (!found && walk.next(next_chunk)) { // (uniform)
+                        uint32_t stripe, slot0, n_live;
+                        found = __builtin_amdgcn_readfirstlane(int(queue.chunk(next_chunk, stripe, slot0, n_live)));
+                        if (found) {
+                            chunk_slot0 = uint32_t(__builtin_amdgcn_readfirstlane(int(slot0)));
+                            chunk_live = uint32_t(__builtin_amdgcn_readfirstlane(int(n_live)));
+                        }
+                    }
+                }
+                if (!found) {
+                    exhausted = true;
+                    break;
+                }
+                const bool mine = lane < chunk_live;
+                const uint32_t ps = chunk_slot0 + lane;
+                uint32_t p_root = POOL_UNPREPARED, p_word = 0;
+                f3 po = {0.0f, 0.0f, 0.0f}, pd = {0.0f, 0.0f, 1.0f};
+                bool entered = false;
+                if (mine) {
+                    const float4 a = rays.o_pdf[ps], b = rays.d_cw[ps];
+                    const uint32_t p_type = get_ray_type(rays.xy_depth[ps].y);
+                    const f3 pro = {a.x, a.y, a.z}, prd = {b.x, b.y, b.z};
+                    const float p_t = init_hits ? MAX_DIST : hits.oi_pi_t_u[ps].z;
+                    const f3 inv = safe_invert(prd);
+                    // the top-level walk of the refill kernel's part C, on scratch entries above this lane's own stack top
+                    uint32_t p_size = size, p_cur = tp.root_index, p_tos = BVH4_SENTINEL;
+                    st.write_at(p_size++, BVH4_SENTINEL);
+                    while (p_cur != BVH4_SENTINEL && !entered) {
+                        if ((p_cur & BVH2_PRIM_COUNT_BITS) == 0) {
+                            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + p_cur);
+                            const float4 d0 = np[0], d1 = np[1], d2 = np[2], links = np[3];
+                            const uint32_t left_child = float_as_uint(links.x), right_child = float_as_uint(links.y);
+                            const float ch0_min[3] = {d0.x, d0.z, d2.x}, ch0_max[3] = {d0.y, d0.w, d2.y};
+                            const float ch1_min[3] = {d1.x, d1.z, d2.z}, ch1_max[3] = {d1.y, d1.w, d2.w};
+                            float ch0_dist, ch1_dist;
+                            const bool ch0_res = bbox_test(pro, inv, p_t, ch0_min, ch0_max, ch0_dist);
+                            const bool ch1_res = bbox_test(pro, inv, p_t, ch1_min, ch1_max, ch1_dist);
+                            if (!ch0_res && !ch1_res) {
+                                p_cur = p_tos;
+                                p_tos = st.read_at(--p_size);
+                            } else if (ch0_res && ch1_res) {
+                                const bool swap = ch1_dist < ch0_dist;
+                                st.write_at(p_size++, p_tos);
+                                p_tos = swap ? left_child : right_child;
+                                p_cur = swap ? right_child : left_child;
+                            } else {
+                                p_cur = ch0_res ? left_child : right_child;
+                            }
+                        } else {
+                            const uint32_t mi = (p_cur & BVH2_PRIM_INDEX_BITS);
+                            const rayhip_mesh_instance &inst = sc.mesh_instances[mi];
+                            if ((inst.ray_visibility & (1u << p_type)) != 0) {
+                                entered = true;
+                                if (p_tos == BVH4_SENTINEL) { // nothing pending at the top level: the ray can change lanes
+                                    po = transform_point(pro, inst.inv_xform);
+                                    pd = transform_direction(prd, inst.inv_xform);
+                                    p_word = mi | (p_type << 24);
+                                    p_root = sc.blas_root4[mi];
+                                }
+                            } else {
+                                p_cur = p_tos;
+                                p_tos = st.read_at(--p_size);
+                            }
+                        }
+                    }
+                    if (!entered) { // the ray misses the top level: finished here (the refill kernel's part D on a ray without a hit)
+                        Hit hm = init_hits ? make_hit() : load_hit(hits, ps);
+                        if (hm.prim_index < 0) {
+                            hm.prim_index = -int(sc.tri_indices[-hm.prim_index - 1]) - 1;
+                        } else {
+                            hm.prim_index = int(sc.tri_indices[hm.prim_index]);
+                        }
+                        store_hit(hits, ps, hm);
+                    }
+                }
+#ifdef RT_PROFILE_TRACE
+                st_prep += 1, st_prep_lanes += chunk_live;
+#endif
+                const unsigned long long ent_mask = __ballot(entered);
+                if (entered) {
+                    const uint32_t e = uint32_t(__popcll(ent_mask & ((1ull << lane) - 1ull)));
+                    lds_pool[0 * WAVE + e] = ps;
+                    lds_pool[1 * WAVE + e] = float_as_uint(po.x), lds_pool[2 * WAVE + e] = float_as_uint(po.y), lds_pool[3 * WAVE + e] = float_as_uint(po.z);
+                    lds_pool[4 * WAVE + e] = float_as_uint(pd.x), lds_pool[5 * WAVE + e] = float_as_uint(pd.y), lds_pool[6 * WAVE + e] = float_as_uint(pd.z);
+                    lds_pool[7 * WAVE + e] = p_word;
+                    lds_pool[8 * WAVE + e] = p_root;
+                }
+                __syncthreads(); // (one wavefront per block: orders the pool writes before the reads of other lanes)
+                pool_head = 0;
+                pool_n = uint32_t(__popcll(ent_mask));
+                RT_PROF_T(23)
+                continue;
+            }
+            const uint32_t rank = uint32_t(__popcll(idle_mask & ((1ull << lane) - 1ull)));
+            const uint32_t n_take = min(uint32_t(__popcll(idle_mask)), pool_n);
+            if (lvl == IDLE && rank < n_take) {
+                const uint32_t e = pool_head + rank;
+                slot = lds_pool[0 * WAVE + e];
+                const uint32_t root = lds_pool[8 * WAVE + e];
+                h = init_hits ? make_hit() : load_hit(hits, slot);
+                if (root == POOL_UNPREPARED) { // top-level nodes were pending at its first instance: this lane walks the top level itself
+                    const float4 a = rays.o_pdf[slot], b = rays.d_cw[slot];
+                    ro = {a.x, a.y, a.z};
+                    rd = {b.x, b.y, b.z};
+                    world = true;
+                    ray_flags = (1u << get_ray_type(rays.xy_depth[slot].y));
+                    begin_round();
+                } else {
+                    o = {uint_as_float(lds_pool[1 * WAVE + e]), uint_as_float(lds_pool[2 * WAVE + e]), uint_as_float(lds_pool[3 * WAVE + e])};
+                    d = {uint_as_float(lds_pool[4 * WAVE + e]), uint_as_float(lds_pool[5 * WAVE + e]), uint_as_float(lds_pool[6 * WAVE + e])};
+                    inv_d = safe_invert(d);
+                    const uint32_t w = lds_pool[7 * WAVE + e];
+                    mi_index = w & 0xffffffu;
+                    ray_flags = 1u << (w >> 24);
+                    world = false;
+                    // begin_round + the instance entry of part C: two sentinels, nothing pending at the top level
+                    t_val = h.t;
+                    res = false;
+                    size = 0;
+                    st.write_at(size++, BVH4_SENTINEL);
+                    st.write_at(size++, BVH4_SENTINEL);
+                    tos = BVH4_SENTINEL;
+                    cur = root;
+                    lvl = BLAS;
+                    leave_blas(); // (a BLAS whose root is the sentinel: nothing to walk)
+                }
+            }
+            pool_head += n_take, pool_n -= n_take;
+        }
+        RT_PROF_T(25)
+        // whoever is idle now stays idle (the pool is empty and the queue exhausted)
+        n_dead = uint32_t(__builtin_amdgcn_readfirstlane(__popcll(__ballot(lvl == IDLE))));
+        if (__builtin_amdgcn_readfirstlane(int(n_dead == uint32_t(WAVE)))) {
+            break;
+        }
+
+        // ---- top-level steps of the lanes that walk it themselves (the refill kernel's part C)
+        for (;;) {
+            const bool in_c = (lvl == TLAS) && (cur != BVH4_SENTINEL);
+            if (__builtin_amdgcn_readfirstlane(int(__ballot(in_c) == 0ull))) {
+                break;
+            }
+#ifdef RT_PROFILE_TRACE
+            st_tlas += 1;
+#endif
+            if (in_c) {
+                if ((cur & BVH2_PRIM_COUNT_BITS) == 0) { // TLAS node (reference BVH2): near child first, far child pushed
+                    const f3 inv = safe_invert(rd);
+                    const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
+                    const float4 d0 = np[0], d1 = np[1], d2 = np[2], links = np[3];
+                    const uint32_t left_child = float_as_uint(links.x), right_child = float_as_uint(links.y);
+                    const float ch0_min[3] = {d0.x, d0.z, d2.x}, ch0_max[3] = {d0.y, d0.w, d2.y};
+                    const float ch1_min[3] = {d1.x, d1.z, d2.z}, ch1_max[3] = {d1.y, d1.w, d2.w};
+                    float ch0_dist, ch1_dist;
+                    const bool ch0_res = bbox_test(ro, inv, h.t, ch0_min, ch0_max, ch0_dist);
+                    const bool ch1_res = bbox_test(ro, inv, h.t, ch1_min, ch1_max, ch1_dist);
+                    if (!ch0_res && !ch1_res) {
+                        pop();
+                    } else if (ch0_res && ch1_res) {
+                        const bool swap = ch1_dist < ch0_dist;
+                        st.write_at(size++, tos);
+                        tos = swap ? left_child : right_child;
+                        cur = swap ? right_child : left_child;
+                    } else {
+                        cur = ch0_res ? left_child : right_child;
+                    }
+                } else { // TLAS leaf: one mesh instance
+                    const uint32_t mi = (cur & BVH2_PRIM_INDEX_BITS);
+                    const rayhip_mesh_instance &inst = sc.mesh_instances[mi];
+                    if ((inst.ray_visibility & ray_flags) != 0) {
+                        mi_index = mi;
+                        o = transform_point(ro, inst.inv_xform);
+                        d = transform_direction(rd, inst.inv_xform);
+                        inv_d = safe_invert(d);
+                        st.write_at(size++, tos); // the TLAS walk resumes from here
+                        tos = BVH4_SENTINEL;
+                        cur = sc.blas_root4[mi];
+                        lvl = BLAS;
+                        leave_blas();
+                    } else {
+                        pop();
+                    }
+                }
+            }
+            RT_PROF_T(24)
+        }
+    }
+#ifdef RT_PROFILE_TRACE
+    RT_PROF_T(27)
+    if (threadIdx.x < 32 && s_prof_acc[threadIdx.x] != 0) {
+        atomicAdd(&g_prof_acc[threadIdx.x], s_prof_acc[threadIdx.x]);
+    }
+    if (lane == 0) {
+        atomicAdd(&g_prof_acc[6], (unsigned long long)st_a), atomicAdd(&g_prof_acc[7], (unsigned long long)st_b);
+        atomicAdd(&g_prof_acc[8], (unsigned long long)st_iter);
+        atomicAdd(&g_prof_acc[9], (unsigned long long)st_serv), atomicAdd(&g_prof_acc[10], (unsigned long long)st_serv_lanes);
+        atomicAdd(&g_prof_acc[11], (unsigned long long)st_tlas);
+        atomicAdd(&g_prof_acc[12], (unsigned long long)st_prep), atomicAdd(&g_prof_acc[13], (unsigned long long)st_prep_lanes);
     }
 #endif
 }

@@ -118,6 +118,9 @@ struct rayhip_ctx {
     int tune_primary_waves = 0, tune_shadow_waves = 5;
     bool refill_secondary_only = false; // RAYHIP_REFILL=2: primary rays (coherent, every lane busy to the end) keep the plain kernel
     bool refill_primary_whole = false;  // RAYHIP_REFILL=3: ... or take the flat kernel with whole-chunk refills (no spill stores in the walk)
+    bool refill_pool = false;           // RAYHIP_REFILL=4: 3 + the secondary bounces of 4-wide scenes through the pooled kernel (k_trace_closest_pool)
+    int pool_waves = 0, pool_resident = 0; // its grid
+    bool pool_scene = false;               // ... and whether the scene in place suits it (refresh_scene_view)
 
     DevBuf pmj, filter_table;
     // scene
@@ -151,7 +154,7 @@ struct rayhip_ctx {
     rayhip_update::MeshRefs mesh_refs;
     uint32_t nodes_used = 0, nodes_reserved = 0;
     uint32_t tlas_half = 0; // which half of the reserved node slots the next rebuilt top level goes to (the live one sits in the other)
-    int wide = 0; // the wide BLAS form the kernels walk: 8 (rt_bvh8.h, default), 4 (rt_bvh4.h) or 0 (the reference's BVH2)
+    int wide = 0; // the wide BLAS form the kernels walk: 4 (rt_bvh4.h, default), 8 (rt_bvh8.h) or 0 (the reference's BVH2)
     uint32_t tex_table[8] = {}, textures_count = 0, tex_flags = 0;
     struct { uint32_t vertices, vtx_indices, tri_materials, materials; } geometry = {};
     bool adaptive_dirty = false; // a pass ran with variance_threshold != 0 since the last Clear / Resize: required_samples may
@@ -490,11 +493,21 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
             }
             c->refill_resident = c->props.multiProcessorCount * per_cu_refill;
             c->refill_waves = std::min(c->grid_waves, c->refill_resident * refill_mult);
-            c->refill_secondary_only = mode == 2 || mode == 3;
-            c->refill_primary_whole = mode == 3;
+            c->refill_secondary_only = mode == 2 || mode == 3 || mode == 4;
+            c->refill_primary_whole = mode == 3 || mode == 4;
+            if (mode == 4) {
+                int per_cu_pool = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_pool, k_trace_closest_pool<>, WAVE, 0) != hipSuccess || per_cu_pool <= 0) {
+                    per_cu_pool = per_cu_refill;
+                }
+                c->refill_pool = true;
+                c->pool_resident = c->props.multiProcessorCount * per_cu_pool;
+                c->pool_waves = std::min(c->grid_waves, c->pool_resident * refill_mult);
+            }
         }
     }
-    if (c->stack_spill.alloc(size_t(c->grid_waves) * STACK_SPILL_DEPTH * WAVE * sizeof(uint32_t))) {
+    // (sized for the shallowest LDS stack any kernel keeps: the pooled closest-hit kernel trades stack entries for its pool)
+    if (c->stack_spill.alloc(size_t(c->grid_waves) * (STACK_TOTAL_DEPTH - std::min(LDS_STACK_DEPTH, POOL_STACK_DEPTH)) * WAVE * sizeof(uint32_t))) {
         delete c;
         return 1;
     }
@@ -544,6 +557,13 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         b.release();
     }
     c->nee_index.release();
+    for (auto &up : c->unet_pass) { // (the UNet's weights and its fifteen tensors -- 1.3 GB at 1080p -- were leaked)
+        up.weights.release();
+        up.bias.release();
+    }
+    for (DevBuf &b : c->unet_tensor) {
+        b.release();
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -659,8 +679,37 @@ static int upload_lights(rayhip_ctx *c, const rayhip_scene_desc *d) {
 
 
 // the kernels' view of what is on the device (SceneView), after a full upload or an instance update
-static void refresh_scene_view(rayhip_ctx *c, const rayhip_scene_desc *d, const uint32_t tlas_root, const rayhip_lbvh::Box &root_box) {
+// distinct instances the top level of a (validated) scene holds: a leaf word of the top level stands for one instance (the reference's
+// one-leaf tree is a root whose two links are the same leaf word, the second one behind a point box at the origin: Core.cpp:1191-1213)
+static uint32_t count_top_level_instances(const rayhip_bvh2_node *nodes, const uint32_t nodes_count, const uint32_t root) {
+    if (root == 0xffffffffu) {
+        return 0;
+    }
+    std::vector<uint32_t> seen, todo(1, root);
+    while (!todo.empty()) {
+        const uint32_t w = todo.back();
+        todo.pop_back();
+        if ((w & BVH2_PRIM_COUNT_BITS) != 0) {
+            const uint32_t mi = w & BVH2_PRIM_INDEX_BITS;
+            if (std::find(seen.begin(), seen.end(), mi) == seen.end()) {
+                if (seen.size() >= 2) {
+                    return 3; // (more than one is all the caller asks)
+                }
+                seen.push_back(mi);
+            }
+        } else if (w < nodes_count) {
+            todo.push_back(nodes[w].left_child), todo.push_back(nodes[w].right_child);
+        }
+    }
+    return uint32_t(seen.size());
+}
+
+static void refresh_scene_view(rayhip_ctx *c, const rayhip_scene_desc *d, const uint32_t tlas_root, const rayhip_lbvh::Box &root_box,
+                               const uint32_t live_instances) {
     SceneView &v = c->sc;
+    // the pooled closest-hit kernel hands prepared rays from lane to lane; a ray can change lanes only while nothing is pending at the top
+    // level, which is every ray of a scene with ONE instance (RAYHIP_POOL_ANY=1: the pooled kernel for any scene -- tests of its other path)
+    c->pool_scene = (live_instances == 1 || getenv("RAYHIP_POOL_ANY") != nullptr) && d->mesh_instances_count < (1u << 24);
     v.nodes = c->nodes.as<rayhip_bvh2_node>(), v.tris = c->tris.as<rayhip_tri_accel>(), v.tri_pitch = c->tri_pitch, v.all_solid = getenv("RAYHIP_NO_ALL_SOLID") ? 0u : c->all_solid;
     v.tri_indices = c->tri_indices.as<uint32_t>(), v.tri_materials = c->tri_materials.as<rayhip_tri_mat_data>();
     v.materials = c->materials.as<rayhip_material>(), v.vertices = c->vertices.as<rayhip_vertex>();
@@ -970,7 +1019,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         if (d->tlas_root != 0xffffffffu && d->tlas_root < d->nodes_count) {
             root_box = rayhip_rebuild::node_box(d->nodes[d->tlas_root]);
         }
-        refresh_scene_view(c, d, tlas_root, root_box);
+        refresh_scene_view(c, d, tlas_root, root_box, count_top_level_instances(d->nodes, d->nodes_count, d->tlas_root));
     }
     c->have_scene = true;
     UPLOAD_TRACE("done")
@@ -986,6 +1035,13 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
 // Returns 0, 1 = error, 2 = the scene needs rayhip_scene_upload (an instance of a mesh that is not on the device, geometry
 // arrays of another size, no room for the tree).
 int rayhip_scene_bvh_width(rayhip_ctx *c) { return !c || !c->have_scene ? 0 : c->wide ? c->wide : 2; }
+
+int rayhip_closest_hit_form(rayhip_ctx *c) {
+    if (!c || !c->have_scene || !c->wide || !c->refill_waves) {
+        return 0;
+    }
+    return (c->wide == 4 && c->refill_pool && c->pool_scene) ? 2 : 1;
+}
 
 int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
     if (use_device(c)) {
@@ -1083,7 +1139,7 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    refresh_scene_view(c, d, tlas_root, root_box);
+    refresh_scene_view(c, d, tlas_root, root_box, uint32_t(live.size()));
     UPLOAD_TRACE("instances updated")
     return 0;
 }
@@ -1262,6 +1318,10 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             } else {
                 k_trace_closest_refill<4, WAVE><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
             }
+        } else if (wide == 4 && c->refill_pool && c->pool_scene && init_hits) {
+            // secondary bounces, pooled kernel (grid: as for the refill kernel below)
+            const int want = int(std::min<size_t>(size_t(c->pool_waves), std::max<size_t>(size_t(c->pool_resident), nslots / WAVE / 8)));
+            k_trace_closest_pool<><<<std::min(gtrace, want), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
         } else if (wide && c->refill_waves && !(c->refill_secondary_only && !init_hits)) {
             // blocks: enough to even out the end of the launch (16 per wave slot on a full-size pass), but never so many that a
             // block gets fewer than ~8 chunks of 64 rays -- below that the kernel degenerates into the plain one with extra
@@ -1605,6 +1665,7 @@ int unet_tensors(rayhip_ctx *c) {
         return 0;
     }
     const int wr = round_up16(c->w), hr = round_up16(c->h);
+    c->unet_w = c->unet_h = 0; // (a failure part-way leaves tensors of two frame sizes: none of them counts as sized)
     for (int t = 0; t < 15; ++t) {
         const size_t n = size_t(wr / UNET_TENSOR_DIV[t] + 2) * size_t(hr / UNET_TENSOR_DIV[t] + 2) * size_t(UNET_TENSOR_CH[t]);
         c->unet_tensor[t].release(); // a fresh, zeroed allocation: the borders must be zero
@@ -1931,7 +1992,9 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
             k_trace_closest<true, 4><<<gg, WAVE, 0, s>>>(KK_ARGS);
         } else if (flags & RAYHIP_FLAG_COUNT_TRAVERSAL) { // instrumented walk of the reference's BVH2
             k_trace_closest<true, 0><<<gg, WAVE, 0, s>>>(KK_ARGS);
-        } else if (c->wide == 8 && c->refill_waves) { // what rayhip_render launches
+        } else if (c->wide == 4 && c->refill_pool && c->pool_scene) { // what rayhip_render launches (the pooled form also takes preset hits)
+            k_trace_closest_pool<><<<std::max(1, std::min(g, c->pool_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
+        } else if (c->wide == 8 && c->refill_waves) {
             k_trace_closest_refill<8><<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
         } else if (c->wide == 4 && c->refill_waves) {
             k_trace_closest_refill<4><<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));

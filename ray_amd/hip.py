@@ -76,7 +76,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 # every symbol include/rayhip.h declares (tests check that the built library exports all of them)
 ENTRY_POINTS = (
     "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
-    "scene_upload", "scene_bvh_width", "scene_upload_blob", "scene_update_instances", "scene_update_instances_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
+    "scene_upload", "scene_bvh_width", "closest_hit_form", "scene_upload_blob", "scene_update_instances", "scene_update_instances_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand", "k_shade",
     "comm_create", "comm_unique_id", "comm_create_rank", "comm_bind", "comm_reduce_framebuffers", "comm_destroy",
@@ -115,6 +115,8 @@ class Library:
         f("render_batch").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_int, C.c_uint32, C.POINTER(Stats)]
         f("max_batch").argtypes = [vp]
         f("scene_bvh_width").argtypes = [vp]
+        if prefix == "rayhip_":
+            f("closest_hit_form").argtypes = [vp]
         f("reserve_batch").argtypes = [vp, C.c_int]
         f("set_tonemap_lut").argtypes = [vp, C.c_int, vp, C.c_int]
         f("denoise_nlm").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int]
@@ -239,6 +241,10 @@ class Context:
     def bvh_width(self) -> int:
         """8 / 4: the wide quantised BLAS form the kernels walk; 2: the reference's BVH2"""
         return int(self.L.fn("scene_bvh_width")(self._ctx))
+
+    def closest_hit_form(self) -> int:
+        """0: one ray per lane; 1: persistent refill kernel; 2: the pooled kernel (include/rayhip.h)"""
+        return int(self.L.fn("closest_hit_form")(self._ctx)) if self.L.prefix == "rayhip_" else 0
 
     def max_batch(self) -> int:
         """largest number of iterations one wavefront pass of the current frame can carry"""

@@ -134,8 +134,10 @@ class Renderer final : public RendererBase {
             const int n = pending_count_;
             pending_count_ = 0;
             for (rayhip_ctx *c : ctxs_) { // (a pass is only enqueued: the devices work side by side)
-                check(rayhip_render_batch(c, &pending_cam_, pending_rect_, pending_first_, n, collect_stats_ ? RAYHIP_FLAG_TIME_STAGES : 0u, nullptr),
-                      "rayhip_render_batch");
+                // stage times are the root's (GetStats / ResetStats read ctx_ only): a rank that is never asked for its times must not
+                // record events either -- its pending marks and event pool would grow with every pass
+                const uint32_t flags = (collect_stats_ && c == ctx_) ? RAYHIP_FLAG_TIME_STAGES : 0u;
+                check(rayhip_render_batch(c, &pending_cam_, pending_rect_, pending_first_, n, flags, nullptr), "rayhip_render_batch");
             }
             assembled_ = comm_ == nullptr;
         }

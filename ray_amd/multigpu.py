@@ -93,8 +93,11 @@ def exchange_frame(ctx: hip.Context, rank: int, world: int, comm: Optional[hip.C
     on_host = ctx.L.prefix != "rayhip_"  # the host build of the kernels (tests): its "device memory" is host memory
     dev = torch.device("cpu") if on_host else torch.device("cuda", torch.cuda.current_device())
     mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if not on_host:
+        # the fill is enqueued on torch's stream, the pack below runs on librayhip's own: without this the zeros may land last
+        torch.cuda.current_stream(dev).synchronize()
     if rank != 0:
-        ctx.export_owned(what, mine.data_ptr(), cap)
+        ctx.export_owned(what, mine.data_ptr(), cap)  # (returns with the pack finished: the gather below may start)
     if via_host or on_host:
         parts = [torch.zeros(cap, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
         dist.gather(mine.cpu(), parts, dst=0)

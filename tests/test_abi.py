@@ -69,20 +69,21 @@ def test_bench_roofline_traffic_lookup():
     per launch for other pass sizes / rank counts of a profiled workload, absent for a workload that was never profiled"""
     sys.path.insert(0, ROOT)
     import bench
-    exact = bench.measured_traffic("bistro", 20, 20, 1)
+    import json
+    with open(bench.traffic_table_path()) as f:
+        runs = [e for e in json.load(f)["runs"] if e["workload"] == "bistro"]
+    spp0, ipp0 = runs[0].get("spp", runs[0]["steps"]), runs[0]["iterations_per_pass"]  # (a frame of rounds 2-3 was `steps` iterations long)
+    exact = bench.measured_traffic("bistro", spp0, ipp0, 1)
     assert exact and exact["exact"] and exact["profiled_avg_launch_ms"] > 0
     assert exact["bytes_per_launch"] == exact["fetch_bytes_per_launch"] + exact["write_bytes_per_launch"]
     # the north star's figure can be recomputed from the file: HBM bytes / launch time / 8 TB/s, a fraction
     frac = exact["bytes_per_launch"] / (exact["profiled_avg_launch_ms"] * 1e-3) / 8e12
     assert 0.05 < frac < 1.0
-    import json
-    with open(bench.traffic_table_path()) as f:
-        runs = [e for e in json.load(f)["runs"] if e["workload"] == "bistro"]
     nearest = min(runs, key=lambda r: abs(r["iterations_per_pass"] - 120))
     big = bench.measured_traffic("bistro", 480, 120, 1)
     assert big and not big["exact"] and abs(big["scaled_by"] - 120 / nearest["iterations_per_pass"]) < 1e-9
     assert big["scaled_from"]["iterations_per_pass"] == nearest["iterations_per_pass"]
-    rank = bench.measured_traffic("bistro", 20, 20, 8)
+    rank = bench.measured_traffic("bistro", spp0, ipp0, 8)
     assert rank and not rank["exact"] and abs(rank["bytes_per_launch"] * 8 - exact["bytes_per_launch"]) < 1.0
     # a profile belongs to the kernel sources it was taken with: the entry carries their hash, the lookup says whether it still holds
     assert "stale" in exact and exact["profiled_csrc_hash"] == runs[0].get("csrc_hash")

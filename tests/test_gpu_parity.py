@@ -75,7 +75,7 @@ def test_closest_hit_on_reference_rays(gpu_lib, name):
     g = util.golden_ref(name)
     ctx = util.make_context(gpu_lib, name)
     rays, hits, tc = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1)
-    # the kernel rayhip_render launches (8-wide quantised BLAS, rt_bvh8.h) must find the very same hits
+    # the kernel rayhip_render launches (the 4-wide quantised BLAS of rt_bvh4.h by default) must find the very same hits
     rays_w, hits_w, _ = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
     assert hits_w.tobytes() == hits.tobytes() and rays_w.tobytes() == rays.tobytes()
     ref = g["primary_hits"]
@@ -360,13 +360,18 @@ def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
     tests per ray, only interleaved differently between lanes -- hits and frames must be the same bits whether no bounce
     (RAYHIP_REFILL=0), every bounce (1) or the secondary bounces (2, the default) go through it: transparency rounds
     (cornell_principled), analytic lights (cornell_lights) and a TLAS with seven instances and visibility masks
-    (cornell_instances) included"""
+    (cornell_instances) included.  "4" / "4any": the pooled form (prepared rays handed from lane to lane through LDS) where the
+    scene suits it (one instance) and forced onto any scene -- the path of rays that cannot change lanes, taken by most rays
+    of cornell_instances"""
     for name in ("cornell_principled", "cornell_lights", "cornell_instances"):
         g = util.golden_ref(name)
         ctxs = {}
-        for mode in ("0", "1", "2"):
+        for mode in ("0", "1", "2", "3", "4"):
             monkeypatch.setenv("RAYHIP_REFILL", mode)
             ctxs[mode] = util.make_context(gpu_lib, name)
+        monkeypatch.setenv("RAYHIP_POOL_ANY", "1")
+        ctxs["4any"] = util.make_context(gpu_lib, name)
+        monkeypatch.delenv("RAYHIP_POOL_ANY")
         monkeypatch.delenv("RAYHIP_REFILL")
         ctxs["default"] = util.make_context(gpu_lib, name)
         hits, frames = {}, {}
@@ -374,7 +379,7 @@ def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
             _, hits[mode], _ = ctx.k_intersect_closest(g["primary_rays"], g["primary_hits_in"], 1, flags=0)
             ctx.render_batch(1, 6)
             frames[mode] = ctx.readback(hip.BUF_RAW)
-        for mode in ("1", "2", "default"):
+        for mode in ("1", "2", "3", "4", "4any", "default"):
             assert hits[mode].tobytes() == hits["0"].tobytes(), (name, mode)
             assert np.array_equal(frames[mode], frames["0"]), (name, mode)
 

@@ -2,20 +2,22 @@
 """rocprofv3 counter CSVs -> profiles/<round>/k2_traffic.json (HBM-side bytes per launch of the closest-hit kernel) and a
 per-kernel HBM table of the whole timed region.
 
-    python tools/k2_traffic.py <out.json> <workload> <steps> <warmup> <iterations_per_pass> <fetch_dir> <write_dir> [<table.txt> [<valu_dir>]]
+    python tools/k2_traffic.py <out.json> <workload> <steps> <warmup> <spp> <iterations_per_pass> <fetch_dir> <write_dir> [<table.txt> [<valu_dir>]]
 
 fetch_dir / write_dir: output directories of two `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of
-`bench.py --steps <steps> --warmup <warmup> --no-cpu-baseline` (separate passes: the two counters do not fit one).
+`bench.py --steps <steps> --warmup <warmup> --spp <spp> --no-cpu-baseline` (separate passes: the two counters do not fit one).
+A step is one frame of <spp> iterations (bench.py, round 4), i.e. ceil(spp / iterations_per_pass) passes.
 
 The closest-hit kernel K2 has two forms (rayhip.hip): k_trace_closest<false,true,N> for the primary rays and
-k_trace_closest_refill for the secondary bounces; "a K2 launch" is a launch of either.  Which launches belong to the timed
-region: bench.py runs, in this order, one priming pass of the timed shape, the warm-up passes, the timed passes and then the
-instrumented passes (other kernels: k_trace_closest<true,...>); every product pass has the same number of K2 launches
-(primary + one per bounce), so the timed ones are the LAST ceil(steps / ipp) x launches_per_pass product launches.
-Unit of both counters: KiB.  Appends / replaces the entry for this (workload, steps, iterations_per_pass)."""
+k_trace_closest_refill / k_trace_closest_pool for the secondary bounces; "a K2 launch" is a launch of any.  Which launches belong to
+the timed region: bench.py runs, in this order, one priming frame of the timed shape, the warm-up frames, the timed frames and then
+the instrumented passes (other kernels: k_trace_closest<true,...>) and the single-iteration parity render; every product pass has the
+same number of K2 launches (primary + one per bounce), so the timed ones are the LAST steps x passes-per-frame x launches_per_pass
+product launches before the first instrumented one.
+Unit of both counters: KiB.  Appends / replaces the entry for this (workload, spp, iterations_per_pass)."""
 import csv, glob, json, os, re, sys
 
-K2_FORMS = ("k_trace_closest<false, 8", "k_trace_closest<false, 4", "k_trace_closest<false, true", "k_trace_closest_refill")
+K2_FORMS = ("k_trace_closest<false, 8", "k_trace_closest<false, 4", "k_trace_closest<false, true", "k_trace_closest_refill", "k_trace_closest_pool")
 
 
 def short(name):
@@ -51,30 +53,35 @@ def is_k2(kernel):
 
 
 def main():
-    out, workload, steps, warmup, ipp, fetch_dir, write_dir = sys.argv[1:8]
-    table_path = sys.argv[8] if len(sys.argv) > 8 else None
-    steps, warmup, ipp = int(steps), int(warmup), int(ipp)
+    out, workload, steps, warmup, spp, ipp, fetch_dir, write_dir = sys.argv[1:9]
+    table_path = sys.argv[9] if len(sys.argv) > 9 else None
+    steps, warmup, spp, ipp = int(steps), int(warmup), int(spp), int(ipp)
     fetch_all, write_all, dur_all = counters(fetch_dir, "FETCH_SIZE"), counters(write_dir, "WRITE_SIZE"), durations(fetch_dir)
-    fetch = [(i, k, v) for i, k, v in fetch_all if is_k2(k)]
-    write = [(i, k, v) for i, k, v in write_all if is_k2(k)]
-    durs = [(t, k, v) for t, k, v in dur_all if is_k2(k)]
-    passes = -(-steps // ipp)
-    warm_passes = -(-warmup // ipp) if warmup else 0
-    per_pass = len(fetch) // max(passes + warm_passes + 1, 1)  # (+1: the priming pass)
+
+    def product_part(rows):
+        """the K2 launches in front of the first instrumented kernel (what follows it -- the counting passes, a parity render -- is not the timed region)"""
+        cut = next((i for i, (_, k, _) in enumerate(rows) if k.startswith("k_trace_closest<true")), len(rows))
+        return [r for r in rows[:cut] if is_k2(r[1])]
+
+    fetch, write, durs = product_part(fetch_all), product_part(write_all), product_part(dur_all)
+    per_frame = -(-spp // ipp)
+    passes = steps * per_frame
+    warm_passes = warmup * per_frame
+    per_pass = len(fetch) // max(passes + warm_passes + per_frame, 1)  # (+ the priming frame)
     take = per_pass * passes
     f, w, dd = fetch[-take:], write[-take:], durs[-take:]
     fsum, wsum = sum(v for _, _, v in f), sum(v for _, _, v in w)
-    entry = {"workload": workload, "steps": steps, "warmup": warmup, "iterations_per_pass": ipp,
+    entry = {"workload": workload, "steps": steps, "warmup": warmup, "spp": spp, "iterations_per_pass": ipp,
              "kernels": sorted({k for _, k, _ in f}),
              "launches_sampled": len(f), "launches_per_pass": per_pass,
              "fetch_bytes_per_launch": fsum / max(len(f), 1), "write_bytes_per_launch": wsum / max(len(w), 1),
-             "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) -- python bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline"}
+             "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) -- python bench.py --steps {steps} --warmup {warmup} --spp {spp} --no-cpu-baseline"}
     # optional third profile, `--pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU`: vector instructions per launch and the lanes they ran with --
     # the kernel is bound by vector-ALU issue (DESIGN.md section 3a), this is its other roofline
-    valu_dir = sys.argv[9] if len(sys.argv) > 9 else None
+    valu_dir = sys.argv[10] if len(sys.argv) > 10 else None
     if valu_dir:
-        insts = [(i, k, v / 1024.0) for i, k, v in counters(valu_dir, "SQ_INSTS_VALU") if is_k2(k)][-take:]
-        lanes = [(i, k, v / 1024.0) for i, k, v in counters(valu_dir, "SQ_THREAD_CYCLES_VALU") if is_k2(k)][-take:]
+        insts = [(i, k, v / 1024.0) for i, k, v in product_part(counters(valu_dir, "SQ_INSTS_VALU"))][-take:]
+        lanes = [(i, k, v / 1024.0) for i, k, v in product_part(counters(valu_dir, "SQ_THREAD_CYCLES_VALU"))][-take:]
         if insts:
             entry["valu_wave_instructions_per_launch"] = sum(v for _, _, v in insts) / len(insts)
             if lanes:
@@ -94,7 +101,7 @@ def main():
         with open(out) as fh:
             table = json.load(fh)
         table["_comment"] = table.get("_comment", "")
-    table["runs"] = [e for e in table.get("runs", []) if not (e["workload"] == workload and e["steps"] == steps and e["iterations_per_pass"] == ipp)]
+    table["runs"] = [e for e in table.get("runs", []) if not (e["workload"] == workload and e.get("spp", e["steps"]) == spp and e["iterations_per_pass"] == ipp)]
     table["runs"].append(entry)
     with open(out, "w") as fh:
         json.dump(table, fh, indent=1)
@@ -139,7 +146,7 @@ def main():
                 ms[k] = ms.get(k, 0.0) + v
         total_ms = sum(ms.values())
         with open(table_path, "w") as fh:
-            fh.write(f"# per-kernel HBM-side traffic of the timed passes: bench.py --workload {workload} --steps {steps} --warmup {warmup}\n"
+            fh.write(f"# per-kernel HBM-side traffic of the timed passes: bench.py --workload {workload} --steps {steps} --warmup {warmup} --spp {spp}\n"
                      f"# (rocprofv3 --kernel-trace --pmc FETCH_SIZE, second run --pmc WRITE_SIZE; times from the FETCH_SIZE run, i.e. under the profiler)\n"
                      f"# {'kernel':58s} {'launches':>8s} {'ms':>9s} {'% time':>7s} {'fetch GB':>9s} {'write GB':>9s} {'TB/s':>6s} {'% of 8 TB/s':>11s}\n")
             for k in sorted(ms, key=lambda k: -ms[k]):

@@ -55,7 +55,7 @@ def build_one(name, flags):
     for line in r.stderr.splitlines():
         if "Function Name:" in line:
             cur = line.split("Function Name:")[1].split("[")[0].strip()
-            cur = "refill" if "k_trace_closest_refill" in cur else "closest" if "k_trace_closestILb0" in cur else "shadow" if "k_trace_shadowILb0" in cur else \
+            cur = "pool" if "k_trace_closest_pool" in cur else "refill" if "k_trace_closest_refill" in cur else "closest" if "k_trace_closestILb0" in cur else "shadow" if "k_trace_shadowILb0" in cur else \
                 "surface" if "k_surfaceILb0ELb0" in cur else "scatter" if "k_scatterILb1ELb1" in cur else "scatter_nee" if "k_scatterILb1ELb0" in cur else \
                 "scatter_cont" if "k_scatterILb0ELb1" in cur else "pick" if "k_light_pick" in cur else None
         elif cur and any(k in line for k in ("VGPRs:", "ScratchSize", "Occupancy", "LDS Size")):
@@ -197,9 +197,8 @@ def run1(name, workload="sponza", K=16):
                           f"done or idle {1 - (buf[6] + buf[7]) / buf[8] / 64:.3f}")
                 if buf[9]:
                     print(f"  refill kernel: {buf[9]} service rounds, {buf[10] / buf[9]:.1f} lanes served per round, {buf[11] / buf[9]:.2f} top-level steps per round")
-                if buf[12] + buf[13] + buf[14]:
-                    print(f"  refill kernel: lanes at TLAS work {buf[9] / buf[8] / 64:.3f}, finishing or idle {buf[10] / buf[8] / 64:.3f}; "
-                          f"phases A {buf[11]} B {buf[12]} C {buf[13]} D {buf[14]}")
+                if buf[12]:
+                    print(f"  pooled kernel: {buf[12]} batch prepares, {buf[13] / buf[12]:.1f} rays per batch")
                 for k in range(16):
                     buf[k] = 0
             tot = float(sum(buf)) or 1.0
