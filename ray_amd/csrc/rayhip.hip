@@ -507,7 +507,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         }
     }
     // (sized for the shallowest LDS stack any kernel keeps: the pooled closest-hit kernel trades stack entries for its pool)
-    if (c->stack_spill.alloc(size_t(c->grid_waves) * (STACK_TOTAL_DEPTH - std::min(LDS_STACK_DEPTH, POOL_STACK_DEPTH)) * WAVE * sizeof(uint32_t))) {
+    if (c->stack_spill.alloc(size_t(c->grid_waves) * std::max(STACK_SPILL_DEPTH * WAVE, POOL_SLAB_WORDS) * sizeof(uint32_t))) {
         delete c;
         return 1;
     }
@@ -784,9 +784,10 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
             return fail("env_qtree holds %u floats, %d levels need %zu", d->env_qtree_count, d->env.qtree_levels, quads * 4);
         }
     }
+    bool all_sides_solid = false; // (over the triangles the trees reach: the pools are sparse, an unused slot is all zeros)
     { // every index a kernel would follow without a bound of its own (scene_validate.h)
         std::string why;
-        if (!rayhip_validate::validate(*d, why)) {
+        if (!rayhip_validate::validate(*d, why, &all_sides_solid)) {
             return fail("%s", why.c_str());
         }
     }
@@ -975,14 +976,10 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     }
     UPLOAD_TRACE("bvh uploaded")
     UP(tri_materials)
-    { // is there a triangle side that is not plainly solid?  (the closest-hit kernels skip the per-hit material fetch when not)
-        const uint32_t n = d->tri_materials_count;
-        bool all_solid = n != 0;
-        for (uint32_t i = 0; i < n && all_solid; ++i) {
-            all_solid = (d->tri_materials[i].front_mi & MATERIAL_SOLID_BIT) != 0 && (d->tri_materials[i].back_mi & MATERIAL_SOLID_BIT) != 0;
-        }
-        c->all_solid = all_solid ? 1u : 0u;
-    }
+    // is there a triangle side that is not plainly solid?  (the closest-hit kernels skip the per-hit material fetch when not; round 4: judged
+    // over the reachable triangles -- the headline scene's pool has unused slots, and the flag had never been set for it)
+    c->all_solid = all_sides_solid ? 1u : 0u;
+    UPLOAD_TRACE(all_sides_solid ? "every reachable triangle side is solid" : "some triangle sides are not solid")
     UP(materials)
     UP(vertices)
     UP(vtx_indices)

@@ -67,7 +67,9 @@ inline bool walk_tree(const rayhip_scene_desc &d, const uint32_t root, std::vect
 
 inline bool validate_lights(const rayhip_scene_desc &d, std::string &err);
 
-inline bool validate(const rayhip_scene_desc &d, std::string &err) {
+// `all_sides_solid` (optional): is every side of every REACHABLE triangle plainly solid?  (the triangle pool is sparse: unused slots hold
+// zeros, which would read as "not solid")
+inline bool validate(const rayhip_scene_desc &d, std::string &err, bool *all_sides_solid = nullptr) {
     constexpr uint32_t COUNT_BITS = 7u << 29, INDEX_BITS = ~COUNT_BITS, NONE = 0xffffffffu;
     constexpr uint32_t NODE_MIX = 4, NODE_PRINCIPLED = 6;
     constexpr uint32_t MAT_INDEX_BITS = 16383;
@@ -138,10 +140,15 @@ inline bool validate(const rayhip_scene_desc &d, std::string &err) {
         }
         tri_used[t] = 1;
     }
+    bool solid = true;
+    if (all_sides_solid) {
+        *all_sides_solid = false; // (until the loop below has seen every reachable triangle)
+    }
     for (uint32_t t = 0; t < n_real_tris; ++t) {
         if (!tri_used[t]) {
             continue;
         }
+        solid = solid && (d.tri_materials[t].front_mi & 0x8000u) != 0 && (d.tri_materials[t].back_mi & 0x8000u) != 0; // MATERIAL_SOLID_BIT
         for (int k = 0; k < 3; ++k) {
             if (d.vtx_indices[size_t(t) * 3 + k] >= d.vertices_count) {
                 return fail(err, "vtx_indices", size_t(t) * 3 + k, d.vtx_indices[size_t(t) * 3 + k], d.vertices_count);
@@ -158,6 +165,9 @@ inline bool validate(const rayhip_scene_desc &d, std::string &err) {
             }
             use_material(md.back_mi & MAT_INDEX_BITS);
         }
+    }
+    if (all_sides_solid) {
+        *all_sides_solid = solid;
     }
     // ---- materials -> sub-materials, textures ; textures -> texel pool ----
     auto use_texture = [&](const uint32_t handle) {

@@ -198,7 +198,7 @@ def run1(name, workload="sponza", K=16):
                 if buf[9]:
                     print(f"  refill kernel: {buf[9]} service rounds, {buf[10] / buf[9]:.1f} lanes served per round, {buf[11] / buf[9]:.2f} top-level steps per round")
                 if buf[12]:
-                    print(f"  pooled kernel: {buf[12]} batch prepares, {buf[13] / buf[12]:.1f} rays per batch")
+                    print(f"  pooled kernel: {buf[12]} batch prepares, {buf[13] / buf[12]:.1f} rays per batch; {buf[14]} swaps, {buf[15] / max(buf[14], 1):.1f} lanes per swap")
                 for k in range(16):
                     buf[k] = 0
             tot = float(sum(buf)) or 1.0
