@@ -55,9 +55,14 @@ __global__ void __launch_bounds__(256) k_collapse_level(const rayhip_bvh2_node *
 // `d_nodes`: the BVH2 as uploaded (device); `roots`: the distinct BLAS roots (BVH2 node indices).  Fills `d_out` (capacity
 // n_nodes2 wide nodes: a wide node stands for at least one BVH2 node) and returns the number of wide nodes; the wide node of
 // roots[r] is r.  Returns false on a device error or if a box could not be quantised.
+// Returns false on failure with the reason in `why`; `*unquantisable` (optional) tells the one failure that is a property of the scene,
+// not an error: a child box that the 8-bit grid cannot hold (non-finite or astronomically large extent) -- the caller then walks the BVH2.
 inline bool build_device(hipStream_t stream, const rayhip_bvh2_node *d_nodes, const uint32_t n_nodes2, const std::vector<uint32_t> &roots,
-                         rt::Bvh4Node *d_out, uint32_t &out_count, std::string &why) {
+                         rt::Bvh4Node *d_out, uint32_t &out_count, std::string &why, bool *unquantisable = nullptr) {
     out_count = 0;
+    if (unquantisable) {
+        *unquantisable = false;
+    }
     if (roots.empty()) {
         return true;
     }
@@ -97,6 +102,9 @@ inline bool build_device(hipStream_t stream, const rayhip_bvh2_node *d_nodes, co
         B4_TRY(hipStreamSynchronize(stream));
         if (ctrl[1]) {
             why = "a child box cannot be quantised (non-finite coordinates)";
+            if (unquantisable) {
+                *unquantisable = true;
+            }
             (void)hipFree(d_front[0]), (void)hipFree(d_front[1]), (void)hipFree(d_ctrl);
             return false;
         }

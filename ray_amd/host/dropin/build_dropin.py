@@ -98,10 +98,10 @@ def patch_tree(ref: str, tree: str) -> None:
         with open(path, "w", encoding="utf-8") as f:
             f.write(text)
     shutil.copy(os.path.join(ROOT, "ray_amd", "host", "RendererHIP.h"), os.path.join(tree, "internal", "RendererHIP.h"))
-    # Config.h + the three stand-ins for the blobs the tree lacks (oracle/gen_stubs.py), then the configuration of THIS build
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import gen_stubs
-    gen_stubs.main(ref, tree)
+    # Config.h + the three stand-ins for the blobs the tree lacks (tools/gen_ref_blobs.py), then the configuration of THIS build
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_ref_blobs
+    gen_ref_blobs.main(ref, tree)
     with open(os.path.join(tree, "Config.h"), "w") as f:
         f.write("#pragma once\n\n#define ENABLE_REF_IMPL\n#define ENABLE_HIP_IMPL\n")
 

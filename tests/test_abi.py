@@ -120,3 +120,14 @@ def test_the_header_is_plain_c_and_a_c_host_links(lib, tmp_path):
                         os.path.join(str(tmp_path), "o.ppm")], capture_output=True, text=True)
     assert r.returncode == 3 and "no HIP device" in r.stderr
     assert not os.path.exists(os.path.join(str(tmp_path), "o.ppm"))
+
+
+def test_the_documents_state_the_entry_point_count_of_the_header():
+    """INTEGRATION.md / DESIGN.md quote the number of `rayhip_*` entry points: it must be the header's (it went stale once)"""
+    import re
+    n = len(declared_entry_points())
+    for doc in ("INTEGRATION.md", "DESIGN.md"):
+        with open(os.path.join(ROOT, doc)) as f:
+            text = f.read()
+        stated = [int(m) for m in re.findall(r"\((\d+) entry points", text)]
+        assert stated and all(k == n for k in stated), (doc, stated, n)

@@ -95,3 +95,33 @@ def test_device_rebuild_of_the_atrium_against_renderer_ref(gpu_lib, leaf_max, mo
         m = util.frame_metrics(ctx.readback(hip.BUF_RAW), ref.get_raw_pixels_ref())
         print("atrium, device rebuild leaf_max", leaf_max, spp, "spp", m)
         assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= bar and m["alpha_equal"], m
+
+
+def test_a_box_the_grid_cannot_hold_falls_back_to_the_bvh2(gpu_lib, monkeypatch):
+    """a child box with an infinite coordinate cannot be quantised onto the 8-bit grid of a wide node: that is a property of the
+    scene, not an error -- the upload succeeds, the kernels walk the BVH2 as handed over (rayhip_scene_bvh_width == 2) and the
+    frame is the BVH2 walk's frame of the untouched scene (the widened box still contains its subtree: culling only)"""
+    import struct
+    import test_hostile_scenes as H
+    monkeypatch.setenv("RAYHIP_REFINE_LEAVES", "0")  # (the patched node must reach the collapse as it is)
+    blob = util.golden_scene("cornell_basic")
+    _, moff, _ = H.sections(blob)["mesh_instances"]
+    root = struct.unpack_from("<I", blob, moff + 4)[0]
+    bad = H.patched(blob, "nodes", 64 * root + 4, "<f", float("inf"))  # ch_data0[1]: child 0's max x
+
+    def frame(b, width=None):
+        if width:
+            monkeypatch.setenv("RAYHIP_BVH_WIDTH", width)
+        ctx = hip.Context(0, gpu_lib)
+        ctx.upload_static(util.pmj())
+        ctx.resize(64, 64)
+        ctx.upload_scene_blob(b)
+        monkeypatch.delenv("RAYHIP_BVH_WIDTH", raising=False)
+        ctx.render_batch(1, 4)
+        return ctx.bvh_width(), ctx.readback(hip.BUF_RAW)
+
+    w_bad, f_bad = frame(bad)
+    w_ok, f_ok = frame(blob)
+    w_2, f_2 = frame(blob, "2")
+    assert (w_bad, w_ok, w_2) == (2, 4, 2)
+    assert np.array_equal(f_bad, f_2) and np.array_equal(f_ok, f_2)

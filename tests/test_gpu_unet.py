@@ -3,7 +3,7 @@ reference's own convolution kernels (oracle: Ref::Convolution3x3 / ConvolutionCo
 Cpu::Renderer::DenoiseImage(pass, region), RendererCPU.h:790-1007 -- oracle/ref_shim.cpp: refk_unet_passes, checked bit for bit
 against the renderer's own sixteen passes in tests/test_unet_oracle.py).
 
-The trained OIDN weights are not part of the reference tree; oracle/gen_stubs.py fills the weight header with deterministic
+The trained OIDN weights are not part of the reference tree; tools/gen_ref_blobs.py fills the weight header with deterministic
 pseudo-random half-precision values of the right shapes, and BOTH sides compute with them (the product takes them from the
 reference's SetupUNetWeights).  What is checked is therefore the arithmetic of all sixteen passes -- 3 x 3 convolution with
 bias and ReLU, 2 x 2 max-pooling, nearest-neighbour upsampling and concatenation, the HDR transfer function and its inverse,

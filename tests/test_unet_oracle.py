@@ -2,7 +2,7 @@
 Cpu::Renderer::DenoiseImage(pass, region) (RendererCPU.h:790-1007) over the reference's own convolution kernels so that tests can
 look at every intermediate tensor; here its final image must equal, bit for bit, what the Reference renderer itself produces
 through the public API (InitUNetFilter + sixteen DenoiseImage(pass, region) calls), and the synthetic weights must be alive
-(oracle/gen_stubs.py: deterministic pseudo-random, the trained ones are not in the tree)."""
+(tools/gen_ref_blobs.py: deterministic pseudo-random, the trained ones are not in the tree)."""
 import numpy as np
 import pytest
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate the build-time files the reference's CPU backends need but /root/reference lacks.
 
-TEST INFRASTRUCTURE (oracle build).  Writes ONLY under oracle/_ref/gen (git-ignored):
+BUILD TOOL shared by the oracle build (oracle/Makefile), the host library (ray_amd/host/Makefile) and the drop-in build: it writes the
+generated directory it is given (all git-ignored), nothing else.  It is a generator, not oracle code: it lives under tools/.
 
 * Config.h -- what CMake's configure_file would emit from Config.h.in (reference
   CMakeLists.txt:204) with ENABLE_REF_IMPL and ENABLE_SIMD_IMPL on, VK/DX off.
