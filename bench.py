@@ -63,6 +63,9 @@ import numpy as np  # noqa: E402
 WORKLOADS = {
     "bistro": dict(kind="atrium", detail=4.3, w=1920, h=1080, label="synthetic Bistro-class atrium"),
     "sponza": dict(kind="atrium", detail=0.36, w=1920, h=1080, label="synthetic Sponza-class atrium"),
+    # the same atrium at four times the tessellation: ~12 M triangles, ~0.9 GB of nodes + triangle records -- 3.5 x the 256 MiB Infinity
+    # Cache, so the walk is served by HBM (not a BASELINE.json config: the out-of-cache data point of the roofline)
+    "bistro12m": dict(kind="atrium", detail=17.2, w=1920, h=1080, label="synthetic atrium, 12 M triangles (out of the last-level cache)"),
     # the same geometry with a texture set (11 mip-mapped 1024^2 maps: base colour on every large surface, a normal map and
     # roughness maps): not a BASELINE.json config -- the material -> texture gathers a textured asset set adds to the shade stage
     "bistro_tex": dict(kind="atrium", detail=4.3, textured=True, w=1920, h=1080, label="synthetic Bistro-class atrium, textured"),
@@ -168,6 +171,31 @@ def measured_traffic(workload, spp, batch, world=1):
     except (OSError, ValueError, KeyError, ZeroDivisionError):
         pass
     return None
+
+
+def valu_issue_block(traffic, launches, k2_s):
+    """the closest-hit kernel against the vector ALU's issue rate FOR ITS OWN INSTRUCTION MIX: vector instructions per launch from the
+    committed PMC profile / the live launch time, against the mix-weighted peak of profiles/r04/k2_valu_mix.json (tools/valu_mix.py:
+    static class mix of the walk loop x the per-class issue costs tools/valu_bench.hip measured).  `frac` = achieved / the serial-issue
+    peak of the mix (every instruction at its class's cost: < 1 unless the classes overlap more than the model allows);
+    `frac_paired_model` = against the peak if every full-rate instruction issued in the shadow of a half-rate one (an upper bound of
+    the peak, so a lower bound of the fraction)"""
+    if not (traffic and traffic.get("valu_wave_instructions_per_launch") and k2_s > 0):
+        return None
+    rate = traffic["valu_wave_instructions_per_launch"] * launches / k2_s
+    out = {"wave_instructions_per_s": rate, "active_lanes_of_64": traffic.get("valu_active_lanes"),
+           "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU of this command / live launch time"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04", "k2_valu_mix.json")) as f:
+            mix = json.load(f)
+        peak = mix["peak_wave_instructions_per_s"]
+        out.update({"mix": mix["share"], "peak_mix_weighted": peak["serial"], "frac": rate / peak["serial"],
+                    "peak_paired_model": peak["paired"], "frac_paired_model": rate / peak["paired"],
+                    "mix_is_stale": mix.get("csrc_hash") != csrc_hash(),
+                    "peaks_from": "profiles/r04/k2_valu_mix.json (tools/valu_mix.py) x profiles/r03/valu_bench.txt"})
+    except (OSError, ValueError, KeyError):
+        out.update({"peak_full_rate_class": 1.09e12, "peak_half_rate_class": 0.59e12})
+    return out
 
 
 def usable_cpus():
@@ -493,12 +521,7 @@ def main():
                 # the kernel's BINDING resource is the issue rate of the vector ALU: vector instructions per launch from the
                 # committed PMC profile / the live launch time, against what tools/valu_bench.hip measures for one instruction class
                 # (all full-rate: mul / add / logic; all half-rate: compares, selects, min / max, conversions, 3-operand integer)
-                "valu_issue": ({"wave_instructions_per_s": traffic["valu_wave_instructions_per_launch"] * launches / k2_s,
-                                "peak_full_rate_class": 1.09e12, "peak_half_rate_class": 0.59e12,
-                                "frac_of_half_rate_class": traffic["valu_wave_instructions_per_launch"] * launches / k2_s / 0.59e12,
-                                "active_lanes_of_64": traffic.get("valu_active_lanes"),
-                                "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU of this command / live launch time; peaks: profiles/r03/valu_bench.txt"}
-                               if (traffic and traffic.get("valu_wave_instructions_per_launch") and k2_s > 0) else None),
+                "valu_issue": valu_issue_block(traffic, launches, k2_s),
                 "avg_launch_ms": k2_ms / launches, "launches": k2_launches,
                 "algorithmic": {
                     "bytes_per_launch": k2_bytes / launches, "GBps": alg_gbs, "frac_of_peak": alg_gbs / HBM_PEAK_GBS,

@@ -820,3 +820,40 @@ def test_renderer_hip_through_the_ray_api(gpu_lib, name):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP
     m = util.frame_metrics(r.get_pixels_ref(), g["final_spp8"])  # the tone-mapped image (8-bit display range)
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP
+
+
+def test_the_tie_pixels_on_the_device(gpu_lib, hostsim_lib, monkeypatch):
+    """the scene of tests/test_hostsim_parity.py::test_the_tie_pixels_of_the_refined_leaves_are_pinned on the device: with the
+    reference's leaves (RAYHIP_REFINE_LEAVES=0) every pixel is within tolerance of the host build walking the same leaves (which is
+    RendererRef bit for bit); with the default refined leaves the two tie pixels -- and only they -- may leave it"""
+    from test_hostsim_parity import TIE_SCENE as t
+    from ray_amd import api, scenes
+    s = api.CreateSceneHIP(use_tex_compression=False)
+    scenes.random_instances(s, seed=t["seed"])
+    blob = api.export_scene_blob(s)
+
+    def frame(lib, batch):
+        ctx = hip.Context(0, lib)
+        ctx.upload_static(util.pmj())
+        ctx.resize(t["w"], t["h"])
+        ctx.upload_scene_blob(blob)
+        if batch:
+            ctx.render_batch(1, t["spp"])
+        else:
+            util.render_frames(ctx, t["spp"])
+        return ctx.readback(hip.BUF_RAW).copy()
+
+    monkeypatch.setenv("HOSTSIM_BVH4", "1")
+    monkeypatch.setenv("HOSTSIM_REFINE", "0")
+    ref = frame(hostsim_lib, False)
+    monkeypatch.setenv("RAYHIP_REFINE_LEAVES", "0")
+    plain = frame(gpu_lib, True)
+    monkeypatch.delenv("RAYHIP_REFINE_LEAVES")
+    refined = frame(gpu_lib, True)
+
+    def outside(img):
+        bad = np.abs(img[..., :3] - ref[..., :3]).max(axis=-1) > util.TOL_REL * np.maximum(1.0, np.abs(ref[..., :3]).max(axis=-1))
+        ys, xs = np.nonzero(bad)
+        return set(zip(xs.tolist(), ys.tolist()))
+    assert outside(plain) == set()
+    assert outside(refined) <= t["pixels"]
