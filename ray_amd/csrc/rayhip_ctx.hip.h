@@ -101,6 +101,7 @@ struct rayhip_ctx {
     };
     UNetPass unet_pass[16];
     DevBuf unet_tensor[15];
+    DevBuf unet_images; // the renderer's three images as one 16-channel tensor (unet_kernels.hip: k_image_inputs)
     int unet_w = 0, unet_h = 0; // frame size the tensors were sized for
     bool unet_ready = false;
     SceneView sc = {};
@@ -532,6 +533,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
     for (DevBuf &b : c->unet_tensor) {
         b.release();
     }
+    c->unet_images.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

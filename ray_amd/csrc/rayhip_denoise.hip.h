@@ -143,6 +143,10 @@ int unet_tensors(rayhip_ctx *c) {
             return 1;
         }
     }
+    c->unet_images.release(); // the three images as a tensor (zero outside the image: never written there)
+    if (c->unet_images.alloc(size_t(wr + 2) * size_t(hr + 2) * size_t(rt::unet::CHUNK) * sizeof(float))) {
+        return 1;
+    }
     c->unet_w = c->w, c->unet_h = c->h;
     return 0;
 }
@@ -193,9 +197,15 @@ int rayhip_denoise_unet(rayhip_ctx *c, const rayhip_camera *cam, const int rect[
         if (d.b >= 0) {
             cp.b = unet_interior(c, d.b), cp.b_stride = wr / UNET_TENSOR_DIV[d.b] + 2, cp.b_ch = d.b_ch;
         }
-        if (d.img) {
-            cp.img_full = c->px.full, cp.img_base = c->px.base_color, cp.img_dn = c->px.depth_normals;
-            cp.img_w = c->w, cp.img_h = c->h;
+        if (d.img) { // the three images as a 16-channel tensor: the first input of pass 0, the second one of dec_conv1a
+            float *img16 = c->unet_images.as<float>() + size_t(wr + 3) * size_t(rt::unet::CHUNK);
+            HIP_TRY(rt::unet::launch_image_inputs(c->px.full, c->px.base_color, c->px.depth_normals, c->w, c->h, img16, wr + 2,
+                                                  grid_for(c, size_t(c->w) * size_t(c->h), 256), c->stream));
+            if (d.a >= 0) {
+                cp.b = img16, cp.b_stride = wr + 2, cp.b_ch = rt::unet::CHUNK;
+            } else {
+                cp.a = img16, cp.a_stride = wr + 2, cp.a_ch = rt::unet::CHUNK, cp.a_up = 0;
+            }
         }
         cp.weights = c->unet_pass[p].weights.as<float>(), cp.bias = c->unet_pass[p].bias.as<float>();
         cp.x0 = rx, cp.y0 = ry, cp.w = rw, cp.h = rh;

@@ -20,7 +20,7 @@
 namespace rt {
 namespace unet {
 
-constexpr int TILE_H = 8, TILE_W = 16; // output pixels per workgroup (4 wavefronts x 2 rows of 16 pixels)
+constexpr int TILE_W = 16;              // output pixels per row of a workgroup's tile (its height: 4 wavefronts x 4 or 2 rows, unet_kernels.hip)
 constexpr int CHUNK = 16;              // input channels staged through LDS at a time
 
 // padded out-channel pitch of the weight rows in LDS and HBM: a multiple of 16 whose residue mod 64 is 16 or 48, so that the
@@ -34,9 +34,7 @@ struct ConvParams {
     // second input (concatenated behind the first): another tensor ...
     const float *b;
     int b_stride, b_ch;
-    // ... or the renderer's three images (radiance: HDR transfer; base colour: as is; depth-normals: 0.5 n + 0.5), 9 channels
-    const float4 *img_full, *img_base, *img_dn;
-    int img_w, img_h;
+    // (the renderer's three images enter as a tensor too: launch_image_inputs writes them as 16 channels, nine used)
     const float *weights; // [chunk][tap][CHUNK][weight_pitch] (rayhip.hip: repack_conv)
     const float *bias;    // [weight_pitch]
     float *out;           // interior pointer of the output tensor, or the float4 image of the last pass
@@ -46,6 +44,10 @@ struct ConvParams {
     int pool;         // 2 x 2 max pooling: one output pixel per 2 x 2 block, at (y / 2, x / 2)
     int final_image;  // last pass: 3 channels through the inverse HDR transfer into a float4 image of pitch out_stride
 };
+
+// the three images (radiance through the HDR transfer, base colour, depth-normals as 0.5 n + 0.5) -> the interior of a 16-channel tensor
+hipError_t launch_image_inputs(const float4 *full, const float4 *base, const float4 *dn, int w, int h, float *out, int out_stride, int blocks,
+                               hipStream_t stream);
 
 // n_tiles = out channels / 16 rounded up (1 .. 7)
 hipError_t launch_conv(const ConvParams &p, int n_tiles, hipStream_t stream);

@@ -2,8 +2,9 @@
 //
 // Workgroup = 4 wavefronts = an 8 x 16 tile of output pixels x ALL output channels.  The K dimension (9 taps x input
 // channels) is walked in chunks of 16 channels: the chunk's (8 + 2) x (16 + 2) input patch and its 9 x 16 x N weight rows
-// are staged in LDS (patch pixels 17 floats apart, weight rows at a pitch that spreads the four k-rows of a fetch over the
-// four 16-bank groups: both operand fetches of a wavefront are conflict-free), then every wavefront issues, per tap and per
+// are staged in LDS (patch pixels 20 floats apart, weight rows at a pitch that spreads the four k-rows of a fetch over the
+// four 16-bank groups: both operand fetches of a wavefront are conflict-free; since round 4 patch pixels are 20 floats apart and the
+// staging is software-pipelined, see k_conv3x3), then every wavefront issues, per tap and per
 // 4 channels, one A fetch per pixel row and one B fetch per 16 output channels and 2 x n_tiles v_mfma_f32_16x16x4_f32:
 //   A operand  lane l: pixel m = l & 15 of the row, channel k = l >> 4        (16 pixels x 4 channels)
 //   B operand  lane l: out channel n = l & 15,      channel k = l >> 4        (4 channels x 16 out channels)
@@ -18,9 +19,10 @@ namespace rt {
 namespace unet {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-constexpr int PATCH_W = TILE_W + 2, PATCH_H = TILE_H + 2;
-constexpr int PATCH_PITCH = CHUNK + 1; // floats per staged pixel (odd: 16 pixels x 4 channels land in distinct banks)
+constexpr int PATCH_W = TILE_W + 2;
+constexpr int PATCH_PITCH = CHUNK + 4; // floats per staged pixel: 16-byte aligned, and 20 m mod 64 spreads the 16 pixels of an A fetch over the banks
 
 // Convolution.h:66-113 (namespace transfer)
 __device__ __forceinline__ float transfer_in_hdr(const float val) {
@@ -45,78 +47,151 @@ __device__ __forceinline__ float transfer_out_hdr(float val) {
     return expf((val - g) / e) - f;
 }
 
-template <int NT> __global__ void __launch_bounds__(256) k_conv3x3(const ConvParams p) {
+// Staging, round 4.  Round 3 staged every chunk element by element (a division chain and a bounds test per float, the global load
+// consumed by the very next LDS store) between two barriers, with the matrix cores idle: 43 % of their f32 peak.  Now
+//   * a thread moves 16-byte pieces: four channels of one patch pixel (NHWC: contiguous), four consecutive weights; which pixels a
+//     thread serves, where they live in the inputs and in LDS, and whether they are inside the tensor is worked out ONCE, before the
+//     chunk loop (the patch geometry does not depend on the chunk);
+//   * the global loads of chunk c + 1 are issued BEFORE the matrix instructions of chunk c and land in registers while those run; only
+//     the short register -> LDS copy stands between the two barriers of a chunk (software pipelining through registers: the LDS chunk
+//     stays single, so the occupancy does);
+//   * patch pixels are 20 floats apart (16-byte aligned for ds_write_b128; 20 m mod 64 is a different multiple of four for each of the 16
+//     pixels of an A fetch, so the four channels of the four k-lanes still land in 64 different banks).
+// The nine image channels of the first and of the third-last pass are a tensor like any other: k_image_inputs below writes them once.
+// ROWS pixel rows per wavefront (a workgroup's tile is 4 ROWS x 16 pixels): every B fetch feeds ROWS matrix instructions and a chunk's
+// weights are staged once per 4 ROWS x 16 pixels -- 4 where the accumulators (4 ROWS NT registers) and the LDS footprint leave the
+// occupancy where it was (NT <= 4: the full- and half-resolution passes, 90 % of the arithmetic), 2 for the wide low-resolution passes.
+template <int NT, int ROWS> __global__ void __launch_bounds__(256) k_conv3x3(const ConvParams p) {
+    constexpr int TILE_H = 4 * ROWS, PATCH_H = TILE_H + 2;
     constexpr int WP = weight_pitch(NT);
-    __shared__ float s_patch[PATCH_H * PATCH_W * PATCH_PITCH];
-    __shared__ float s_w[9 * CHUNK * WP];
+    constexpr int W4 = 9 * CHUNK * WP / 4, W4_PER_THREAD = (W4 + 255) / 256;               // 16-byte pieces of a weight chunk
+    constexpr int P4 = PATCH_H * PATCH_W * (CHUNK / 4), P4_PER_THREAD = (P4 + 255) / 256; // ... of a patch chunk
+    __shared__ __attribute__((aligned(16))) float s_patch[PATCH_H * PATCH_W * PATCH_PITCH];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * CHUNK * WP];
 
     const int tiles_x = (p.w + TILE_W - 1) / TILE_W;
     const int tx0 = p.x0 + int(blockIdx.x % tiles_x) * TILE_W, ty0 = p.y0 + int(blockIdx.x / tiles_x) * TILE_H;
-    const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+    const int tid = int(threadIdx.x), lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
-    const int r0 = 2 * wave; // this wavefront's two pixel rows of the tile
+    const int r0 = ROWS * wave; // this wavefront's pixel rows of the tile
 
-    f32x4 acc[2][NT];
+    f32x4 acc[ROWS][NT];
     for (int nt = 0; nt < NT; ++nt) {
         const float bias = p.bias[nt * 16 + m];
-        acc[0][nt] = f32x4{bias, bias, bias, bias};
-        acc[1][nt] = acc[0][nt];
+        for (int r = 0; r < ROWS; ++r) {
+            acc[r][nt] = f32x4{bias, bias, bias, bias};
+        }
     }
 
-    const int chunks_a = p.a ? p.a_ch / CHUNK : 0, chunks_b = p.b ? p.b_ch / CHUNK : 0, chunks_img = p.img_full ? 1 : 0;
-    const int n_chunks = chunks_a + chunks_b + chunks_img;
+    const int chunks_a = p.a ? p.a_ch / CHUNK : 0, chunks_b = p.b ? p.b_ch / CHUNK : 0;
+    const int n_chunks = chunks_a + chunks_b;
+
+    // the patch pieces of this thread: piece e = tid + 256 j is channels 4 (e & 3) .. + 3 of patch pixel e >> 2.  Kept per piece: the
+    // pixel's index in each input tensor (32 bits: a tensor has < 2^31 floats) and one bit "inside the tensor, border included"
+    static_assert(P4_PER_THREAD <= 8, "piece indices are kept in 8-wide native vectors");
+    i32x8 piece_a = {0, 0, 0, 0, 0, 0, 0, 0}, piece_b = piece_a; // (native vectors, indexed by unrolled constants: registers, not scratch)
+    uint32_t inside = 0;
+#pragma unroll
+    for (int j = 0; j < P4_PER_THREAD; ++j) {
+        const int e = tid + 256 * j, pixel = e >> 2;
+        const int px = pixel % PATCH_W, py = pixel / PATCH_W;
+        const int X = tx0 - 1 + px, Y = ty0 - 1 + py; // coordinates in this pass's resolution
+        const bool in = e < P4 && X >= -1 && X <= p.in_w && Y >= -1 && Y <= p.in_h; // (the tensors carry a one-pixel zero border)
+        inside |= in ? (1u << j) : 0u;
+        const int sx = p.a_up ? (X >> 1) : X, sy = p.a_up ? (Y >> 1) : Y; // (arithmetic shift: -1 stays on the border)
+        piece_a[j] = in ? sy * p.a_stride + sx : 0;
+        piece_b[j] = in ? Y * p.b_stride + X : 0;
+    }
+    const int quad4 = (tid & 3) * 4; // (256 is a multiple of 4: every piece of a thread is the same channel quad)
+
+    f32x4 held_patch[P4_PER_THREAD], held_w[W4_PER_THREAD]; // (native vectors: the arrays must become registers)
+    // chunk `ch` -> registers
+    auto fetch = [&](const int ch) __attribute__((always_inline)) {
+        const bool from_a = ch < chunks_a;
+        const float *src = from_a ? p.a + ch * CHUNK + quad4 : p.b + (ch - chunks_a) * CHUNK + quad4;
+        const int n_ch = from_a ? p.a_ch : p.b_ch;
+#pragma unroll
+        for (int j = 0; j < P4_PER_THREAD; ++j) {
+            held_patch[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if ((inside >> j) & 1u) {
+                held_patch[j] = *reinterpret_cast<const f32x4 *>(src + ptrdiff_t(from_a ? piece_a[j] : piece_b[j]) * n_ch);
+            }
+        }
+        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(p.weights + size_t(ch) * size_t(9 * CHUNK * WP));
+#pragma unroll
+        for (int j = 0; j < W4_PER_THREAD; ++j) {
+            const int i = tid + 256 * j;
+            held_w[j] = wsrc[(W4 % 256 == 0 || i < W4) ? i : W4 - 1]; // (the last round is partial: a clamped, unused load)
+        }
+    };
+    // registers -> LDS
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < P4_PER_THREAD; ++j) {
+            const int e = tid + 256 * j;
+            if (P4 % 256 == 0 || e < P4) {
+                *reinterpret_cast<f32x4 *>(&s_patch[(e >> 2) * PATCH_PITCH + quad4]) = held_patch[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < W4_PER_THREAD; ++j) {
+            const int i = tid + 256 * j;
+            if (W4 % 256 == 0 || i < W4) {
+                reinterpret_cast<f32x4 *>(s_w)[i] = held_w[j];
+            }
+        }
+    };
+
+    fetch(0);
     for (int ch = 0; ch < n_chunks; ++ch) {
         __syncthreads(); // (the previous chunk's readers are done)
-        // ---- stage the input patch of this chunk: PATCH_H x PATCH_W pixels x CHUNK channels
-        for (int i = int(threadIdx.x); i < PATCH_H * PATCH_W * CHUNK; i += 256) {
-            const int c = i % CHUNK, px = (i / CHUNK) % PATCH_W, py = i / (CHUNK * PATCH_W);
-            const int X = tx0 - 1 + px, Y = ty0 - 1 + py; // coordinates in this pass's resolution
-            float v = 0.0f;
-            if (ch < chunks_a) {
-                if (X >= -1 && X <= p.in_w && Y >= -1 && Y <= p.in_h) {
-                    const int sx = p.a_up ? (X >> 1) : X, sy = p.a_up ? (Y >> 1) : Y; // (arithmetic shift: -1 stays on the border)
-                    v = p.a[(ptrdiff_t(sy) * p.a_stride + sx) * p.a_ch + ch * CHUNK + c];
-                }
-            } else if (ch < chunks_a + chunks_b) {
-                if (X >= -1 && X <= p.in_w && Y >= -1 && Y <= p.in_h) {
-                    v = p.b[(ptrdiff_t(Y) * p.b_stride + X) * p.b_ch + (ch - chunks_a) * CHUNK + c];
-                }
-            } else if (c < 9 && X >= 0 && X < p.img_w && Y >= 0 && Y < p.img_h) {
-                const size_t idx = size_t(Y) * size_t(p.img_w) + size_t(X);
-                const float4 *img = c < 3 ? p.img_full : (c < 6 ? p.img_base : p.img_dn);
-                const float4 t = img[idx];
-                const int cc = c % 3;
-                const float s = cc == 0 ? t.x : (cc == 1 ? t.y : t.z);
-                v = c < 3 ? transfer_in_hdr(s) : (c < 6 ? s : 0.5f * s + 0.5f);
-            }
-            s_patch[(py * PATCH_W + px) * PATCH_PITCH + c] = v;
-        }
-        // ---- and its weights: 9 taps x CHUNK channels x WP, contiguous in HBM
-        {
-            const float *src = p.weights + size_t(ch) * size_t(9 * CHUNK * WP);
-            for (int i = int(threadIdx.x); i < 9 * CHUNK * WP; i += 256) {
-                s_w[i] = src[i];
-            }
-        }
+        commit();
         __syncthreads();
+        if (ch + 1 < n_chunks) {
+            fetch(ch + 1); // in flight while the matrix instructions below run
+        }
+        // 36 steps (tap, four channels) of ROWS x NT matrix instructions each.  The operands of step s + 1 are requested from LDS BEFORE the
+        // matrix instructions of step s are issued and are waited for after them (the compiler, left alone, put every ds_read directly in
+        // front of its first use: an LDS round trip in front of every group of matrix instructions); the scheduling barriers pin that order.
+        float a_now[ROWS], b_now[NT], a_next[ROWS], b_next[NT];
+        auto operands = [&](const int step, float (&a)[ROWS], float (&b)[NT]) __attribute__((always_inline)) {
+            const int tap = step / (CHUNK / 4), k4 = step % (CHUNK / 4), ky = tap / 3, kx = tap % 3;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
+            for (int r = 0; r < ROWS; ++r) {
+                a[r] = s_patch[((r0 + r + ky) * PATCH_W + (m + kx)) * PATCH_PITCH + k4 * 4 + kq];
+            }
 #pragma unroll
-            for (int k4 = 0; k4 < CHUNK / 4; ++k4) {
-                const float a0 = s_patch[((r0 + ky) * PATCH_W + (m + kx)) * PATCH_PITCH + k4 * 4 + kq];
-                const float a1 = s_patch[((r0 + 1 + ky) * PATCH_W + (m + kx)) * PATCH_PITCH + k4 * 4 + kq];
+            for (int nt = 0; nt < NT; ++nt) {
+                b[nt] = s_w[(tap * CHUNK + k4 * 4 + kq) * WP + nt * 16 + m];
+            }
+        };
+        operands(0, a_now, b_now);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float b = s_w[(tap * CHUNK + k4 * 4 + kq) * WP + nt * 16 + m];
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][nt], 0, 0, 0);
+        for (int step = 0; step < 9 * (CHUNK / 4); ++step) {
+            if (step + 1 < 9 * (CHUNK / 4)) {
+                operands(step + 1, a_next, b_next);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_now[r], b_now[nt], acc[r][nt], 0, 0, 0);
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                a_now[r] = a_next[r];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                b_now[nt] = b_next[nt];
             }
         }
     }
 
-    // ---- epilogue: lane holds out channel nt * 16 + m for the pixels x = tx0 + 4 kq + 0 .. 3 of rows ty0 + r0, ty0 + r0 + 1
+    // ---- epilogue: lane holds out channel nt * 16 + m for the pixels x = tx0 + 4 kq + 0 .. 3 of rows ty0 + r0 .. + ROWS - 1
     const int xe = p.x0 + p.w, ye = p.y0 + p.h;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -125,20 +200,25 @@ template <int NT> __global__ void __launch_bounds__(256) k_conv3x3(const ConvPar
             continue;
         }
         if (p.pool) {
-            const int y = ty0 + r0;
-            if (y < ye) {
+#pragma unroll
+            for (int rp = 0; rp < ROWS; rp += 2) { // (row pairs: r0 and ROWS are even)
+                const int y = ty0 + r0 + rp;
+                if (y >= ye) {
+                    continue;
+                }
                 for (int pr = 0; pr < 2; ++pr) {
                     const int x = tx0 + 4 * kq + 2 * pr;
                     if (x < xe) {
-                        float v = fmaxf(fmaxf(fmaxf(acc[0][nt][2 * pr], 0.0f), fmaxf(acc[0][nt][2 * pr + 1], 0.0f)),
-                                        fmaxf(fmaxf(acc[1][nt][2 * pr], 0.0f), fmaxf(acc[1][nt][2 * pr + 1], 0.0f)));
+                        float v = fmaxf(fmaxf(fmaxf(acc[rp][nt][2 * pr], 0.0f), fmaxf(acc[rp][nt][2 * pr + 1], 0.0f)),
+                                        fmaxf(fmaxf(acc[rp + 1][nt][2 * pr], 0.0f), fmaxf(acc[rp + 1][nt][2 * pr + 1], 0.0f)));
                         v = fmaxf(v, 0.0f);
                         p.out[(ptrdiff_t(y / 2) * p.out_stride + (x / 2)) * p.out_ch + n] = v;
                     }
                 }
             }
         } else {
-            for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
                 const int y = ty0 + r0 + rr;
                 if (y >= ye) {
                     continue;
@@ -160,35 +240,59 @@ template <int NT> __global__ void __launch_bounds__(256) k_conv3x3(const ConvPar
     }
 }
 
-hipError_t launch_conv(const ConvParams &p, const int n_tiles, hipStream_t stream) {
-    const int tiles = ((p.w + TILE_W - 1) / TILE_W) * ((p.h + TILE_H - 1) / TILE_H);
-    if (tiles <= 0) {
-        return hipSuccess;
+// The renderer's three images as ONE 16-channel tensor (nine used: radiance through the HDR transfer function, base colour as it is,
+// depth-normals as 0.5 n + 0.5; Convolution.h:222-244): what the first pass convolves and what dec_conv1a concatenates.  Rounds 1-3
+// evaluated the transfer function (powf / logf) inside the convolution's staging, once per tile that touches the pixel and between the
+// two barriers of the chunk; now it is evaluated once per pixel and the convolution stages the result like any other tensor.
+// Pixels of the padded tensor outside the image stay zero (they are never written).
+__global__ void __launch_bounds__(256) k_image_inputs(const float4 *__restrict__ full, const float4 *__restrict__ base, const float4 *__restrict__ dn,
+                                                     const int w, const int h, float *__restrict__ out, const int out_stride) {
+    const int n = w * h;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int x = i % w, y = i / w;
+        const float4 a = full[i], b = base[i], c = dn[i];
+        f32x4 *o = reinterpret_cast<f32x4 *>(out + (ptrdiff_t(y) * out_stride + x) * CHUNK);
+        o[0] = f32x4{transfer_in_hdr(a.x), transfer_in_hdr(a.y), transfer_in_hdr(a.z), b.x};
+        o[1] = f32x4{b.y, b.z, 0.5f * c.x + 0.5f, 0.5f * c.y + 0.5f};
+        o[2] = f32x4{0.5f * c.z + 0.5f, 0.0f, 0.0f, 0.0f};
+        o[3] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
+}
+
+hipError_t launch_image_inputs(const float4 *full, const float4 *base, const float4 *dn, const int w, const int h, float *out, const int out_stride,
+                               const int blocks, hipStream_t stream) {
+    k_image_inputs<<<blocks, 256, 0, stream>>>(full, base, dn, w, h, out, out_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvParams &p, const int n_tiles, hipStream_t stream) {
+    if (n_tiles < 1 || n_tiles > 7 || p.w <= 0 || p.h <= 0) {
+        return n_tiles < 1 || n_tiles > 7 ? hipErrorInvalidValue : hipSuccess;
+    }
+    const int rows = n_tiles <= 4 ? 4 : 2, tile_h = 4 * rows;
+    const int tiles = ((p.w + TILE_W - 1) / TILE_W) * ((p.h + tile_h - 1) / tile_h);
     switch (n_tiles) {
     case 1:
-        k_conv3x3<1><<<tiles, 256, 0, stream>>>(p);
+        k_conv3x3<1, 4><<<tiles, 256, 0, stream>>>(p);
         break;
     case 2:
-        k_conv3x3<2><<<tiles, 256, 0, stream>>>(p);
+        k_conv3x3<2, 4><<<tiles, 256, 0, stream>>>(p);
         break;
     case 3:
-        k_conv3x3<3><<<tiles, 256, 0, stream>>>(p);
+        k_conv3x3<3, 4><<<tiles, 256, 0, stream>>>(p);
         break;
     case 4:
-        k_conv3x3<4><<<tiles, 256, 0, stream>>>(p);
+        k_conv3x3<4, 4><<<tiles, 256, 0, stream>>>(p);
         break;
     case 5:
-        k_conv3x3<5><<<tiles, 256, 0, stream>>>(p);
+        k_conv3x3<5, 2><<<tiles, 256, 0, stream>>>(p);
         break;
     case 6:
-        k_conv3x3<6><<<tiles, 256, 0, stream>>>(p);
-        break;
-    case 7:
-        k_conv3x3<7><<<tiles, 256, 0, stream>>>(p);
+        k_conv3x3<6, 2><<<tiles, 256, 0, stream>>>(p);
         break;
     default:
-        return hipErrorInvalidValue;
+        k_conv3x3<7, 2><<<tiles, 256, 0, stream>>>(p);
+        break;
     }
     return hipGetLastError();
 }
