@@ -176,6 +176,36 @@ typedef struct rayhip_camera {
 /* Flat scene: what reference RendererCPU.h:390-413 gathers into scene_data_t before every RenderScene.
  * All pointers are HOST pointers; counts are element counts (capacity of the sparse pools, since the
  * indices stored in the arrays are pool slots). */
+/* == Ray::atmosphere_params_t (reference SceneBase.h:314-341), field for field: the physical sky's parameters */
+typedef struct __attribute__((aligned(16))) rayhip_atmosphere {
+    float planet_radius, viewpoint_height, atmosphere_height, rayleigh_height, mie_height;
+    float clouds_height_beg, clouds_height_end, clouds_variety, clouds_density;
+    float clouds_offset_x, clouds_offset_z, clouds_flutter_x, clouds_flutter_z;
+    float cirrus_clouds_amount, cirrus_clouds_height;
+    float ozone_height_center, ozone_half_width, atmosphere_density;
+    float stars_brightness, moon_radius, moon_distance;
+    float moon_dir[4] __attribute__((aligned(16)));
+    float rayleigh_scattering[4], mie_scattering[4], mie_extinction[4], mie_absorption[4], ozone_absorption[4], ground_albedo[4];
+} rayhip_atmosphere; /* 208 B */
+
+/* The physical sky (environment_t::env_map == PhysicalSkyTexture: env.sky_map_spread_angle > 0).  Rays wider than that angle read
+ * the baked environment map like any other (the reference bakes it on the host, SceneCPU.cpp:1017-1056, and so does SceneHIP); rays
+ * narrower than it -- camera rays, mirror bounces -- are evaluated analytically (ShadeSkyPrimary / ShadeSkySecondary,
+ * RendererCPU.h:484-486, 555-557; AtmosphereRef.cpp), which needs what this struct names: the atmosphere, the two look-up tables
+ * the scene computes from it (SceneCommon.cpp:186-283), the indices of the directional lights (the suns), and the five textures the
+ * reference compiles in (internal/precomputed: weather map, 3-d noise, curl noise, moon albedo, cirrus).  One element or none. */
+typedef struct rayhip_sky {
+    rayhip_atmosphere atmosphere;
+    int32_t transmittance_lut_w, transmittance_lut_h; /* rayhip_scene_desc::sky_transmittance_lut: w * h * 4 floats */
+    int32_t multiscatter_lut_res;                     /* ... sky_multiscatter_lut: res * res * 4 floats (0: none) */
+    int32_t weather_res;                              /* sky_weather_tex: res * res * 3 bytes */
+    int32_t noise3d_res;                              /* sky_noise3d_tex: res^3 bytes */
+    int32_t curl_res;                                 /* sky_curl_tex: res * res * 3 bytes */
+    int32_t moon_w, moon_h;                           /* sky_moon_tex: w * h * 3 bytes */
+    int32_t cirrus_res;                               /* sky_cirrus_tex: res * res * 2 bytes */
+    int32_t _pad[3];
+} rayhip_sky; /* 256 B */
+
 typedef struct rayhip_scene_desc {
     const rayhip_bvh2_node *nodes;
     uint32_t nodes_count;
@@ -215,6 +245,17 @@ typedef struct rayhip_scene_desc {
     uint32_t blocker_lights_count;
     float bbox_min[3], bbox_max[3]; /* Scene::GetBounds (SceneCPU.cpp:1523), feeds the ray-sort grid only */
     uint32_t texture_flags;         /* RAYHIP_TEX_* */
+    /* the physical sky (see rayhip_sky): all null / 0 unless env.sky_map_spread_angle > 0 */
+    const rayhip_sky *sky;
+    uint32_t sky_count; /* 0 or 1 */
+    const float *sky_transmittance_lut;
+    uint32_t sky_transmittance_lut_count;
+    const float *sky_multiscatter_lut;
+    uint32_t sky_multiscatter_lut_count;
+    const uint32_t *sky_dir_lights; /* indices into `lights` of the LIGHT_TYPE_DIR lights (Scene::dir_lights_) */
+    uint32_t sky_dir_lights_count;
+    const uint8_t *sky_weather_tex, *sky_noise3d_tex, *sky_curl_tex, *sky_moon_tex, *sky_cirrus_tex;
+    uint32_t sky_weather_tex_count, sky_noise3d_tex_count, sky_curl_tex_count, sky_moon_tex_count, sky_cirrus_tex_count; /* bytes */
 } rayhip_scene_desc;
 
 /* rayhip_scene_desc::texture_flags.  RAW_BC: the textures of the four block-compressed storages (tex_table[4..7]: BC1,

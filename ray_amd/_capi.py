@@ -8,6 +8,7 @@ import ctypes as C
 
 ray_handle = C.c_uint64
 INVALID_HANDLE = 0xFFFFFFFF
+PHYSICAL_SKY_TEXTURE = 0xFFFFFFFE  # Ray::PhysicalSkyTexture (SceneBase.h:35)
 
 
 class ShadingNodeDesc(C.Structure):  # ray_shading_node_desc
@@ -182,6 +183,13 @@ class EnvDesc(C.Structure):  # ray_env_desc
         ("env_map_rotation", C.c_float),
         ("back_map_rotation", C.c_float),
         ("importance_sample", C.c_int32),
+        ("envmap_resolution", C.c_int32),
+        ("clouds_density", C.c_float),
+        ("cirrus_clouds_amount", C.c_float),
+        ("stars_brightness", C.c_float),
+        ("moon_radius", C.c_float),
+        ("clouds_offset_x", C.c_float),
+        ("clouds_offset_z", C.c_float),
     ]
 
 

@@ -67,6 +67,7 @@ class eAUXBuffer(IntEnum):  # Types.h:47
 
 
 InvalidHandle = _capi.INVALID_HANDLE
+PhysicalSkyTexture = _capi.PHYSICAL_SKY_TEXTURE  # as env_map / back_map: the analytic sky, lit by the scene's directional lights
 
 
 @dataclass
@@ -139,12 +140,14 @@ class SceneBase:
 
     # -- environment ---------------------------------------------------------------------------------------
     def SetEnvironment(self, env_col=(0.0, 0.0, 0.0), back_col=(0.0, 0.0, 0.0), env_map=InvalidHandle,
-                       back_map=InvalidHandle, env_map_rotation=0.0, back_map_rotation=0.0, importance_sample=True):
+                       back_map=InvalidHandle, env_map_rotation=0.0, back_map_rotation=0.0, importance_sample=True, **atmosphere):
+        """atmosphere: envmap_resolution, clouds_density, cirrus_clouds_amount, stars_brightness, moon_radius, clouds_offset_x / _z
+        (environment_desc_t::envmap_resolution and atmosphere_params_t, SceneBase.h:314-353); the rest stays at its default"""
         d = _capi.EnvDesc()
         self._lib.ray_default_env(C.byref(d))
         _set(d, env_col=env_col, back_col=back_col, env_map=env_map, back_map=back_map,
              env_map_rotation=env_map_rotation, back_map_rotation=back_map_rotation,
-             importance_sample=int(importance_sample))
+             importance_sample=int(importance_sample), **atmosphere)
         self._lib.ray_scene_set_environment(self._ptr, C.byref(d))
 
     # -- textures / materials ----------------------------------------------------------------------------------

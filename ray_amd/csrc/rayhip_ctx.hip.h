@@ -101,6 +101,9 @@ struct rayhip_ctx {
     };
     UNetPass unet_pass[16];
     DevBuf unet_tensor[15];
+    DevBuf sky_desc, sky_transmittance_lut, sky_multiscatter_lut, sky_dir_lights, sky_weather, sky_noise3d, sky_curl, sky_moon, sky_cirrus; // the physical sky (rt_sky.h)
+    SkyView sky_view = {};
+    DevBuf sky_index;  // ray slots of the paths that ended in the physical sky, per stripe (k_surface -> k_shade_sky)
     DevBuf unet_images; // the renderer's three images as one 16-channel tensor (unet_kernels.hip: k_image_inputs)
     int unet_w = 0, unet_h = 0; // frame size the tensors were sized for
     bool unet_ready = false;
@@ -162,12 +165,13 @@ struct rayhip_ctx {
     double stage_us[11] = {};
 
     static constexpr size_t QUEUE_WORDS = size_t(QUEUE_MAX_STRIPES) * QUEUE_COUNTER_STRIDE;
-    static constexpr int QUEUES_PER_BOUNCE = 5;
+    static constexpr int QUEUES_PER_BOUNCE = 6;
     uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b) * QUEUE_WORDS; }
     uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 1) * QUEUE_WORDS; }
     uint32_t *deferred_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 2) * QUEUE_WORDS; }
     uint32_t *point_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 3) * QUEUE_WORDS; }
     uint32_t *nee_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 4) * QUEUE_WORDS; }
+    uint32_t *sky_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 5) * QUEUE_WORDS; }
     // queue geometry for a frame of `items` pixels split over `stripes` stripes
     static RayQueue make_queue(uint32_t *counts, size_t items, uint32_t stripes) {
         const size_t chunks = (items + WAVE - 1) / WAVE;
@@ -178,6 +182,7 @@ struct rayhip_ctx {
     RayQueue deferred_queue(int b, size_t items, uint32_t stripes) const { return make_queue(deferred_count(b), items, stripes); }
     RayQueue point_queue(int b, size_t items, uint32_t stripes) const { return make_queue(point_count(b), items, stripes); }
     RayQueue nee_queue(int b, size_t items, uint32_t stripes) const { return make_queue(nee_count(b), items, stripes); }
+    RayQueue sky_queue(int b, size_t items, uint32_t stripes) const { return make_queue(sky_count(b), items, stripes); }
     int clear_queues(int bounces, hipStream_t s) const {
         return hipMemsetAsync(counters.p, 0, size_t(QUEUES_PER_BOUNCE * bounces) * QUEUE_WORDS * sizeof(uint32_t), s) == hipSuccess ? 0 : 1;
     }
@@ -294,6 +299,9 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
         return 1;
     }
     c->points.nee_index = c->nee_index.as<uint32_t>();
+    if (c->sky_index.alloc(n * 4)) {
+        return 1;
+    }
     // the ray sort only runs on single-iteration passes
     const size_t n_sort = tile_slots(w, h) + size_t(WAVE) * QUEUE_MAX_STRIPES;
     size_t temp_bytes = 0;
@@ -534,6 +542,10 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         b.release();
     }
     c->unet_images.release();
+    for (DevBuf *b : {&c->sky_desc, &c->sky_transmittance_lut, &c->sky_multiscatter_lut, &c->sky_dir_lights, &c->sky_weather, &c->sky_noise3d, &c->sky_curl, &c->sky_moon,
+                      &c->sky_cirrus, &c->sky_index}) {
+        b->release();
+    }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

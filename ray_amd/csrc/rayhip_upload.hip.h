@@ -3,6 +3,32 @@
 // rayhip_scene_update_instances (top level rebuilt on the device), filter table, tonemap LUT, the blob forms.
 #pragma once
 
+// the physical sky (rayhip_sky + its tables and textures: 1.6 MB): device copies and the view the kernels read; the directional-light
+// list is part of it, so an instance / light update sends it again
+static int upload_sky(rayhip_ctx *c, const rayhip_scene_desc *d) {
+    c->sky_view = SkyView{};
+    if (!(d->env.sky_map_spread_angle > 0.0f) || d->sky_count == 0) {
+        return 0;
+    }
+    if (upload(c, c->sky_desc, d->sky, sizeof(rayhip_sky)) ||
+        upload(c, c->sky_transmittance_lut, d->sky_transmittance_lut, size_t(d->sky_transmittance_lut_count) * sizeof(float)) ||
+        upload(c, c->sky_multiscatter_lut, d->sky_multiscatter_lut, size_t(d->sky_multiscatter_lut_count) * sizeof(float)) ||
+        upload(c, c->sky_dir_lights, d->sky_dir_lights, size_t(d->sky_dir_lights_count) * sizeof(uint32_t)) ||
+        upload(c, c->sky_weather, d->sky_weather_tex, d->sky_weather_tex_count) || upload(c, c->sky_noise3d, d->sky_noise3d_tex, d->sky_noise3d_tex_count) ||
+        upload(c, c->sky_curl, d->sky_curl_tex, d->sky_curl_tex_count) || upload(c, c->sky_moon, d->sky_moon_tex, d->sky_moon_tex_count) ||
+        upload(c, c->sky_cirrus, d->sky_cirrus_tex, d->sky_cirrus_tex_count)) {
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    SkyView &v = c->sky_view;
+    v.desc = c->sky_desc.as<rayhip_sky>();
+    v.transmittance_lut = c->sky_transmittance_lut.as<float>(), v.multiscatter_lut = c->sky_multiscatter_lut.as<float>();
+    v.dir_lights = c->sky_dir_lights.as<uint32_t>(), v.dir_lights_count = d->sky_dir_lights_count;
+    v.weather = c->sky_weather.as<uint8_t>(), v.noise3d = c->sky_noise3d.as<uint8_t>(), v.curl = c->sky_curl.as<uint8_t>();
+    v.moon = c->sky_moon.as<uint8_t>(), v.cirrus = c->sky_cirrus.as<uint8_t>();
+    return 0;
+}
+
 // lights, their index list, the light tree (+ its per-node importance table) and the world-space corners of the triangle
 // lights: everything an instance / light change replaces besides the top-level tree
 static int upload_lights(rayhip_ctx *c, const rayhip_scene_desc *d) {
@@ -105,6 +131,7 @@ static void refresh_scene_view(rayhip_ctx *c, const rayhip_scene_desc *d, const 
     v.blocker_lights_count = d->blocker_lights_count;
     v.tlas_root = tlas_root;
     v.env = d->env;
+    v.sky = c->sky_view;
     memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
     // ray-sort grid: true bounds of the TLAS root (Scene::GetBounds takes fminf for the max corner, SceneCPU.cpp:1553)
     for (int i = 0; i < 3; ++i) {
@@ -135,12 +162,8 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     if (d->env.qtree_levels < 0 || d->env.qtree_levels > 16) {
         return fail("bad env-map quadtree depth %d", d->env.qtree_levels);
     }
-    if (d->env.sky_map_spread_angle > 0.0f) {
-        // With PhysicalSkyTexture the reference evaluates narrow rays analytically (ShadeSky*, AtmosphereRef.cpp: SURVEY
-        // section 2, out of scope) and only wide ones through the baked map; rendering all of them from the map would be
-        // a silently different image.
-        return fail("the physical sky (environment_t::sky_map_spread_angle > 0) is not supported by the HIP backend");
-    }
+    // (the physical sky, environment_t::sky_map_spread_angle > 0: narrow rays are evaluated analytically, rt_sky.h; what that needs
+    // arrives as rayhip_scene_desc::sky* and is checked by the validation below)
     {
         size_t quads = 0;
         for (int lod = 0; lod < d->env.qtree_levels; ++lod) {
@@ -388,6 +411,9 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         if (d->tlas_root != 0xffffffffu && d->tlas_root < d->nodes_count) {
             root_box = rayhip_rebuild::node_box(d->nodes[d->tlas_root]);
         }
+        if (upload_sky(c, d)) {
+            return 1;
+        }
         refresh_scene_view(c, d, tlas_root, root_box, count_top_level_instances(d->nodes, d->nodes_count, d->tlas_root));
     }
     c->have_scene = true;
@@ -430,8 +456,11 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
     if (d->env.qtree_levels < 0 || d->env.qtree_levels > 16) {
         return fail("bad env-map quadtree depth %d", d->env.qtree_levels);
     }
-    if (d->env.sky_map_spread_angle > 0.0f) {
-        return fail("the physical sky (environment_t::sky_map_spread_angle > 0) is not supported by the HIP backend");
+    {
+        std::string why;
+        if (!rayhip_validate::validate_sky(*d, why)) {
+            return fail("%s", why.c_str());
+        }
     }
     {
         size_t quads = 0;
@@ -508,6 +537,9 @@ int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (upload_sky(c, d)) {
+        return 1;
+    }
     refresh_scene_view(c, d, tlas_root, root_box, uint32_t(live.size()));
     UPLOAD_TRACE("instances updated")
     return 0;

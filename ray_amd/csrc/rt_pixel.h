@@ -71,6 +71,14 @@ RT_HD void add_secondary_pixel(const ShadeResult &r, const uint32_t xy, const in
     temp_buf[idx] = o;
 }
 
+// ShadeSky tail, AtmosphereRef.cpp:1004-1007: temp += rgb, alpha = 1
+RT_HD void add_sky_pixel(const f3 c, const uint32_t xy, const int img_w, float4 *temp_buf) {
+    const int x = int((xy >> 16) & 0x0000ffff), y = int(xy & 0x0000ffff);
+    float4 o = temp_buf[y * img_w + x];
+    o.x += c.x, o.y += c.y, o.z += c.z, o.w = 1.0f;
+    temp_buf[y * img_w + x] = o;
+}
+
 // TraceShadowRays tail, CoreRef.cpp:4866-4880: clamp on the rgb sum, then temp += rc
 RT_HD void add_shadow_pixel(f3 rc, const float limit, const uint32_t xy, const int img_w, float4 *temp_buf) {
     const int x = int((xy >> 16) & 0x0000ffff), y = int(xy & 0x0000ffff);

@@ -6,6 +6,7 @@
 // one shadow ray.
 #pragma once
 
+#include "rt_sky.h"
 #include "shade_lobes.h"
 
 namespace rt {
@@ -15,6 +16,7 @@ struct ShadeResult {
     f3 base_color;   // first-hit feature images
     f4 depth_normal; // N.xyz, t
     bool emit_secondary, emit_shadow;
+    bool defer_sky; // the path ended in the physical sky: shade_sky_ray (rt_sky.h) adds its radiance to the pixel afterwards
 };
 
 // radiance the scatter stage books at once (lights that cast no shadow): throughput, then the indirect clamp
@@ -38,6 +40,7 @@ RT_HD ShadeResult shade_surface(const SceneView &sc, const ShadeParams &sp, cons
     res.col = so.radiance;
     res.base_color = so.base_color;
     res.depth_normal = so.normal_depth;
+    res.defer_sky = so.deferred_sky;
     if (!continues) {
         return res;
     }

@@ -19,6 +19,15 @@ namespace rt {
 struct Bvh4Node; // rt_bvh4.h
 struct Bvh8Node; // rt_bvh8.h
 
+// what the physical sky reads (rt_sky.h): rayhip_sky + the arrays it sizes; desc == null: the environment is not the physical sky
+struct SkyView {
+    const rayhip_sky *desc;
+    const float *transmittance_lut, *multiscatter_lut;
+    const uint32_t *dir_lights;
+    uint32_t dir_lights_count;
+    const uint8_t *weather, *noise3d, *curl, *moon, *cirrus;
+};
+
 // Device-side view of the flat scene (pointers into HBM).  Mirrors reference Core.h:511-535 scene_data_t.
 struct SceneView {
     const rayhip_bvh2_node *nodes;
@@ -54,6 +63,7 @@ struct SceneView {
     uint32_t blocker_lights_count;
     uint32_t tlas_root;
     rayhip_environment env;
+    SkyView sky;
 };
 
 // ---- light_t bitfield accessors (Core.h:197-205; GCC packs bitfields LSB first) --------------------

@@ -75,6 +75,17 @@ inline std::vector<uint8_t> serialize(const rayhip_scene_desc &d, const rayhip_c
     ARR(textures)
     ARR(texels)
     ARR(env_qtree)
+    if (d.sky_count != 0) { // the physical sky (rayhip_sky): present only when the environment is one
+        ARR(sky)
+        ARR(sky_transmittance_lut)
+        ARR(sky_multiscatter_lut)
+        ARR(sky_dir_lights)
+        ARR(sky_weather_tex)
+        ARR(sky_noise3d_tex)
+        ARR(sky_curl_tex)
+        ARR(sky_moon_tex)
+        ARR(sky_cirrus_tex)
+    }
 #undef ARR
     Scalars sc = {};
     memcpy(sc.tex_table, d.tex_table, sizeof(sc.tex_table));
@@ -169,6 +180,15 @@ inline bool deserialize(const void *blob, size_t size, rayhip_scene_desc &d, ray
         ARR(textures, rayhip_texture)
         ARR(texels, uint32_t)
         ARR(env_qtree, float)
+        ARR(sky, rayhip_sky)
+        ARR(sky_transmittance_lut, float)
+        ARR(sky_multiscatter_lut, float)
+        ARR(sky_dir_lights, uint32_t)
+        ARR(sky_weather_tex, uint8_t)
+        ARR(sky_noise3d_tex, uint8_t)
+        ARR(sky_curl_tex, uint8_t)
+        ARR(sky_moon_tex, uint8_t)
+        ARR(sky_cirrus_tex, uint8_t)
 #undef ARR
         if (name == "tonemap_lut") {
             int dims = 1;

@@ -66,10 +66,14 @@ inline bool walk_tree(const rayhip_scene_desc &d, const uint32_t root, std::vect
 }
 
 inline bool validate_lights(const rayhip_scene_desc &d, std::string &err);
+inline bool validate_sky(const rayhip_scene_desc &d, std::string &err);
 
 // `all_sides_solid` (optional): is every side of every REACHABLE triangle plainly solid?  (the triangle pool is sparse: unused slots hold
 // zeros, which would read as "not solid")
 inline bool validate(const rayhip_scene_desc &d, std::string &err, bool *all_sides_solid = nullptr) {
+    if (!validate_sky(d, err)) {
+        return false;
+    }
     constexpr uint32_t COUNT_BITS = 7u << 29, INDEX_BITS = ~COUNT_BITS, NONE = 0xffffffffu;
     constexpr uint32_t NODE_MIX = 4, NODE_PRINCIPLED = 6;
     constexpr uint32_t MAT_INDEX_BITS = 16383;
@@ -235,6 +239,50 @@ inline bool validate(const rayhip_scene_desc &d, std::string &err, bool *all_sid
 }
 
 // the part an instance / light update replaces (rayhip_scene_update_instances): lights, light tree, env light
+// the physical sky (rayhip_sky): array sizes against the dimensions the struct states, power-of-two sizes where the samplers wrap with a
+// mask, the directional-light list against the light array
+inline bool validate_sky(const rayhip_scene_desc &d, std::string &err) {
+    if (!(d.env.sky_map_spread_angle > 0.0f)) {
+        return true; // (not a physical sky: the fields are ignored)
+    }
+    if (d.sky_count != 1 || d.sky == nullptr) {
+        err = "scene validation: the environment is the physical sky (sky_map_spread_angle > 0) but rayhip_scene_desc::sky is missing";
+        return false;
+    }
+    const rayhip_sky &k = *d.sky;
+    const auto pow2 = [](const int32_t v) { return v > 0 && (v & (v - 1)) == 0; };
+    const auto sized = [&](const char *what, const uint64_t have, const uint64_t want) {
+        if (have != want) {
+            err = std::string("scene validation: sky ") + what + " holds " + std::to_string(have) + " elements, its dimensions need " + std::to_string(want);
+            return false;
+        }
+        return true;
+    };
+    if (k.transmittance_lut_w <= 0 || k.transmittance_lut_h <= 0 || k.multiscatter_lut_res < 0 || !pow2(k.weather_res) || !pow2(k.noise3d_res) ||
+        !pow2(k.curl_res) || !pow2(k.moon_w) || !pow2(k.moon_h) || !pow2(k.cirrus_res) || k.weather_res > 4096 || k.noise3d_res > 512 ||
+        k.curl_res > 4096 || k.moon_w > 8192 || k.moon_h > 8192 || k.cirrus_res > 4096 || k.transmittance_lut_w > 4096 || k.transmittance_lut_h > 4096 ||
+        k.multiscatter_lut_res > 1024) {
+        err = "scene validation: sky texture / table dimensions out of range (wrapped textures need power-of-two sizes)";
+        return false;
+    }
+    if (!sized("transmittance table", d.sky_transmittance_lut_count, uint64_t(4) * uint64_t(k.transmittance_lut_w) * uint64_t(k.transmittance_lut_h)) ||
+        !sized("multiple-scattering table", d.sky_multiscatter_lut_count, uint64_t(4) * uint64_t(k.multiscatter_lut_res) * uint64_t(k.multiscatter_lut_res)) ||
+        !sized("weather map", d.sky_weather_tex_count, uint64_t(3) * uint64_t(k.weather_res) * uint64_t(k.weather_res)) ||
+        !sized("3-d noise", d.sky_noise3d_tex_count, uint64_t(k.noise3d_res) * uint64_t(k.noise3d_res) * uint64_t(k.noise3d_res)) ||
+        !sized("curl noise", d.sky_curl_tex_count, uint64_t(3) * uint64_t(k.curl_res) * uint64_t(k.curl_res)) ||
+        !sized("moon map", d.sky_moon_tex_count, uint64_t(3) * uint64_t(k.moon_w) * uint64_t(k.moon_h)) ||
+        !sized("cirrus map", d.sky_cirrus_tex_count, uint64_t(2) * uint64_t(k.cirrus_res) * uint64_t(k.cirrus_res))) {
+        return false;
+    }
+    for (uint32_t i = 0; i < d.sky_dir_lights_count; ++i) {
+        if (d.sky_dir_lights[i] >= d.lights_count || (d.lights[d.sky_dir_lights[i]].flags & 7u) != 1u /* LIGHT_TYPE_DIR */) {
+            err = "scene validation: sky_dir_lights[" + std::to_string(i) + "] does not name a directional light";
+            return false;
+        }
+    }
+    return true;
+}
+
 inline bool validate_lights(const rayhip_scene_desc &d, std::string &err) {
     constexpr uint32_t NONE = 0xffffffffu, LIGHT_LEAF_BIT = 1u << 31, LIGHT_TYPE_TRI = 5;
     const uint32_t n_real_tris = d.vtx_indices_count / 3;

@@ -103,12 +103,12 @@ __device__ __forceinline__ ShadeParams layer_params(const ShadeParams &sp, const
     return p;
 }
 
-template <bool PRIMARY, bool PICK>
+template <bool PRIMARY, bool PICK, bool SKY = false>
 __global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
                                                                        const RayQueue in, const PointSoA points, const RayQueue out_points,
                                                                        const DeferredSoA deferred_out, const RayQueue out_deferred,
                                                                        const PixelBuffers px, const int img_w, const float mix_factor,
-                                                                       const Layering layers) {
+                                                                       const Layering layers, uint32_t *__restrict__ sky_index, const RayQueue out_sky) {
     const uint32_t n_live_chunks = in.live_chunks();
     ChunkWalk walk(n_live_chunks);
     for (uint32_t c; walk.next(c);) {
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const Sc
         }
         const uint32_t i = slot0 + threadIdx.x; // (the whole wavefront stays in the body for the ballots)
         const bool active = threadIdx.x < n_live;
-        bool continues = false, defer = false;
+        bool continues = false, defer = false, sky = false;
         ShadePoint pt;
         SurfaceOut so;
         LightPick pick = no_light_pick();
@@ -129,8 +129,9 @@ __global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const Sc
             const uint32_t layer = xy_layer(xy, layers);
             const ShadeParams spl = layer_params(sp, layer);
             ray.xy = xy_real(xy, layers, layer);
-            continues = surface_stage<true>(sc, spl, hit, ray, pt, so); // (emitter MIS weights: k_shade_emissive)
+            continues = surface_stage<true, SKY>(sc, spl, hit, ray, pt, so); // (emitter MIS weights: k_shade_emissive)
             defer = so.deferred_emitter;
+            sky = SKY && so.deferred_sky;
             if (PRIMARY) {
                 // the pixel of a continuing path starts at (0, 0, 0, 1); the scatter stage adds what shadow-less lights give
                 ShadeResult res;
@@ -156,6 +157,12 @@ __global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const Sc
             store_point(points, p_slot, pt, i);
             if (PICK) {
                 store_pick(points, p_slot, pick);
+            }
+        }
+        if (SKY) { // the physical sky: paths that ended in it wait for k_shade_sky (their pixel got zeros above)
+            const uint32_t s_slot = out_sky.alloc(stripe, sky);
+            if (sky) {
+                sky_index[s_slot] = i;
             }
         }
         if (__any(defer)) { // rare
@@ -313,6 +320,31 @@ __global__ void __launch_bounds__(WAVE) k_shade_emissive(const SceneView sc, con
     }
 }
 
+// The physical sky for the paths k_surface deferred (ShadeSkyPrimary / ShadeSkySecondary, RendererCPU.h:484-486, 555-557): the analytic
+// integrator of rt_sky.h per ray -- air below / inside / above the cloud layer, 48 cloud steps with a 24-step shadow march each, cirrus,
+// sun disk, stars, moon: thousands of texture taps per ray, three orders of magnitude above any other per-ray work of the stage, which
+// is why it has its own launch over its own queue.  One ray per pixel and layer: the pixel update needs no atomics.
+__global__ void __launch_bounds__(WAVE) k_shade_sky(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
+                                                   const uint32_t *__restrict__ sky_index, const RayQueue queue, const PixelBuffers px, const int img_w,
+                                                   const Layering layers) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_live_chunks = queue.live_chunks();
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
+        uint32_t stripe, slot0, n_live;
+        if (!queue.chunk(c, stripe, slot0, n_live) || lane >= n_live) {
+            continue;
+        }
+        const uint32_t i = sky_index[slot0 + lane];
+        Ray ray = load_ray(rays_in, i);
+        const Hit hit = load_hit(hits, i);
+        const uint32_t xy = ray.xy, layer = xy_layer(xy, layers);
+        const ShadeParams spl = layer_params(sp, layer);
+        ray.xy = xy_real(xy, layers, layer);
+        add_sky_pixel(shade_sky_ray(sc, ray, hit, spl.iteration, int(spl.ps.max_total_depth), spl.limits[0]), xy, img_w, px.temp);
+    }
+}
+
 // (Round 3 also tried the pick with EIGHT lanes per shade point -- lane j fetches and evaluates child j, the group exchanges the
 // importances and every lane runs light_level_choice; the table is row-type major for it, 128 consecutive bytes per group and
 // load.  Bit-identical picks, an eighth of the L1 traffic -- and 0.73 instead of 0.34 ms per iteration: only the importance
@@ -324,19 +356,25 @@ void launch(const ShadeLaunch &a) {
     hipStream_t s = a.stream;
     const int g = a.grid;
     const bool pick_apart = (a.split & 1) != 0 && a.sc.light_cwnodes_count != 0;
-    // stage 1: what was hit
+    // stage 1: what was hit (SKY: the environment is the physical sky -- narrow rays that leave the scene are queued for k_shade_sky)
+#define RT_SURFACE_ARGS a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers, a.sky_index, a.out_sky
+    const bool sky = a.sc.sky.desc != nullptr;
     if (a.bounce == 0) {
-        if (pick_apart) {
-            k_surface<true, false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers);
+        if (sky) {
+            pick_apart ? k_surface<true, false, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS) : k_surface<true, true, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS);
         } else {
-            k_surface<true, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers);
+            pick_apart ? k_surface<true, false><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS) : k_surface<true, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS);
         }
     } else {
-        if (pick_apart) {
-            k_surface<false, false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers);
+        if (sky) {
+            pick_apart ? k_surface<false, false, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS) : k_surface<false, true, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS);
         } else {
-            k_surface<false, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers);
+            pick_apart ? k_surface<false, false><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS) : k_surface<false, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS);
         }
+    }
+#undef RT_SURFACE_ARGS
+    if (a.sc.sky.desc != nullptr) { // paths that ended in the physical sky
+        k_shade_sky<<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.sky_index, a.out_sky, a.px, a.vw, a.layers);
     }
     // emitter hits whose MIS weight was deferred; an empty queue costs a few microseconds
     k_shade_emissive<<<std::min(g, 2048), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.deferred, a.out_deferred, a.px, a.vw);

@@ -29,7 +29,8 @@ struct ShadeLaunch {
     ShadowSoA shadow;
     DeferredSoA deferred;
     PointSoA points;
-    RayQueue in, pts, out_rays, out_shadow, out_deferred, nee;
+    RayQueue in, pts, out_rays, out_shadow, out_deferred, nee, out_sky;
+    uint32_t *sky_index; // ray slots of the paths that ended in the physical sky (k_surface -> k_shade_sky), densely per stripe
     PixelBuffers px;
     Layering layers;
     int vw;           // row pitch of the per-iteration pixel buffers (virtual frame width)

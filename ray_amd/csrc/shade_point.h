@@ -71,6 +71,9 @@ struct SurfaceOut {
     bool deferred_emitter;
     uint32_t emitter_triangle;
     float emitter_mix_weight;
+    // the ray left the scene into a physical sky and is narrower than the baked map resolves: `radiance` is all zero, the caller runs
+    // shade_sky_ray (rt_sky.h) on it later and adds the result to the pixel (ShadeRef.cpp:1192-1196 -> ShadeSky, AtmosphereRef.cpp:928)
+    bool deferred_sky;
 };
 
 // `tri_verts` table: what the surface stage needs of a triangle, gathered through vtx_indices[] once per scene.  One row
@@ -247,12 +250,14 @@ RT_HD f4 emissive_hit_radiance(const ShadeParams &sp, const float mix_weight, co
 // ---- the surface stage -----------------------------------------------------------------------------------------------------------
 // Returns true when `pt` was filled (the path continues through stages 2 and 3), false when the path ends with out.radiance.
 // DEFER_EMITTERS: leave the MIS weight of emitter hits to the caller (see SurfaceOut).
-template <bool DEFER_EMITTERS>
+// SKY: the environment may be the physical sky (false: the test is compiled out -- the device picks the kernel per scene).
+template <bool DEFER_EMITTERS, bool SKY = true>
 RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &hit, const Ray &ray, ShadePoint &pt, SurfaceOut &out) {
     out.radiance = f4{0.0f, 0.0f, 0.0f, 0.0f};
     out.base_color = f3{0.0f, 0.0f, 0.0f};
     out.normal_depth = f4{0.0f, 0.0f, 0.0f, 0.0f};
     out.deferred_emitter = false;
+    out.deferred_sky = false;
 
     const PathRandom rnd = path_random(sc, sp, ray.xy, ray.depth);
     // the texture-lookup random pair of this path vertex: computed where a lookup happens (an integer hash chain + two
@@ -270,6 +275,10 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     } tex_jitter = {rnd, false, f2{0.0f, 0.0f}};
 
     if (hit.v < 0.0f) { // nothing hit
+        if (SKY && sc.sky.desc != nullptr && ray.cone_spread < sc.env.sky_map_spread_angle) {
+            out.deferred_sky = true;
+            return false;
+        }
         const float inv_pick_prob = (get_total_depth(ray.depth) < sp.ps.max_total_depth) ? safe_div_pos(1.0f, hit.u) : -1.0f;
         f4 c = environment_radiance(sc, ray, inv_pick_prob, tex_jitter);
         c *= mk4(ray.c.x, ray.c.y, ray.c.z, 0.0f);

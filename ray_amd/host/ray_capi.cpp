@@ -139,6 +139,11 @@ void ray_default_env(ray_env_desc *d) {
     memset(d, 0, sizeof(*d));
     d->env_map = d->back_map = RAY_INVALID_HANDLE;
     d->importance_sample = 1;
+    const Ray::environment_desc_t e;
+    d->envmap_resolution = e.envmap_resolution;
+    d->clouds_density = e.atmosphere.clouds_density, d->cirrus_clouds_amount = e.atmosphere.cirrus_clouds_amount;
+    d->stars_brightness = e.atmosphere.stars_brightness, d->moon_radius = e.atmosphere.moon_radius;
+    d->clouds_offset_x = e.atmosphere.clouds_offset_x, d->clouds_offset_z = e.atmosphere.clouds_offset_z;
 }
 
 ray_renderer *ray_renderer_create(const char *type_name, int w, int h, int use_tex_compression, int verbose) {
@@ -298,6 +303,10 @@ void ray_scene_set_environment(ray_scene *s, const ray_env_desc *d) {
     e.back_map = to_handle<Ray::TextureHandle>(d->back_map);
     e.env_map_rotation = d->env_map_rotation, e.back_map_rotation = d->back_map_rotation;
     e.importance_sample = d->importance_sample != 0;
+    e.envmap_resolution = d->envmap_resolution;
+    e.atmosphere.clouds_density = d->clouds_density, e.atmosphere.cirrus_clouds_amount = d->cirrus_clouds_amount;
+    e.atmosphere.stars_brightness = d->stars_brightness, e.atmosphere.moon_radius = d->moon_radius;
+    e.atmosphere.clouds_offset_x = d->clouds_offset_x, e.atmosphere.clouds_offset_z = d->clouds_offset_z;
     s->s->SetEnvironment(e);
 }
 

@@ -135,13 +135,17 @@ typedef struct ray_camera_desc { /* Ray::camera_desc_t, SceneBase.h:264-311 */
     float variance_threshold, regularize_alpha;
 } ray_camera_desc;
 
-typedef struct ray_env_desc { /* Ray::environment_desc_t (atmosphere left at defaults), SceneBase.h:343-353 */
+#define RAY_PHYSICAL_SKY_TEXTURE 0xfffffffeull /* Ray::PhysicalSkyTexture (SceneBase.h:35): as env_map / back_map, the analytic sky */
+typedef struct ray_env_desc { /* Ray::environment_desc_t, SceneBase.h:343-353; of the atmosphere the fields tests vary, the rest at defaults */
     float env_col[3];
     ray_handle env_map;
     float back_col[3];
     ray_handle back_map;
     float env_map_rotation, back_map_rotation;
     int32_t importance_sample;
+    int32_t envmap_resolution;                                        /* resolution of the baked sky map (default 1024) */
+    float clouds_density, cirrus_clouds_amount, stars_brightness, moon_radius; /* atmosphere_params_t (SceneBase.h:314-341) */
+    float clouds_offset_x, clouds_offset_z;
 } ray_env_desc;
 
 typedef struct ray_stats { /* RendererBase::stats_t, RendererBase.h:230-244 */

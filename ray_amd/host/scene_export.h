@@ -20,6 +20,10 @@
 #include "../../include/rayhip.h"
 
 namespace Ray {
+// the five textures the reference compiles into AtmosphereRef.cpp (internal/precomputed/*.inl: `extern const` in namespace Ray)
+extern const int WEATHER_TEX_RES, NOISE_3D_RES, CURL_TEX_RES, MOON_TEX_W, MOON_TEX_H, CIRRUS_TEX_RES;
+extern const uint8_t __weather_tex[], __3d_noise_tex[], __curl_tex[], __moon_tex[], __cirrus_tex[];
+
 namespace Hip {
 
 static_assert(sizeof(rayhip_tri_accel) == sizeof(tri_accel_t), "layout");
@@ -39,6 +43,10 @@ static_assert(offsetof(rayhip_camera, pass_settings) == offsetof(camera_t, pass_
 static_assert(offsetof(rayhip_camera, origin) == offsetof(camera_t, origin), "layout");
 static_assert(sizeof(rayhip_pass_settings) == sizeof(pass_settings_t), "layout");
 static_assert(sizeof(rayhip_stats) == sizeof(RendererBase::stats_t), "layout");
+static_assert(sizeof(rayhip_atmosphere) == sizeof(atmosphere_params_t), "layout");
+static_assert(offsetof(rayhip_atmosphere, moon_dir) == offsetof(atmosphere_params_t, moon_dir), "layout");
+static_assert(offsetof(rayhip_atmosphere, ground_albedo) == offsetof(atmosphere_params_t, ground_albedo), "layout");
+static_assert(offsetof(rayhip_atmosphere, cirrus_clouds_height) == offsetof(atmosphere_params_t, cirrus_clouds_height), "layout");
 
 // ---- the block-compressed storages as they are kept ----------------------------------------------------
 // TexStorageBCn<N> (TextureStorageCPU.h:364-617) keeps its images -- 4x4 blocks per mip -- in a private member and offers
@@ -63,6 +71,7 @@ struct FlatScene {
     std::vector<rayhip_texture> textures;
     std::vector<uint32_t> texels;
     std::vector<float> env_qtree;
+    rayhip_sky sky = {};
 };
 
 // Access to Cpu::Scene / SceneCommon protected members through a derived class (legal: the member pointers
@@ -220,6 +229,27 @@ class SceneAccess : public Cpu::Scene {
         d.env.light_index = e.light_index;
         d.env.sky_map_spread_angle = e.sky_map_spread_angle;
         d.env.qtree_levels = e.qtree_levels;
+
+        // the physical sky: what the analytic evaluation of narrow rays needs (rayhip_sky; AtmosphereRef.cpp: ShadeSky)
+        d.sky = nullptr, d.sky_count = 0;
+        if (e.sky_map_spread_angle > 0.0f) {
+            rayhip_sky &k = out.sky;
+            k = {};
+            memcpy(&k.atmosphere, &e.atmosphere, sizeof(k.atmosphere));
+            k.transmittance_lut_w = SKY_TRANSMITTANCE_LUT_W, k.transmittance_lut_h = SKY_TRANSMITTANCE_LUT_H;
+            k.multiscatter_lut_res = s.sky_multiscatter_lut_.empty() ? 0 : SKY_MULTISCATTER_LUT_RES;
+            k.weather_res = WEATHER_TEX_RES, k.noise3d_res = NOISE_3D_RES, k.curl_res = CURL_TEX_RES;
+            k.moon_w = MOON_TEX_W, k.moon_h = MOON_TEX_H, k.cirrus_res = CIRRUS_TEX_RES;
+            d.sky = &k, d.sky_count = 1;
+            d.sky_transmittance_lut = s.sky_transmittance_lut_.data(), d.sky_transmittance_lut_count = uint32_t(s.sky_transmittance_lut_.size());
+            d.sky_multiscatter_lut = s.sky_multiscatter_lut_.data(), d.sky_multiscatter_lut_count = uint32_t(s.sky_multiscatter_lut_.size());
+            d.sky_dir_lights = s.dir_lights_.data(), d.sky_dir_lights_count = uint32_t(s.dir_lights_.size());
+            d.sky_weather_tex = __weather_tex, d.sky_weather_tex_count = uint32_t(3 * WEATHER_TEX_RES * WEATHER_TEX_RES);
+            d.sky_noise3d_tex = __3d_noise_tex, d.sky_noise3d_tex_count = uint32_t(NOISE_3D_RES * NOISE_3D_RES * NOISE_3D_RES);
+            d.sky_curl_tex = __curl_tex, d.sky_curl_tex_count = uint32_t(3 * CURL_TEX_RES * CURL_TEX_RES);
+            d.sky_moon_tex = __moon_tex, d.sky_moon_tex_count = uint32_t(3 * MOON_TEX_W * MOON_TEX_H);
+            d.sky_cirrus_tex = __cirrus_tex, d.sky_cirrus_tex_count = uint32_t(2 * CIRRUS_TEX_RES * CIRRUS_TEX_RES);
+        }
 
         d.tlas_root = s.tlas_root_;
         d.visible_lights_count = s.visible_lights_count_;

@@ -15,6 +15,7 @@ from typing import Tuple
 
 import numpy as np
 
+from . import api
 from .api import InvalidHandle, PrincipledMat, ShadingNode, eShadingNode, eTextureFormat
 
 # ---- Cornell box ----------------------------------------------------------------------------------------------
@@ -254,6 +255,31 @@ def cornell_env(scene, **cam_overrides):
     groups = [(grey, None, 0, 12), (red, None, 12, 6), (green, None, 18, 6), (grey, None, 24, 30), (shiny, None, 54, 30)]
     mesh = scene.AddMesh(attrs, idx, groups)
     scene.AddMeshInstance(mesh)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
+def cornell_sky(scene, night: bool = False, envmap_resolution: int = 256, **cam_overrides):
+    """Cornell box without ceiling and back wall under the PHYSICAL SKY: the environment is
+    Ray::PhysicalSkyTexture, lit by a directional light (the sun).  Camera rays and the mirror-like block's reflections that leave
+    the box are narrower than the baked map resolves and are evaluated analytically (ShadeSkyPrimary / ShadeSkySecondary ->
+    IntegrateScattering: air, the cloud layer with its shadow marches, cirrus, the sun's disk; at `night` stars and the moon);
+    diffuse bounces read the map the host baked from the same integrator, importance-sampled through its quadtree."""
+    scene.SetEnvironment(env_col=(1.0, 1.0, 1.0), back_col=(1.0, 1.0, 1.0), env_map=api.PhysicalSkyTexture, back_map=api.PhysicalSkyTexture,
+                         importance_sample=True, envmap_resolution=envmap_resolution, clouds_density=0.6, cirrus_clouds_amount=0.6)
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.05, 0.05)))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.05, 0.5, 0.05)))
+    mirror = scene.AddMaterial(PrincipledMat(base_color=(0.9, 0.9, 0.9), metallic=1.0, roughness=0.0))
+    q = _CORNELL_QUADS
+    attrs, idx = cornell_mesh_arrays([q[0], q[3], q[4]] + _block_quads("short") + _block_quads("tall"))  # floor, left, right; two blocks
+    groups = [(grey, None, 0, 6), (red, None, 6, 6), (green, None, 12, 6), (grey, None, 18, 30), (mirror, None, 48, 30)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    if night:  # the sun below the horizon: moonlight, stars, the moon's disk
+        scene.AddLight("directional", color=(12.0, 11.0, 10.0), direction=(0.2, 0.3, -1.0), angle=0.5)
+    else:
+        scene.AddLight("directional", color=(12.0, 11.0, 10.0), direction=(0.3, -0.5, -1.0), angle=0.6)
     _cornell_camera(scene, **cam_overrides)
     scene.Finalize()
 
@@ -942,6 +968,12 @@ SCENES = {
     "cornell_env": cornell_env,
     "cornell_filmic": cornell_filmic,
     "cornell_instances": cornell_instances,
+}
+
+
+# scenes whose golden fixtures are frames only (tests/golden/make_fixtures.py)
+FRAME_SCENES = {
+    "cornell_sky": cornell_sky,
 }
 
 

@@ -16,6 +16,7 @@ Files
                                          secondary_rays, shadow_rays), the shadow rays' IntersectScene(shadow) results;
                                          bounce 1: the secondary rays after IntersectScene (+ their hits) and
                                          ShadeSecondary's image / rays (shade1_color, secondary_rays1, shadow_rays1)
+  cornell_sky.rayscene / _ref.npz        the physical sky (scenes.FRAME_SCENES): frames only -- raw_spp1 / raw_spp8 / final / aux
   rng_vectors.npz                        get_scrambled_2d_rand known answers
 """
 import os
@@ -69,6 +70,27 @@ def main():
         color1, sec2, sh1 = O.ref_shade(s, W, H, 1, 1, sec1, hits1, color)
         out["shade1_color"], out["secondary_rays1"], out["shadow_rays1"] = color1, sec2, sh1
         # frames
+        region = api.RegionContext((0, 0, W, H))
+        for it in range(1, 9):
+            r.RenderScene(s, region)
+            if it == 1:
+                out["raw_spp1"] = r.get_raw_pixels_ref()
+        out["raw_spp8"] = r.get_raw_pixels_ref()
+        out["final_spp8"] = r.get_pixels_ref()
+        out["base_color_spp8"] = r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor)
+        out["depth_normals_spp8"] = r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals)
+        np.savez_compressed(os.path.join(HERE, f"{name}_ref.npz"), **out)
+        print(name, {k: v.shape for k, v in out.items()})
+
+    # scenes pinned by their FRAMES only (no kernel-level dumps): the physical sky -- its rays are finished by a pass of their own
+    # (ShadeSkyPrimary / ShadeSkySecondary, RendererCPU.h:484-486, 555-557), which the kernel-level shade hook does not model
+    for name, fn in scenes.FRAME_SCENES.items():
+        r = O.create_renderer(W, H, "REF")
+        s = r.CreateScene()
+        fn(s)
+        with open(os.path.join(HERE, f"{name}.rayscene"), "wb") as f:
+            f.write(O.export_scene(s))
+        out = {}
         region = api.RegionContext((0, 0, W, H))
         for it in range(1, 9):
             r.RenderScene(s, region)

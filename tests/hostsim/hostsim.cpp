@@ -54,6 +54,30 @@ struct HostScene {
     std::vector<uint32_t> blas_root4; // roots in the wide form in use (nodes4 or nodes8)
     std::vector<rayhip_texture> textures;
     std::vector<uint32_t> texels;
+    // the physical sky (rayhip_sky): a copy of everything rt_sky.h reads
+    rayhip_sky sky;
+    std::vector<float> sky_transmittance_lut, sky_multiscatter_lut;
+    std::vector<uint32_t> sky_dir_lights;
+    std::vector<uint8_t> sky_weather, sky_noise3d, sky_curl, sky_moon, sky_cirrus;
+    SkyView sky_view(const rayhip_scene_desc &d) {
+        SkyView v = {};
+        if (!(d.env.sky_map_spread_angle > 0.0f) || d.sky_count == 0) {
+            return v;
+        }
+        sky = *d.sky;
+        sky_transmittance_lut.assign(d.sky_transmittance_lut, d.sky_transmittance_lut + d.sky_transmittance_lut_count);
+        sky_multiscatter_lut.assign(d.sky_multiscatter_lut, d.sky_multiscatter_lut + d.sky_multiscatter_lut_count);
+        sky_dir_lights.assign(d.sky_dir_lights, d.sky_dir_lights + d.sky_dir_lights_count);
+        sky_weather.assign(d.sky_weather_tex, d.sky_weather_tex + d.sky_weather_tex_count);
+        sky_noise3d.assign(d.sky_noise3d_tex, d.sky_noise3d_tex + d.sky_noise3d_tex_count);
+        sky_curl.assign(d.sky_curl_tex, d.sky_curl_tex + d.sky_curl_tex_count);
+        sky_moon.assign(d.sky_moon_tex, d.sky_moon_tex + d.sky_moon_tex_count);
+        sky_cirrus.assign(d.sky_cirrus_tex, d.sky_cirrus_tex + d.sky_cirrus_tex_count);
+        v.desc = &sky, v.transmittance_lut = sky_transmittance_lut.data(), v.multiscatter_lut = sky_multiscatter_lut.data();
+        v.dir_lights = sky_dir_lights.data(), v.dir_lights_count = uint32_t(sky_dir_lights.size());
+        v.weather = sky_weather.data(), v.noise3d = sky_noise3d.data(), v.curl = sky_curl.data(), v.moon = sky_moon.data(), v.cirrus = sky_cirrus.data();
+        return v;
+    }
 };
 } // namespace
 
@@ -286,6 +310,7 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     v.blocker_lights_count = d->blocker_lights_count;
     v.tlas_root = tlas_root;
     v.env = d->env;
+    v.sky = s.sky_view(*d);
     memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
     return 0;
 }
@@ -356,6 +381,7 @@ HS_API int hostsim_scene_update_instances(hostsim_ctx *c, const rayhip_scene_des
     v.visible_lights_count = d->visible_lights_count, v.blocker_lights_count = d->blocker_lights_count;
     v.tlas_root = tlas_root;
     v.env = d->env;
+    v.sky = s.sky_view(*d); // (the suns are lights: they may have moved)
     memcpy(c->bbox_min, d->bbox_min, 12), memcpy(c->bbox_max, d->bbox_max, 12);
     return 0;
 }
@@ -483,10 +509,14 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
         // K5: shade
         const ShadeParams sp = make_shade_params(*cam, iteration, bounce);
         next_rays.clear(), shadow.clear();
+        std::vector<size_t> sky_rays; // ShadeSkyPrimary / ShadeSkySecondary run over these after the surface shading (RendererCPU.h:484-486, 555-557)
         for (size_t i = 0; i < rays.size(); ++i) {
             Ray nr;
             ShadowRay sr;
             const ShadeResult res = shade_surface(c->sc, sp, hits[i], rays[i], nr, sr);
+            if (res.defer_sky) {
+                sky_rays.push_back(i);
+            }
             if (bounce == 0) {
                 write_primary_pixel(res, rays[i].xy, w, mix_factor, c->temp.data(), c->base_color.data(),
                                     c->depth_normals.data());
@@ -499,6 +529,9 @@ HS_API int hostsim_render(hostsim_ctx *c, const rayhip_camera *cam, const int re
             if (res.emit_shadow) {
                 shadow.push_back(sr);
             }
+        }
+        for (const size_t i : sky_rays) {
+            add_sky_pixel(shade_sky_ray(c->sc, rays[i], hits[i], sp.iteration, int(sp.ps.max_total_depth), sp.limits[0]), rays[i].xy, w, c->temp.data());
         }
         // K3: shadow rays
         const float limit = shadow_clamp_limit(*cam, bounce);

@@ -106,8 +106,20 @@ def test_a_box_the_grid_cannot_hold_falls_back_to_the_bvh2(gpu_lib, monkeypatch)
     monkeypatch.setenv("RAYHIP_REFINE_LEAVES", "0")  # (the patched node must reach the collapse as it is)
     blob = util.golden_scene("cornell_basic")
     _, moff, _ = H.sections(blob)["mesh_instances"]
-    root = struct.unpack_from("<I", blob, moff + 4)[0]
-    bad = H.patched(blob, "nodes", 64 * root + 4, "<f", float("inf"))  # ch_data0[1]: child 0's max x
+    _, noff, nsize = H.sections(blob)["nodes"]
+    nodes = np.frombuffer(blob, dtype=np.uint32, count=nsize // 4, offset=noff).reshape(-1, 16)
+    # a LEAF child's box (an inner child is opened by the collapse and its own box never quantised): walk down from the instance's root
+    todo, site = [int(struct.unpack_from("<I", blob, moff + 4)[0])], None
+    while todo and site is None:
+        n = todo.pop()
+        for side in (0, 1):
+            w = int(nodes[n, 12 + side])
+            if w & (7 << 29):
+                site = (n, side)
+                break
+            todo.append(w)
+    n, side = site
+    bad = H.patched(blob, "nodes", 64 * n + (4 if side == 0 else 16 + 4), "<f", float("inf"))  # ch_data0[1] / ch_data1[1]: that child's max x
 
     def frame(b, width=None):
         if width:

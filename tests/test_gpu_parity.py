@@ -857,3 +857,53 @@ def test_the_tie_pixels_on_the_device(gpu_lib, hostsim_lib, monkeypatch):
         return set(zip(xs.tolist(), ys.tolist()))
     assert outside(plain) == set()
     assert outside(refined) <= t["pixels"]
+
+
+def test_physical_sky_on_the_device(gpu_lib, hostsim_lib):
+    """the physical sky on the device (k_surface<.., SKY> queues the narrow rays that leave the scene, k_shade_sky runs the
+    analytic integrator of rt_sky.h over them): frames against the committed RendererRef frames within the stated tolerance at 1 and
+    8 spp, aux images, a layered pass bit-identical to single iterations; and a larger frame against the host build.  (The device's
+    powf / expf / sinf are not glibc's: a handful of star pixels -- sin(1e5) amplified 4e4 times by the hash -- may leave the
+    tolerance, which is what the 99.5 % bar allows.)"""
+    g = util.golden_ref("cornell_sky")
+    ctx = util.make_context(gpu_lib, "cornell_sky")
+    ctx.render(1)
+    m1 = util.frame_metrics(ctx.readback(hip.BUF_RAW), g["raw_spp1"])
+    for it in range(2, 9):
+        ctx.render(it)
+    raw8 = ctx.readback(hip.BUF_RAW).copy()
+    m8 = util.frame_metrics(raw8, g["raw_spp8"])
+    print("cornell_sky 1 spp", m1, "8 spp", m8)
+    assert m1["frac_within"] >= util.MIN_FRACTION and m1["alpha_equal"]
+    assert m8["frac_within"] >= util.MIN_FRACTION and m8["alpha_equal"]
+    np.testing.assert_allclose(ctx.readback(hip.BUF_BASE_COLOR), g["base_color_spp8"], atol=2e-3)
+    batched = util.make_context(gpu_lib, "cornell_sky")
+    batched.render_batch(1, 8)
+    assert np.array_equal(batched.readback(hip.BUF_RAW), raw8)
+    # 160 x 120, 4 spp: device against the host build of the same sources (itself the reference bit for bit)
+    w, h = 160, 120
+    imgs = []
+    for lib in (hostsim_lib, gpu_lib):
+        c = util.make_context(lib, "cornell_sky", w, h)
+        if lib is gpu_lib:
+            c.render_batch(1, 4)
+        else:
+            util.render_frames(c, 4)
+        imgs.append(c.readback(hip.BUF_RAW).copy())
+    m = util.frame_metrics(imgs[1], imgs[0])
+    print("cornell_sky 160x120 4 spp, device vs host build", m)
+    assert m["frac_within"] >= util.MIN_FRACTION
+
+
+def test_a_physical_sky_without_its_tables_is_refused(gpu_lib):
+    """environment_t::sky_map_spread_angle > 0 promises rayhip_scene_desc::sky*: a blob that lacks them is turned away at upload"""
+    import test_hostile_scenes as H
+    blob = util.golden_scene("cornell_sky")
+    i, off, size = H.sections(blob)["sky"]
+    bad = bytearray(blob)
+    bad[H.HEADER + i * H.SECTION: H.HEADER + i * H.SECTION + 3] = b"xky"  # the section is no longer found under its name
+    ctx = hip.Context(0, gpu_lib)
+    ctx.upload_static(util.pmj())
+    ctx.resize(32, 32)
+    with pytest.raises(Exception, match="physical sky"):
+        ctx.upload_scene_blob(bytes(bad))

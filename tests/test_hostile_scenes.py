@@ -184,3 +184,20 @@ def test_a_mesh_tree_that_links_into_the_top_level_is_refused():
         upload(bad)
     print(e.value)
     assert "top-level" in str(e.value) or "not a tree" in str(e.value)
+
+
+def test_a_physical_sky_must_bring_its_tables():
+    """sky_map_spread_angle > 0 without rayhip_scene_desc::sky, or with a texture whose size does not match the stated dimensions"""
+    blob = util.golden_scene("cornell_sky")
+    upload(blob).render(1)
+    secs = sections(blob)
+    i, _, _ = secs["sky"]
+    b = bytearray(blob)
+    b[HEADER + i * SECTION: HEADER + i * SECTION + 3] = b"xky"
+    with pytest.raises(Exception, match="physical sky"):
+        upload(bytes(b))
+    _, off, _ = secs["sky"]
+    with pytest.raises(Exception, match="sky"):
+        upload(patched(blob, "sky", 208 + 12, "<i", 100))  # weather_res: not a power of two, and not the size of the section
+    with pytest.raises(Exception, match="directional"):
+        upload(patched(blob, "sky_dir_lights", 0, "<I", 0x00ffffff))

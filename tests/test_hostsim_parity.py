@@ -461,6 +461,43 @@ def test_random_textures_against_live_reference(lib, seed, compress):
     assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
 
 
+def test_physical_sky_golden_frames(lib):
+    """the physical sky (environment = Ray::PhysicalSkyTexture, a directional light as the sun; SURVEY 8f N3): narrow rays that leave
+    the scene -- camera rays, the mirror block's reflections -- go through the analytic integrator (rt_sky.h: air, the cloud layer
+    with its shadow marches, cirrus, sun disk, stars, moon), wide ones read the map the host baked.  Host build against the
+    committed frames of RendererRef, bit for bit"""
+    g = util.golden_ref("cornell_sky")
+    ctx = util.make_context(lib, "cornell_sky")
+    ctx.render(1)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), g["raw_spp1"])
+    for it in range(2, 9):
+        ctx.render(it)
+    assert np.array_equal(ctx.readback(hip.BUF_RAW), g["raw_spp8"])
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), g["final_spp8"])
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), g["base_color_spp8"])
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), g["depth_normals_spp8"])
+    top = g["raw_spp8"][:8, :, :3]
+    assert float(g["raw_spp8"][..., :3].max()) > 10.0 and ((top[..., 2] > 0.1) & (top[..., 2] > top[..., 0])).mean() > 0.3, "the top rows look into a blue sky"
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("night", [False, True])
+def test_physical_sky_against_live_reference(lib, night):
+    """... and against the live reference: by day (sun above the horizon) and by night (the sun below it: moonlight on the clouds,
+    stars, the moon's textured disk), another frame size, the rect form"""
+    from functools import partial
+    from ray_amd import api, scenes
+
+    w, h, spp = 48, 40, 3
+    r, s = O.render_ref(partial(scenes.cornell_sky, night=night), w, h, spp)
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), r.get_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_BASE_COLOR), r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor))
+    assert np.array_equal(ctx.readback(hip.BUF_DEPTH_NORMALS), r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))
+    assert not np.isnan(r.get_raw_pixels_ref()).any()
+
+
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_sky_portals_against_live_reference(lib):
     """rect / disk lights with sky_portal = true over an environment map"""
