@@ -32,6 +32,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -65,6 +67,8 @@ int load_rccl() {
     RCCL_SYM(CommInitRank, "ncclCommInitRank")
     RCCL_SYM(CommInitAll, "ncclCommInitAll")
     RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    RCCL_SYM(CommCount, "ncclCommCount")
+    RCCL_SYM(CommUserRank, "ncclCommUserRank")
     RCCL_SYM(Send, "ncclSend")
     RCCL_SYM(Recv, "ncclRecv")
     RCCL_SYM(GroupStart, "ncclGroupStart")
@@ -233,6 +237,18 @@ int rayhip_comm_create_rank(const void *unique_id, int nranks, int rank, rayhip_
     memcpy(&id, unique_id, sizeof(id));
     ncclComm_t comm = nullptr;
     RCCL_TRY(g_rccl.CommInitRank(&comm, nranks, id, rank));
+    // what RCCL itself thinks this communicator is -- the one place a wrong rendezvous (a stale id, two jobs sharing one) shows before
+    // the first gather hangs; logged once per rank so that a multi-GPU run leaves a trace of the transport it really used
+    int seen_ranks = -1, seen_rank = -1;
+    ncclResult_t asked = g_rccl.CommCount(comm, &seen_ranks);
+    if (asked == ncclSuccess) {
+        asked = g_rccl.CommUserRank(comm, &seen_rank);
+    }
+    if (asked != ncclSuccess || seen_ranks != nranks || seen_rank != rank) {
+        g_rccl.CommDestroy(comm);
+        return fail("RCCL communicator reports rank %d of %d, expected rank %d of %d", seen_rank, seen_ranks, rank, nranks);
+    }
+    fprintf(stderr, "rayhip: RCCL communicator up: rank %d of %d on device %d\n", seen_rank, seen_ranks, ctx->device);
     rayhip_comm *m = new rayhip_comm();
     m->nranks = nranks;
     m->local.push_back(rank);
