@@ -174,8 +174,13 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const int g = int(std::min<size_t>(size_t(c->grid_waves), (size_t(count) + WAVE - 1) / WAVE));
     // results land in the (otherwise idle) hit plane
-    k_trace_shadow<true, 0><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
-                                                    c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
+    if (getenv("RAYHIP_HOOK_SHADOW_REFILL") && c->wide == 4) { // the product's flat persistent form over the 4-wide tree (no counters)
+        k_trace_shadow_refill<<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
+                                                       c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
+    } else {
+        k_trace_shadow<true, 0><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
+                                                        c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipMemcpyAsync(after, tc, sizeof(after), hipMemcpyDeviceToHost, s));

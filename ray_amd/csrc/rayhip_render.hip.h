@@ -40,6 +40,9 @@ static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration,
     a.out_rays = c->ray_queue(bounce + 1, nslots, stripes), a.out_shadow = c->shadow_queue(bounce, nslots, stripes);
     a.out_deferred = c->deferred_queue(bounce, nslots, stripes), a.nee = c->nee_queue(bounce, nslots, stripes);
     a.out_sky = c->sky_queue(bounce, nslots, stripes), a.sky_index = c->sky_index.as<uint32_t>();
+    for (int k = 0; k < CONT_CLASSES; ++k) {
+        a.classes.q[k] = c->class_queue(bounce, k, nslots, stripes), a.classes.index[k] = c->class_index[k].as<uint32_t>();
+    }
     a.px = c->px, a.layers = layers, a.vw = vw, a.mix_factor = mix_factor;
     a.bounce = bounce, a.grid = gtrace, a.split = c->shade_split, a.stream = c->stream;
     shade::launch(a);
@@ -215,6 +218,8 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
                 k_trace_shadow<true, 4><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
             } else if (count) {
                 k_trace_shadow<true, 0><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
+            } else if (wide == 4 && c->shadow_refill) { // the flat persistent form (kernels.hip.h)
+                k_trace_shadow_refill<<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit, vw, c->px.temp, nullptr, spill, layers);
             } else if (wide == 8 && (c->small_scene || c->tune_shadow_waves == 5)) {
                 k_trace_shadow<false, 8, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
             } else if (wide == 8) {

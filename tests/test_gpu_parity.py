@@ -385,6 +385,27 @@ def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("name", SCENES)
+def test_flat_shadow_kernel_is_bit_identical(gpu_lib, name, monkeypatch):
+    """K3 as the flat persistent kernel (k_trace_shadow_refill, the default over the 4-wide tree) against the nested form: the
+    throughput of the oracle's own shadow rays (hook) and whole frames -- transparent surfaces between a point and its light
+    (cornell_principled), analytic blockers (cornell_lights), instances with visibility masks (cornell_instances)"""
+    g = util.golden_ref(name)
+    monkeypatch.setenv("RAYHIP_SHADOW_REFILL", "0")
+    nested = util.make_context(gpu_lib, name)
+    monkeypatch.delenv("RAYHIP_SHADOW_REFILL")
+    flat = util.make_context(gpu_lib, name)
+    rc_nested, _ = nested.k_intersect_shadow(g["shadow_rays"], 1)
+    monkeypatch.setenv("RAYHIP_HOOK_SHADOW_REFILL", "1")
+    rc_flat, _ = flat.k_intersect_shadow(g["shadow_rays"], 1)
+    monkeypatch.delenv("RAYHIP_HOOK_SHADOW_REFILL")
+    assert rc_flat.tobytes() == rc_nested.tobytes()
+    np.testing.assert_allclose(rc_flat, g["shadow_rc"], rtol=1e-6, atol=0)
+    nested.render_batch(1, 6), flat.render_batch(1, 6)
+    assert np.array_equal(flat.readback(hip.BUF_RAW), nested.readback(hip.BUF_RAW))
+    assert np.array_equal(flat.readback(hip.BUF_VARIANCE), nested.readback(hip.BUF_VARIANCE))
+
+
+@pytest.mark.parametrize("name", SCENES)
 def test_wide_forms_agree_bit_for_bit(gpu_lib, name, monkeypatch):
     """the three acceleration-structure forms the kernels can walk -- the reference's BVH2 (RAYHIP_BVH_WIDTH=2), the 4-wide
     collapse (4, the default) and the 8-wide one (8: its own child order, its own triangle order, one stack entry per level)
