@@ -136,11 +136,11 @@ struct rayhip_ctx {
     PixelBuffers px = {};
 
     // wavefront state, sized w*h
-    DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3], deferred_planes[2], point_planes[7], nee_index, class_index[CONT_CLASSES];
+    DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3], deferred_planes[2], point_planes[7], nee_index;
     PointSoA points = {};
     // how the shade stage is cut into launches (kernels.hip.h): bit 0 = the light pick as its own kernel, bit 1 = next-event
     // estimation and continuation as two scatter launches.  RAYHIP_SHADE_SPLIT overrides (A/B measurements).
-    int shade_split = 13; // shade_launch.h: bit 0 pick as its own kernel, bit 1 NEE / continuation as two launches, bit 2 NEE over the compacted queue of points that got a light, bit 3 continuation class by class
+    int shade_split = 5; // shade_launch.h: bit 0 pick as its own kernel, bit 1 NEE / continuation as two launches, bit 2 NEE over the compacted queue of points that got a light
     RaySoA rays[2] = {};
     HitSoA hits = {};
     ShadowSoA shadow = {};
@@ -166,14 +166,13 @@ struct rayhip_ctx {
     double stage_us[11] = {};
 
     static constexpr size_t QUEUE_WORDS = size_t(QUEUE_MAX_STRIPES) * QUEUE_COUNTER_STRIDE;
-    static constexpr int QUEUES_PER_BOUNCE = 6 + CONT_CLASSES;
+    static constexpr int QUEUES_PER_BOUNCE = 6;
     uint32_t *ray_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b) * QUEUE_WORDS; }
     uint32_t *shadow_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 1) * QUEUE_WORDS; }
     uint32_t *deferred_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 2) * QUEUE_WORDS; }
     uint32_t *point_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 3) * QUEUE_WORDS; }
     uint32_t *nee_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 4) * QUEUE_WORDS; }
     uint32_t *sky_count(int b) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 5) * QUEUE_WORDS; }
-    uint32_t *class_count(int b, int k) const { return counters.as<uint32_t>() + size_t(QUEUES_PER_BOUNCE * b + 6 + k) * QUEUE_WORDS; }
     // queue geometry for a frame of `items` pixels split over `stripes` stripes
     static RayQueue make_queue(uint32_t *counts, size_t items, uint32_t stripes) {
         const size_t chunks = (items + WAVE - 1) / WAVE;
@@ -185,7 +184,6 @@ struct rayhip_ctx {
     RayQueue point_queue(int b, size_t items, uint32_t stripes) const { return make_queue(point_count(b), items, stripes); }
     RayQueue nee_queue(int b, size_t items, uint32_t stripes) const { return make_queue(nee_count(b), items, stripes); }
     RayQueue sky_queue(int b, size_t items, uint32_t stripes) const { return make_queue(sky_count(b), items, stripes); }
-    RayQueue class_queue(int b, int k, size_t items, uint32_t stripes) const { return make_queue(class_count(b, k), items, stripes); }
     int clear_queues(int bounces, hipStream_t s) const {
         return hipMemsetAsync(counters.p, 0, size_t(QUEUES_PER_BOUNCE * bounces) * QUEUE_WORDS * sizeof(uint32_t), s) == hipSuccess ? 0 : 1;
     }
@@ -302,11 +300,6 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
         return 1;
     }
     c->points.nee_index = c->nee_index.as<uint32_t>();
-    for (int k = 0; k < CONT_CLASSES; ++k) { // (only touched when the continuation runs class by class: shade_split bit 3)
-        if (c->class_index[k].alloc(n * 4)) {
-            return 1;
-        }
-    }
     if (c->sky_index.alloc(n * 4)) {
         return 1;
     }
@@ -456,7 +449,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         c->sort_key_mode = std::max(0, std::min(3, atoi(e)));
     }
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
-        c->shade_split = atoi(e) & 15;
+        c->shade_split = atoi(e) & 7;
     }
     // The persistent ray-refill form of the closest-hit kernel (kernels.hip.h): lanes whose ray is finished fetch the next one
     // instead of idling until the longest walk of their wavefront ends.  RAYHIP_REFILL: 2 = for the secondary
@@ -545,9 +538,6 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         b.release();
     }
     c->nee_index.release();
-    for (auto &b : c->class_index) {
-        b.release();
-    }
     for (auto &up : c->unet_pass) { // (the UNet's weights and its fifteen tensors -- 1.3 GB at 1080p -- were leaked)
         up.weights.release();
         up.bias.release();

@@ -40,9 +40,6 @@ static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration,
     a.out_rays = c->ray_queue(bounce + 1, nslots, stripes), a.out_shadow = c->shadow_queue(bounce, nslots, stripes);
     a.out_deferred = c->deferred_queue(bounce, nslots, stripes), a.nee = c->nee_queue(bounce, nslots, stripes);
     a.out_sky = c->sky_queue(bounce, nslots, stripes), a.sky_index = c->sky_index.as<uint32_t>();
-    for (int k = 0; k < CONT_CLASSES; ++k) {
-        a.classes.q[k] = c->class_queue(bounce, k, nslots, stripes), a.classes.index[k] = c->class_index[k].as<uint32_t>();
-    }
     a.px = c->px, a.layers = layers, a.vw = vw, a.mix_factor = mix_factor;
     a.bounce = bounce, a.grid = gtrace, a.split = c->shade_split, a.stream = c->stream;
     shade::launch(a);

@@ -177,12 +177,10 @@ __global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const Sc
 
 // COMPACT: the points whose descent ended at a light (inv_prob != 0: the only ones the next-event estimation has work for -- 18 % of
 // the points of the Bistro-class scene) are listed densely in the `nee` queue of their stripe, for k_scatter<true, false, true>
-// CLASSIFY: every point is also filed under the branch its continuation will take (shade_lobes.h: continuation_class), one dense index
-// list per class and stripe, for k_scatter_by_class
-template <bool COMPACT, bool CLASSIFY = false>
+template <bool COMPACT>
 __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
                                                                        const PointSoA points, const RayQueue queue, const RayQueue nee,
-                                                                       const Layering layers, const ClassQueues classes) {
+                                                                       const Layering layers) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n_live_chunks = queue.live_chunks();
     ChunkWalk walk(n_live_chunks);
@@ -193,39 +191,19 @@ __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick(const Sc
         }
         const uint32_t i = slot0 + lane;
         bool usable = false;
-        int cls = -1;
         if (lane < n_live) {
             const float4 ps = points.p_slot[i];
-            const uint32_t ray_slot = float_as_uint(ps.w);
-            const uint2 xd = rays_in.xy_depth[ray_slot];
+            const uint2 xd = rays_in.xy_depth[float_as_uint(ps.w)];
             const uint32_t layer = xy_layer(xd.x, layers);
             const ShadeParams spl = layer_params(sp, layer);
-            if (sc.light_cwnodes_count != 0) {
-                const LightPick pk = pick_light(sc, f3{ps.x, ps.y, ps.z}, light_pick_random(sc, spl, xy_real(xd.x, layers, layer), xd.y));
-                store_pick(points, i, pk);
-                usable = pk.inv_prob != 0.0f;
-            }
-            if (CLASSIFY) {
-                uint32_t unused;
-                const ShadePoint pt = load_point(points, i, unused);
-                const float4 d = rays_in.d_cw[ray_slot];
-                cls = continuation_class(sc, sp.ps, f3{d.x, d.y, d.z}, xd.y, pt);
-            }
+            const LightPick pk = pick_light(sc, f3{ps.x, ps.y, ps.z}, light_pick_random(sc, spl, xy_real(xd.x, layers, layer), xd.y));
+            store_pick(points, i, pk);
+            usable = pk.inv_prob != 0.0f;
         }
         if (COMPACT) {
             const uint32_t slot = nee.alloc(stripe, usable);
             if (usable) {
                 points.nee_index[slot] = i;
-            }
-        }
-        if (CLASSIFY) {
-            for (int k = 0; k < CONT_CLASSES; ++k) {
-                if (__any(cls == k)) {
-                    const uint32_t slot = classes.q[k].alloc(stripe, cls == k);
-                    if (cls == k) {
-                        classes.index[k][slot] = i;
-                    }
-                }
             }
         }
     }
@@ -247,12 +225,15 @@ __device__ __forceinline__ bool lit_points_are_sparse(const RayQueue &pts, const
 
 // INDEXED: `in` is the queue of points that got a light (k_light_pick<true>); its slots name the point slots.
 // MODE: 0 = runs unconditionally; 1 = only if the lit points are sparse (the split form); 2 = only if they are not
-// one queue of shade points through stage 3; INDEXED: the queue's slots name the point slots through `index`
-template <bool NEE, bool CONTINUE, bool INDEXED>
-__device__ __forceinline__ void scatter_queue(const SceneView &sc, const ShadeParams &sp, const RaySoA &rays_in, const PointSoA &points, const RayQueue &in,
-                                              const uint32_t *__restrict__ index, const RaySoA &rays_out, const RayQueue &out_rays,
-                                              const ShadowSoA &shadow_out, const RayQueue &out_shadow, const PixelBuffers &px, const int img_w,
-                                              const Layering &layers) {
+template <bool NEE, bool CONTINUE, bool INDEXED = false, int MODE = 0>
+__global__ void __launch_bounds__(WAVE, (NEE && CONTINUE) ? RT_SCATTER_MIN_WAVES : (NEE ? RT_SCATTER_NEE_MIN_WAVES : RT_SCATTER_CONT_MIN_WAVES)) k_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
+                                                                       const PointSoA points, const RayQueue in, const RaySoA rays_out,
+                                                                       const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
+                                                                       const PixelBuffers px, const int img_w, const Layering layers,
+                                                                       const RayQueue all_points, const RayQueue lit_points) {
+    if (MODE != 0 && lit_points_are_sparse(all_points, lit_points) != (MODE == 1)) {
+        return;
+    }
     const uint32_t n_live_chunks = in.live_chunks();
     ChunkWalk walk(n_live_chunks);
     for (uint32_t c; walk.next(c);) {
@@ -266,7 +247,7 @@ __device__ __forceinline__ void scatter_queue(const SceneView &sc, const ShadePa
         uint32_t xy = 0;
         if (active) {
             uint32_t ray_slot;
-            const uint32_t point_slot = INDEXED ? index[slot0 + threadIdx.x] : slot0 + threadIdx.x;
+            const uint32_t point_slot = INDEXED ? points.nee_index[slot0 + threadIdx.x] : slot0 + threadIdx.x;
             const ShadePoint pt = load_point(points, point_slot, ray_slot);
             const LightPick pick = (NEE && sc.light_cwnodes_count != 0) ? load_pick(points, point_slot) : no_light_pick();
             Ray ray;
@@ -306,34 +287,6 @@ __device__ __forceinline__ void scatter_queue(const SceneView &sc, const ShadePa
                 store_ray(rays_out, ray_slot, sct.next);
             }
         }
-    }
-}
-
-template <bool NEE, bool CONTINUE, bool INDEXED = false, int MODE = 0>
-__global__ void __launch_bounds__(WAVE, (NEE && CONTINUE) ? RT_SCATTER_MIN_WAVES : (NEE ? RT_SCATTER_NEE_MIN_WAVES : RT_SCATTER_CONT_MIN_WAVES)) k_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
-                                                                       const PointSoA points, const RayQueue in, const RaySoA rays_out,
-                                                                       const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
-                                                                       const PixelBuffers px, const int img_w, const Layering layers,
-                                                                       const RayQueue all_points, const RayQueue lit_points) {
-    if (MODE != 0 && lit_points_are_sparse(all_points, lit_points) != (MODE == 1)) {
-        return;
-    }
-    scatter_queue<NEE, CONTINUE, INDEXED>(sc, sp, rays_in, points, in, points.nee_index, rays_out, out_rays, shadow_out, out_shadow, px, img_w, layers);
-}
-
-// the continuation over the points class by class (k_light_pick<., true> filed them): wavefronts whose points take the same branch
-template <int MODE = 0>
-__global__ void __launch_bounds__(WAVE, RT_SCATTER_CONT_MIN_WAVES) k_scatter_by_class(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
-                                                                       const PointSoA points, const ClassQueues classes, const RaySoA rays_out,
-                                                                       const RayQueue out_rays, const ShadowSoA shadow_out, const RayQueue out_shadow,
-                                                                       const PixelBuffers px, const int img_w, const Layering layers,
-                                                                       const RayQueue all_points, const RayQueue lit_points) {
-    if (MODE != 0 && lit_points_are_sparse(all_points, lit_points) != (MODE == 1)) {
-        return;
-    }
-#pragma unroll 1
-    for (int k = 0; k < CONT_CLASSES; ++k) { // (one copy of the stage's code: the queue is the loop variable)
-        scatter_queue<false, true, true>(sc, sp, rays_in, points, classes.q[k], classes.index[k], rays_out, out_rays, shadow_out, out_shadow, px, img_w, layers);
     }
 }
 
@@ -398,6 +351,12 @@ __global__ void __launch_bounds__(WAVE) k_shade_sky(const SceneView sc, const Sh
 // (40 of the ~110 instructions of a level) is shared out, the selection, the exchange and the per-point set-up run once per
 // eight points instead of once per sixty-four.  profiles/r03/experiments/variants_pick_*.txt; the kernel was removed.)
 
+// (Round 4 tried the continuation CLASS BY CLASS: k_light_pick filed every point under the branch its continuation takes -- principled /
+// diffuse lobe, principled / specular lobes, Diffuse material, other -- in four index lists, and the continuation walked the lists, so that
+// no wavefront ran the GGX draw for 9 of its 64 points.  Bit-identical frames, and slower: continuation 114 -> 152 ms, pick 86 -> 128 ms
+// per four 64-spp frames.  The stage moves ~80 GB per frame at 3 TB/s; an index list turns every 16-byte plane read of the rarer classes
+// into a 64-byte line, and that costs more than the idle lanes did.  profiles/r04/experiments/shade_by_class.txt; code: commit e0e002d.)
+
 // ---- launcher ---------------------------------------------------------------------------------------------------------------
 void launch(const ShadeLaunch &a) {
     hipStream_t s = a.stream;
@@ -425,27 +384,20 @@ void launch(const ShadeLaunch &a) {
     }
     // emitter hits whose MIS weight was deferred; an empty queue costs a few microseconds
     k_shade_emissive<<<std::min(g, 2048), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.deferred, a.out_deferred, a.px, a.vw);
-    // stage 2: which light (and, by_class, which branch of the continuation)
+    // stage 2: which light
     const bool nee_compact = pick_apart && (a.split & 4) != 0;
-    const bool by_class = nee_compact && (a.split & 8) != 0;
-    if (by_class) {
-        k_light_pick<true, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers, a.classes);
-    } else if (nee_compact) {
-        k_light_pick<true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers, a.classes);
+    if (nee_compact) {
+        k_light_pick<true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
     } else if (pick_apart) {
-        k_light_pick<false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers, a.classes);
+        k_light_pick<false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
     }
     // stage 3: shadow ray + continuation
     if (nee_compact) {
         // the next-event estimation runs over the points that have a light to sample -- full wavefronts instead of the 11 of 64
-        // lanes that take that branch in the combined kernel (Bistro-class scene) -- the continuation over all points (by_class: in the
-        // order of the branch they take); or, when most points are lit, the combined kernel (lit_points_are_sparse)
+        // lanes that take that branch in the combined kernel (Bistro-class scene) -- the continuation over all points; or, when
+        // most points are lit, the combined kernel (lit_points_are_sparse)
         k_scatter<true, false, true, 1><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.nee, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
-        if (by_class) {
-            k_scatter_by_class<1><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.classes, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
-        } else {
-            k_scatter<false, true, false, 1><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
-        }
+        k_scatter<false, true, false, 1><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
         k_scatter<true, true, false, 2><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
     } else if ((a.split & 2) != 0) {
         k_scatter<true, false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);

@@ -19,13 +19,6 @@ struct PointSoA {
     uint32_t *nee_index; // written by k_light_pick: the points that got a light, densely (slots of the `nee` queue -> point slots)
 };
 
-// the points of a bounce filed by the branch their continuation takes (shade_lobes.h: ContinuationClass): per class a queue (counts per
-// stripe) and the dense list of point slots its slots stand for
-struct ClassQueues {
-    RayQueue q[CONT_CLASSES];
-    uint32_t *index[CONT_CLASSES];
-};
-
 // one bounce of K5: shade the rays of queue `in` (ray buffer rays_in + hits) -> shade points (pts) -> secondary rays into
 // out_rays of rays_out, shadow rays into out_shadow, radiance into the per-iteration pixel buffer
 struct ShadeLaunch {
@@ -37,7 +30,6 @@ struct ShadeLaunch {
     DeferredSoA deferred;
     PointSoA points;
     RayQueue in, pts, out_rays, out_shadow, out_deferred, nee, out_sky;
-    ClassQueues classes;
     uint32_t *sky_index; // ray slots of the paths that ended in the physical sky (k_surface -> k_shade_sky), densely per stripe
     PixelBuffers px;
     Layering layers;
@@ -45,8 +37,7 @@ struct ShadeLaunch {
     float mix_factor; // 1 / iteration: blend of the first-hit feature images (single-layer passes)
     int bounce, grid;
     int split;        // bit 0: the light pick as its own kernel; bit 1: next-event estimation and continuation as two launches;
-                      // bit 2 (with bit 0): next-event estimation as its own launch over the points that GOT a light, densely packed;
-                      // bit 3 (with bit 2): the continuation walks the points class by class (ClassQueues)
+                      // bit 2 (with bit 0): next-event estimation as its own launch over the points that GOT a light, densely packed
     hipStream_t stream;
 };
 namespace shade {

@@ -394,30 +394,6 @@ RT_HD void principled_continue(const ScatterFrame &fr, const ShadePoint &pt, con
     }
 }
 
-// ---- which branch of the continuation a point will take -----------------------------------------------------------------------------
-// The continuation draws from ONE lobe per point, and the lobes cost hundreds of instructions each: a wavefront whose 64 points want
-// different ones runs them all (Bistro-class scene: the GGX draw with 9 of 64 lanes in 99 % of the wavefronts, the Oren-Nayar material
-// with 3 lanes in 64 %).  The light-pick kernel therefore files every point under the branch it is going to take, and the continuation
-// walks the points class by class -- same points, same arithmetic per point (the scatter stage decides again for itself, with the
-// same functions on the same values; this is only the order in which points are handed to wavefronts).
-enum ContinuationClass { CONT_PRINCIPLED_DIFFUSE = 0, CONT_PRINCIPLED_SPECULAR = 1, CONT_DIFFUSE_MATERIAL = 2, CONT_OTHER = 3, CONT_CLASSES = 4 };
-RT_HD int continuation_class(const SceneView &sc, const PassLimits &ps, const f3 ray_d, const uint32_t ray_depth, const ShadePoint &pt) {
-    const rayhip_material &mat = sc.materials[pt.material];
-    if (mat.type == NODE_DIFFUSE) {
-        return CONT_DIFFUSE_MATERIAL;
-    }
-    if (mat.type != NODE_PRINCIPLED) {
-        return CONT_OTHER;
-    }
-    ScatterFrame fr;
-    fr.P = pt.P, fr.N = pt.N, fr.B = pt.B, fr.Ng = pt.plane_N, fr.T = pt.B, fr.wo = pt.N; // (only N, I and the alpha floor enter the lobe weights)
-    fr.I = ray_d;
-    fr.floor_alpha = (get_diff_depth(ray_depth) > 0) ? ps.regularize_alpha : 0.0f;
-    fr.mix_weight = pt.mix_weight, fr.mis = false;
-    const PrincipledLobes L = principled_lobes(fr, pt, mat, 1.0f);
-    return pt.mix_pick < L.p_diffuse ? CONT_PRINCIPLED_DIFFUSE : CONT_PRINCIPLED_SPECULAR;
-}
-
 // ---- the scatter stage ------------------------------------------------------------------------------------------------------------------
 // `ray`: the ray that produced the shade point (direction, throughput, ior stack, cone, pixel, depth counters)
 template <bool NEE = true, bool CONTINUE = true>
