@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint
                 generate_primary_ray(pl, pmj, filter_table, x, y, r, h);
                 r.xy += layer_offset_xy(layers, layer);
             }
-            store_ray(rays, slot, r);
+            store_ray(rays, slot, r, p.skip_ior == 0);
             store_hit(hits, slot, h);
         }
     }
@@ -383,23 +383,12 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_closest(const SceneView sc
 #define RT_REFILL_VOTE_NUM 1
 #define RT_REFILL_VOTE_DEN 1
 #endif
-#ifndef RT_REFILL_PREFETCH_INDEX
-#define RT_REFILL_PREFETCH_INDEX 0
-#endif
 template <int WIDE, int MIN_WAIT = RT_REFILL_MIN>
 __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_refill(const SceneView sc, const TraceParams tp, const RaySoA rays,
                                                                const HitSoA hits, const RayQueue queue, const int init_hits,
                                                                uint32_t *__restrict__ stack_spill, const Layering layers) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t lane = threadIdx.x;
-#ifdef RT_EXPERIMENT_EXTRA_LDS // (tuning probe: what does the LDS footprint alone cost?  bytes of LDS that are allocated and never used)
-    __shared__ uint32_t lds_ballast[RT_EXPERIMENT_EXTRA_LDS / 4];
-    if (tp.iteration < 0) {
-        lds_ballast[lane] = lane;
-        __syncthreads();
-        hits.v[0] = float(lds_ballast[63 - lane]);
-    }
-#endif
 #ifdef RT_PROFILE_TRACE
     if (threadIdx.x < 32) {
         s_prof_acc[threadIdx.x] = 0;
@@ -423,8 +412,6 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
     uint32_t lvl = IDLE, slot = 0, cur = BVH4_SENTINEL, tos = BVH4_SENTINEL, size = 0, mi_index = 0, ray_flags = 0;
     uint32_t cur_bits = 0, tos_bits = 0, tri_base = 0, l0 = 0, l1 = 0, oct_inv = 0;
     bool res = false;
-    bool back = false; // RT_REFILL_PREFETCH_INDEX: once a leaf has reported a hit (`res`), h.prim_index is tri_indices[] of the closest hit -- requested by
-                       // the leaf step that found it, so that the finish of the ray does not wait for it -- and `back` the sign the raw index carried
     f3 ro = {0.0f, 0.0f, 0.0f}, rd = {0.0f, 0.0f, 1.0f}; // world-space origin of the current transparency segment, direction
     f3 o = ro, d = rd, inv_d = rd;                        // object-space ray of the instance being walked
     Hit h = make_hit();
@@ -509,10 +496,6 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
                     const uint32_t word = WIDE == 8 ? bvh8_take_leaf(tri_base, l0, l1) : cur;
                     const int tri_start = int(word & BVH2_PRIM_INDEX_BITS), tri_end = int(tri_start + ((word & BVH2_PRIM_COUNT_BITS) >> 29) + 1);
                     const bool hit = intersect_tris_closest(o, d, tri_table(sc), tri_start, tri_end, int(mi_index), h);
-                    if (RT_REFILL_PREFETCH_INDEX && hit) {
-                        back = h.prim_index < 0;
-                        h.prim_index = int(sc.tri_indices[back ? -h.prim_index - 1 : h.prim_index]);
-                    }
                     res |= hit;
                     if (WIDE == 8) {
                         if ((l0 | l1) == 0u && (cur_bits >> 8) == 0u) {
@@ -535,9 +518,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
             const bool in_fin = (lvl == TLAS) && (cur == BVH4_SENTINEL);
             if (in_fin) {
                 // end of Traverse_TLAS_WithStack_ClosestHit: primitive index indirection (runs on misses too)
-                if (RT_REFILL_PREFETCH_INDEX && res) {
-                    h.prim_index = back ? -h.prim_index - 1 : h.prim_index;
-                } else if (h.prim_index < 0) {
+                if (h.prim_index < 0) {
                     h.prim_index = -int(sc.tri_indices[-h.prim_index - 1]) - 1;
                 } else {
                     h.prim_index = int(sc.tri_indices[h.prim_index]);

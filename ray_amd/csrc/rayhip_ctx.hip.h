@@ -75,6 +75,7 @@ struct rayhip_ctx {
     hipStream_t stream = nullptr;
     uint32_t tri_pitch = 3; // 16-byte rows per record of `tris` as uploaded (SceneView::tri_pitch)
     uint32_t all_solid = 0; // SceneView::all_solid
+    bool plain_ior = false; // no material of the scene refracts: ShadeParams::plain_ior for the passes that start at the camera
     hipDeviceProp_t props = {};
     int grid_waves = 0; // resident-ish grid for the wave-per-block kernels
     bool small_scene = false; // BLAS nodes + triangles fit one XCD's L2: traversal kernels with the smaller register footprint

@@ -30,10 +30,11 @@ static int ensure_pass(rayhip_ctx *c, const int rect[4], int n) {
 // other ray buffer, shadow rays into shadow queue `bounce`, radiance into the per-iteration pixel buffer.  One place for
 // rayhip_render and the kernel-level hook rayhip_k_shade.
 static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration, int bounce, int cur, size_t nslots, uint32_t stripes,
-                         int gtrace, int vw, float mix_factor, const Layering &layers) {
+                         int gtrace, int vw, float mix_factor, const Layering &layers, bool plain_ior = false) {
     ShadeLaunch a;
     a.sc = c->sc;
     a.sp = make_shade_params(cam, iteration, bounce);
+    a.sp.plain_ior = plain_ior ? 1u : 0u;
     a.rays_in = c->rays[cur], a.rays_out = c->rays[cur ^ 1];
     a.hits = c->hits, a.shadow = c->shadow, a.deferred = c->deferred, a.points = c->points;
     a.in = c->ray_queue(bounce, nslots, stripes), a.pts = c->point_queue(bounce, nslots, stripes);
@@ -146,7 +147,8 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         return fail("queue counter clear failed");
     }
 
-    const RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
+    RayGenParams rg = make_raygen_params(*cam, c->w, c->h, rect, iteration, c->shard);
+    rg.skip_ior = c->plain_ior ? 1 : 0; // (the scatter stage will not read the plane: rayhip_upload.hip.h)
     const TraceParams tp = make_trace_params(*cam, c->sc.tlas_root, iteration);
     const float mix_factor = 1.0f / float(iteration);
 
@@ -198,7 +200,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         if (tm.mark(bounce == 0 ? ST_PSHADE : ST_SSHADE, -1)) {
             return 1;
         }
-        launch_shade(c, *cam, iteration, bounce, cur, nslots, stripes, gtrace, vw, mix_factor, layers);
+        launch_shade(c, *cam, iteration, bounce, cur, nslots, stripes, gtrace, vw, mix_factor, layers, c->plain_ior);
         if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
             return 1;
         }

@@ -376,6 +376,15 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     c->all_solid = all_sides_solid ? 1u : 0u;
     UPLOAD_TRACE(all_sides_solid ? "every reachable triangle side is solid" : "some triangle sides are not solid")
     UP(materials)
+    { // can any surface change a ray's stack of refractive indices?  (ShadeParams::plain_ior: if not, the passes leave the rays' ior plane alone)
+        bool refracts = false;
+        for (uint32_t i = 0; i < d->materials_count; ++i) {
+            const rayhip_material &m = d->materials[i];
+            refracts |= m.type == NODE_REFRACTIVE || (m.type == NODE_PRINCIPLED && m.transmission_unorm != 0);
+        }
+        c->plain_ior = !refracts && !getenv("RAYHIP_NO_PLAIN_IOR");
+        UPLOAD_TRACE(refracts ? "refractive surfaces: rays carry their ior stacks" : "no refractive surface: the ior plane of the rays is not used")
+    }
     UP(vertices)
     UP(vtx_indices)
     { // vertices gathered per triangle (shade_point.h: fill_tri_verts), on the device from the arrays just uploaded

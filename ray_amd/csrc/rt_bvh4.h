@@ -87,30 +87,11 @@ RT_HD void bvh4_test_node(const Bvh4Node *nodes4, const uint32_t cur, const f3 r
     // with 10 % fewer instructions (round 3; the fourth load's destination overlapped the address registers, so it went last,
     // and a compare on the first load's result was placed in front of it)
     float4 w0, w1, w2, w3;
-#ifdef RT_EXPERIMENT_EXTRA_TOUCH
-    // tuning probe: N more lane-address touches of the node being fetched -- same lines, issued with the four real loads in front of
-    // the one wait, no arithmetic, results unused: what does a lane-address cost the kernel?
-    float dummy;
-#if RT_EXPERIMENT_EXTRA_TOUCH == 1
-#define RT_EXTRA_TOUCHES "global_load_dword %4, %5, off offset:4\n\t"
-#elif RT_EXPERIMENT_EXTRA_TOUCH == 2
-#define RT_EXTRA_TOUCHES "global_load_dword %4, %5, off offset:4\n\tglobal_load_dword %4, %5, off offset:20\n\t"
-#else
-#define RT_EXTRA_TOUCHES "global_load_dword %4, %5, off offset:4\n\tglobal_load_dword %4, %5, off offset:20\n\tglobal_load_dword %4, %5, off offset:36\n\tglobal_load_dword %4, %5, off offset:52\n\t"
-#endif
-    asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %5, off offset:16\n\tglobal_load_dwordx4 %2, %5, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %5, off offset:48\n\t" RT_EXTRA_TOUCHES "s_waitcnt vmcnt(0)"
-                 : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(dummy)
-                 : "v"(np)
-                 : "memory");
-#undef RT_EXTRA_TOUCHES
-#else
     asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\tglobal_load_dwordx4 %2, %4, off offset:32\n\t"
                  "global_load_dwordx4 %3, %4, off offset:48\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
                  : "v"(np)
                  : "memory");
-#endif
 #else
     const float4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
 #endif

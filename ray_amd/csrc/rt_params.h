@@ -38,6 +38,7 @@ inline RayGenParams make_raygen_params(const rayhip_camera &cam, int w, int h, c
     p.iteration = iteration;
     p.rand_seed = iteration_rand_seed(iteration);
     p.shard = shard;
+    p.skip_ior = 0;
     return p;
 }
 
@@ -76,6 +77,7 @@ inline ShadeParams make_shade_params(const rayhip_camera &cam, int iteration, in
     }
     sp.rand_seed = iteration_rand_seed(iteration);
     sp.iteration = iteration;
+    sp.plain_ior = 0u;
     return sp;
 }
 

@@ -25,6 +25,7 @@ struct RayGenParams {
     int iteration;
     uint32_t rand_seed;
     Shard shard;
+    int skip_ior; // 1: the ior plane of the rays is not written (ShadeParams::plain_ior: nobody will read it)
 };
 
 // CoreRef.cpp:1452-1467

@@ -154,11 +154,15 @@ RT_HD Ray load_ray(const RaySoA &s, uint32_t i) {
     r.xy = xd.x, r.depth = xd.y;
     return r;
 }
-RT_HD void store_ray(const RaySoA &s, uint32_t i, const Ray &r) {
+// with_ior = false: the stack of refractive indices is not written (a pass over a scene without refractive surfaces: every ray carries the
+// stack the camera gave it, nobody reads the plane -- ShadeParams::plain_ior)
+RT_HD void store_ray(const RaySoA &s, uint32_t i, const Ray &r, const bool with_ior = true) {
     s.o_pdf[i] = mkfloat4(r.o.x, r.o.y, r.o.z, r.pdf);
     s.d_cw[i] = mkfloat4(r.d.x, r.d.y, r.d.z, r.cone_width);
     s.c_cs[i] = mkfloat4(r.c.x, r.c.y, r.c.z, r.cone_spread);
-    s.ior[i] = mkfloat4(r.ior[0], r.ior[1], r.ior[2], r.ior[3]);
+    if (with_ior) {
+        s.ior[i] = mkfloat4(r.ior[0], r.ior[1], r.ior[2], r.ior[3]);
+    }
     uint2 xd;
     xd.x = r.xy, xd.y = r.depth;
     s.xy_depth[i] = xd;

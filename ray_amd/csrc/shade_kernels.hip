@@ -252,7 +252,8 @@ __global__ void __launch_bounds__(WAVE, (NEE && CONTINUE) ? RT_SCATTER_MIN_WAVES
             const LightPick pick = (NEE && sc.light_cwnodes_count != 0) ? load_pick(points, point_slot) : no_light_pick();
             Ray ray;
             {
-                const float4 d = rays_in.d_cw[ray_slot], cc = rays_in.c_cs[ray_slot], io = rays_in.ior[ray_slot];
+                const float4 d = rays_in.d_cw[ray_slot], cc = rays_in.c_cs[ray_slot];
+                const float4 io = sp.plain_ior != 0u ? mkfloat4(-1.0f, -1.0f, -1.0f, -1.0f) : rays_in.ior[ray_slot]; // (plain_ior: the camera's stack)
                 const uint2 xd = rays_in.xy_depth[ray_slot];
                 ray.o = pt.P, ray.pdf = 0.0f; // (not read by the scatter stage)
                 ray.d = {d.x, d.y, d.z}, ray.cone_width = d.w;
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(WAVE, (NEE && CONTINUE) ? RT_SCATTER_MIN_WAVES
         if (CONTINUE) {
             const uint32_t ray_slot = out_rays.alloc(stripe, sct.has_next);
             if (sct.has_next) {
-                store_ray(rays_out, ray_slot, sct.next);
+                store_ray(rays_out, ray_slot, sct.next, sp.plain_ior == 0u);
             }
         }
     }

@@ -34,6 +34,11 @@ struct ShadeParams {
     float limits[2]; // {direct, indirect} clamp on the rgb SUM (3 x clamp) or FLT_MAX
     uint32_t rand_seed;
     int iteration;
+    // 1: no surface of the scene can change a ray's stack of refractive indices (no Refractive node, no Principled transmission) and the
+    // rays of this pass come from the camera (stack = four times -1, rt_raygen.h): the scatter stage takes that constant instead of
+    // reading the ior plane of the ray and does not write the plane of the ray it spawns -- 48 of the ~450 bytes a path vertex moves
+    // through the stage.  Set by render_pass only (kernel-level hooks are handed rays by the caller: 0).
+    uint32_t plain_ior;
 };
 
 // the per-path random stream: dimensions of this bounce, keyed by pixel and iteration

@@ -385,6 +385,20 @@ def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("name", SCENES)
+def test_unused_ior_plane_is_bit_identical(gpu_lib, name, monkeypatch):
+    """a scene without refractive surfaces: its passes neither write nor read the rays' stacks of refractive indices
+    (ShadeParams::plain_ior) -- every image the same bits as with the plane in use; scenes WITH refraction (cornell_principled)
+    keep the plane, whatever the switch says"""
+    monkeypatch.setenv("RAYHIP_NO_PLAIN_IOR", "1")
+    with_plane = util.make_context(gpu_lib, name)
+    monkeypatch.delenv("RAYHIP_NO_PLAIN_IOR")
+    default = util.make_context(gpu_lib, name)
+    with_plane.render_batch(1, 6), default.render_batch(1, 6)
+    for buf in (hip.BUF_RAW, hip.BUF_VARIANCE, hip.BUF_BASE_COLOR, hip.BUF_DEPTH_NORMALS):
+        assert np.array_equal(default.readback(buf), with_plane.readback(buf)), buf
+
+
+@pytest.mark.parametrize("name", SCENES)
 def test_flat_shadow_kernel_is_bit_identical(gpu_lib, name, monkeypatch):
     """K3 as the flat persistent kernel (k_trace_shadow_refill, the default over the 4-wide tree) against the nested form: the
     throughput of the oracle's own shadow rays (hook) and whole frames -- transparent surfaces between a point and its light
