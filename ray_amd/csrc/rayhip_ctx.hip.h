@@ -141,7 +141,7 @@ struct rayhip_ctx {
     PointSoA points = {};
     // how the shade stage is cut into launches (kernels.hip.h): bit 0 = the light pick as its own kernel, bit 1 = next-event
     // estimation and continuation as two scatter launches.  RAYHIP_SHADE_SPLIT overrides (A/B measurements).
-    int shade_split = 5; // shade_launch.h: bit 0 pick as its own kernel, bit 1 NEE / continuation as two launches, bit 2 NEE over the compacted queue of points that got a light
+    int shade_split = 13; // shade_launch.h: bit 0 pick as its own kernel, bit 1 NEE / continuation as two launches, bit 2 NEE over the compacted queue of points that got a light, bit 3 the light pick with lane refill
     RaySoA rays[2] = {};
     HitSoA hits = {};
     ShadowSoA shadow = {};
@@ -450,7 +450,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         c->sort_key_mode = std::max(0, std::min(3, atoi(e)));
     }
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
-        c->shade_split = atoi(e) & 7;
+        c->shade_split = atoi(e) & 15;
     }
     // The persistent ray-refill form of the closest-hit kernel (kernels.hip.h): lanes whose ray is finished fetch the next one
     // instead of idling until the longest walk of their wavefront ends.  RAYHIP_REFILL: 2 = for the secondary

@@ -209,6 +209,111 @@ __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick(const Sc
     }
 }
 
+// The same pick with lanes that take the next point as soon as theirs is through (round 4).  A descent ends where a subtree cannot light
+// the point -- at the root for some points, five levels down for others: in the chunk-at-a-time kernel above 58 % of the lanes were busy
+// (profiles/r03/pmc_sq_tcc_summary.txt).  A lane's whole state is eight registers (position, random number, probability, node), so a
+// finished lane is refilled for the price of two loads and one Owen-scrambled sample, once RT_PICK_REFILL_MIN lanes wait for it.  Per
+// point the descent is pick_light's, statement for statement: the same pick in the same slot; only the order of the `nee` list differs.
+#ifndef RT_PICK_REFILL_MIN
+#define RT_PICK_REFILL_MIN 16
+#endif
+template <bool COMPACT>
+__global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick_refill(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
+                                                                              const PointSoA points, const RayQueue queue, const RayQueue nee,
+                                                                              const Layering layers) {
+    const uint32_t lane = threadIdx.x;
+    ChunkWalk walk(queue.live_chunks());
+    uint32_t pool_slot = 0, pool_left = 0, pool_stripe = 0; // (uniform) the chunk being handed out
+    bool exhausted = false;                                  // (uniform) no chunk left to hand out
+    // lane state
+    bool busy = false;
+    uint32_t i = 0, stripe = 0, cur = 0;
+    f3 P = {0.0f, 0.0f, 0.0f};
+    float u = 0.0f, u_first = 0.0f, prob = 1.0f;
+    for (;;) {
+        const int n_idle = __popcll(__ballot(!busy));
+        if (!exhausted && n_idle >= RT_PICK_REFILL_MIN) {
+            for (;;) {
+                const unsigned long long idle_mask = __ballot(!busy);
+                if (idle_mask == 0ull) {
+                    break;
+                }
+                if (pool_left == 0) {
+                    int found = 0;
+                    uint32_t next_chunk;
+                    while (!found && walk.next(next_chunk)) { // (uniform)
+                        uint32_t s, slot0, n_live;
+                        found = __builtin_amdgcn_readfirstlane(int(queue.chunk(next_chunk, s, slot0, n_live)));
+                        if (found) {
+                            pool_slot = uint32_t(__builtin_amdgcn_readfirstlane(int(slot0)));
+                            pool_left = uint32_t(__builtin_amdgcn_readfirstlane(int(n_live)));
+                            pool_stripe = uint32_t(__builtin_amdgcn_readfirstlane(int(s)));
+                        }
+                    }
+                    if (!found) {
+                        exhausted = true;
+                        break;
+                    }
+                }
+                const uint32_t rank = uint32_t(__popcll(idle_mask & ((1ull << lane) - 1ull)));
+                const uint32_t n_take = min(uint32_t(__popcll(idle_mask)), pool_left);
+                if (!busy && rank < n_take) {
+                    i = pool_slot + rank, stripe = pool_stripe;
+                    const float4 ps = points.p_slot[i];
+                    const uint2 xd = rays_in.xy_depth[float_as_uint(ps.w)];
+                    const uint32_t layer = xy_layer(xd.x, layers);
+                    const ShadeParams spl = layer_params(sp, layer);
+                    P = {ps.x, ps.y, ps.z};
+                    u = u_first = light_pick_random(sc, spl, xy_real(xd.x, layers, layer), xd.y);
+                    prob = 1.0f, cur = 0;
+                    busy = true;
+                }
+                pool_slot += n_take, pool_left -= n_take;
+            }
+        }
+        if (__ballot(busy) == 0ull) {
+            if (exhausted) {
+                break;
+            }
+            continue; // (every lane idle: the next round refills)
+        }
+        // one level of the descent for the lanes that hold a point (pick_light, shade_lights.h)
+        bool lit = false;
+        if (busy) {
+            LightPick pk;
+            pk.light = 0, pk.inv_prob = 0.0f, pk.u_left = u_first;
+            float imp[8];
+            light_node_importances(sc, cur, P, imp);
+            int chosen;
+            bool done = !light_level_choice(imp, u, prob, chosen); // false: nothing in this subtree can light P
+            if (!done) {
+                cur = light_child_link(sc, cur, chosen);
+                if ((cur & LEAF_NODE_BIT) != 0) {
+                    pk.light = (cur & PRIM_INDEX_BITS), pk.inv_prob = 1.0f / prob, pk.u_left = u;
+                    done = true;
+                }
+            }
+            if (done) {
+                store_pick(points, i, pk);
+                lit = pk.inv_prob != 0.0f;
+                busy = false;
+            }
+        }
+        if (COMPACT) { // the points that got a light join the `nee` list of their stripe (the lanes of a wavefront hold at most a few stripes)
+            unsigned long long todo = __ballot(lit);
+            while (todo != 0ull) {
+                const uint32_t s = uint32_t(__shfl(int(stripe), __ffsll((long long)todo) - 1));
+                const bool mine = lit && stripe == s;
+                const uint32_t slot = nee.alloc(uint32_t(__builtin_amdgcn_readfirstlane(int(s))), mine);
+                if (mine) {
+                    points.nee_index[slot] = i;
+                }
+                todo &= ~__ballot(mine);
+            }
+        }
+    }
+}
+
 // Which form of stage 3 runs is decided on the device, from the two fill counts k_light_pick left behind, by every wavefront of
 // the three candidate launches in the same way (wavefront-collective: all 64 lanes active): the split form when fewer than half
 // of the points have a light to sample -- otherwise the work both launches repeat (frame, lobe set-up, loads) costs more than
@@ -387,7 +492,12 @@ void launch(const ShadeLaunch &a) {
     k_shade_emissive<<<std::min(g, 2048), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.deferred, a.out_deferred, a.px, a.vw);
     // stage 2: which light
     const bool nee_compact = pick_apart && (a.split & 4) != 0;
-    if (nee_compact) {
+    const bool pick_refill = (a.split & 8) != 0;
+    if (nee_compact && pick_refill) {
+        k_light_pick_refill<true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
+    } else if (pick_apart && pick_refill) {
+        k_light_pick_refill<false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
+    } else if (nee_compact) {
         k_light_pick<true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
     } else if (pick_apart) {
         k_light_pick<false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);

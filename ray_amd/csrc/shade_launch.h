@@ -37,7 +37,8 @@ struct ShadeLaunch {
     float mix_factor; // 1 / iteration: blend of the first-hit feature images (single-layer passes)
     int bounce, grid;
     int split;        // bit 0: the light pick as its own kernel; bit 1: next-event estimation and continuation as two launches;
-                      // bit 2 (with bit 0): next-event estimation as its own launch over the points that GOT a light, densely packed
+                      // bit 2 (with bit 0): next-event estimation as its own launch over the points that GOT a light, densely packed;
+                      // bit 3 (with bit 0): the light pick as a persistent kernel whose lanes take the next point when theirs is through
     hipStream_t stream;
 };
 namespace shade {

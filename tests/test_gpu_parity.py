@@ -385,6 +385,23 @@ def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("name", SCENES)
+def test_light_pick_with_lane_refill_is_bit_identical(gpu_lib, name, monkeypatch):
+    """the light pick as a persistent kernel whose lanes take the next point when their descent is over (k_light_pick_refill, the
+    default) against the chunk-at-a-time kernel: per point the same descent, so every image is the same bits (the list of lit
+    points comes out in another order, which no pixel can see)"""
+    monkeypatch.setenv("RAYHIP_SHADE_SPLIT", "5")
+    chunked = util.make_context(gpu_lib, name)
+    monkeypatch.delenv("RAYHIP_SHADE_SPLIT")
+    default = util.make_context(gpu_lib, name)
+    chunked.render_batch(1, 6), default.render_batch(1, 6)
+    for buf in (hip.BUF_RAW, hip.BUF_VARIANCE):
+        assert np.array_equal(default.readback(buf), chunked.readback(buf)), buf
+    for it in range(7, 9):  # single-layer passes
+        chunked.render(it), default.render(it)
+    assert np.array_equal(default.readback(hip.BUF_RAW), chunked.readback(hip.BUF_RAW))
+
+
+@pytest.mark.parametrize("name", SCENES)
 def test_unused_ior_plane_is_bit_identical(gpu_lib, name, monkeypatch):
     """a scene without refractive surfaces: its passes neither write nor read the rays' stacks of refractive indices
     (ShadeParams::plain_ior) -- every image the same bits as with the plane in use; scenes WITH refraction (cornell_principled)
