@@ -26,7 +26,7 @@ def main():
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
     for K in Ks:
         base = None
-        print(f"== {workload} {W}x{H}, {K} spp (what `bench.py --steps {K}` asks of every rank)")
+        print(f"== {workload} {W}x{H}, one frame of {K} spp (64: a step of `bench.py` since round 4; 20: the frame of round 3's driver line)")
         for world in (1, 2, 4, 8):
             ctx = hip.Context(0)
             ctx.upload_static(api.pmj_table())
