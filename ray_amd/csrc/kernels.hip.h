@@ -157,13 +157,14 @@ struct RayGenTiling {
     uint32_t owned_only;    // 1: walk only the shard tiles this rank owns
     uint32_t sub;           // 8x8 tiles per shard-tile side (shard.tile / 8)
     uint32_t shard_tiles_x; // shard tiles per frame row
+    uint32_t samples_per_wave; // 1: a wavefront = one 8x8 tile of one layer; S = 4 / 16 / 64: a block of 64 / S pixels of the tile in S consecutive layers
 };
 // host and device: the tiling of a rect under a shard (owned_only needs shard tiles that are whole 8x8 tiles)
 __host__ __device__ inline RayGenTiling make_raygen_tiling(const int frame_w, const int frame_h, const int rect_w, const int rect_h, const Shard sh) {
     RayGenTiling t;
     t.tiles_x = uint32_t(rect_w + 7) / 8u;
     t.tiles = t.tiles_x * (uint32_t(rect_h + 7) / 8u);
-    t.owned_only = 0, t.sub = 1, t.shard_tiles_x = 1;
+    t.owned_only = 0, t.sub = 1, t.shard_tiles_x = 1, t.samples_per_wave = 1;
     if (sh.count > 1 && sh.tile % 8 == 0) {
         const uint32_t stx = uint32_t(frame_w + sh.tile - 1) / uint32_t(sh.tile), sty = uint32_t(frame_h + sh.tile - 1) / uint32_t(sh.tile);
         const uint32_t total = stx * sty;
@@ -192,18 +193,29 @@ __global__ void __launch_bounds__(256) k_raygen(const RayGenParams p, const uint
     const uint32_t lane = threadIdx.x % WAVE;
     // pixel chunk pc -> stripe pc % stripes: every stripe gets at most ceil(n_chunks / stripes) chunks
     for (uint32_t pc = blockIdx.x * waves_per_block + threadIdx.x / WAVE; pc < n_chunks; pc += gridDim.x * waves_per_block) {
-        const uint32_t layer = pc / tiles, tile = pc % tiles; // wave-uniform
+        uint32_t layer = pc / tiles;
+        const uint32_t tile = pc % tiles; // wave-uniform
+        uint32_t in_x = lane & 7u, in_y = lane >> 3; // the lane's pixel inside the 8x8 tile
+        if (tiling.samples_per_wave > 1) {
+            // S = 4, 16 or 64 samples of a pixel in one wavefront: chunk `layer` of a group of S stands for one (8 / sqrt S)-pixel-wide
+            // block of the tile in all S layers of the group (the S rays of a pixel walk the same nodes, hit the same triangle, read
+            // the same texels)
+            const uint32_t S = tiling.samples_per_wave, side = S == 4 ? 4u : (S == 16 ? 2u : 1u), per_row = 8u / side;
+            const uint32_t block = layer & (S - 1u);
+            in_x = (lane % side) + side * (block % per_row), in_y = ((lane / side) % side) + side * (block / per_row);
+            layer = (layer & ~(S - 1u)) + lane / (side * side);
+        }
         int x, y;
         bool in_rect;
         if (tiling.owned_only) {
             const uint32_t sub_n = tiling.sub * tiling.sub, owned = tile / sub_n, sub = tile % sub_n;
             const uint32_t t = uint32_t(p.shard.index) + owned * uint32_t(p.shard.count); // frame shard-tile ordinal
-            x = int((t % tiling.shard_tiles_x) * uint32_t(p.shard.tile) + (sub % tiling.sub) * 8u + (lane & 7u));
-            y = int((t / tiling.shard_tiles_x) * uint32_t(p.shard.tile) + (sub / tiling.sub) * 8u + (lane >> 3));
+            x = int((t % tiling.shard_tiles_x) * uint32_t(p.shard.tile) + (sub % tiling.sub) * 8u + in_x);
+            y = int((t / tiling.shard_tiles_x) * uint32_t(p.shard.tile) + (sub / tiling.sub) * 8u + in_y);
             in_rect = x >= p.rect[0] && y >= p.rect[1] && x < p.rect[0] + p.rect[2] && y < p.rect[1] + p.rect[3];
             x = in_rect ? x : p.rect[0], y = in_rect ? y : p.rect[1];
         } else {
-            const int lx = int((tile % tiling.tiles_x) * 8u + (lane & 7u)), ly = int((tile / tiling.tiles_x) * 8u + (lane >> 3));
+            const int lx = int((tile % tiling.tiles_x) * 8u + in_x), ly = int((tile / tiling.tiles_x) * 8u + in_y);
             in_rect = lx < p.rect[2] && ly < p.rect[3];
             x = p.rect[0] + (in_rect ? lx : 0), y = p.rect[1] + (in_rect ? ly : 0);
         }

@@ -85,6 +85,11 @@ struct rayhip_ctx {
     // RAYHIP_PRIMARY_WAVES / RAYHIP_SHADOW_WAVES: register footprint of the plain K2 (primary rays) / of K3.  K3 runs at 5 waves per
     // SIMD (96 VGPRs, 32 spilled registers per ray instead of 51 at 6 waves: same time, a third less scratch traffic)
     int tune_primary_waves = 0, tune_shadow_waves = 5;
+    // layered passes: a primary wavefront holds S samples of each of 64 / S pixels of an 8x8 tile (RayGenTiling).  Measured on the headline
+    // scene, 64-layer passes (profiles/r04/experiments/raygen_samples_per_wave.txt): primary K2 268 / 250 / 237 / 223 us per sample for
+    // S = 1 / 4 / 16 / 64 -- the S rays of a pixel walk the same nodes -- and the primary shade 287 / 294 / 397 / 545: its three 16-byte
+    // pixel writes per ray stay in runs of four pixels at S = 4 and scatter over the layers beyond.  4 is the default; RAYHIP_RAYGEN_SAMPLES
+    int raygen_samples_per_wave = 4;
     bool shadow_refill = true; // K3 as the flat persistent kernel (4-wide walk); RAYHIP_SHADOW_REFILL=0: the nested form
     bool refill_secondary_only = false; // RAYHIP_REFILL=2: primary rays (coherent, every lane busy to the end) keep the plain kernel
     bool refill_primary_whole = false;  // RAYHIP_REFILL=3: ... or take the flat kernel with whole-chunk refills (no spill stores in the walk)
@@ -442,6 +447,10 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     }
     if (const char *e = getenv("RAYHIP_SHADOW_WAVES")) {
         c->tune_shadow_waves = atoi(e);
+    }
+    if (const char *e = getenv("RAYHIP_RAYGEN_SAMPLES")) {
+        const int v = atoi(e);
+        c->raygen_samples_per_wave = (v == 4 || v == 16 || v == 64) ? v : 1;
     }
     if (const char *e = getenv("RAYHIP_SHADOW_REFILL")) {
         c->shadow_refill = atoi(e) != 0;

@@ -83,7 +83,10 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     const Layering layers = make_layering(c->w, c->h, count_iterations);
     const int vw = virtual_width(layers); // row pitch of the per-iteration pixel buffers
     // ray slots: the 8x8 tiles the ray generator walks (this rank's share under a shard), one set per iteration in flight
-    const RayGenTiling tiling = make_raygen_tiling(c->w, c->h, rect[2], rect[3], c->shard);
+    RayGenTiling tiling = make_raygen_tiling(c->w, c->h, rect[2], rect[3], c->shard);
+    if (c->raygen_samples_per_wave > 1 && layers.count % c->raygen_samples_per_wave == 0) {
+        tiling.samples_per_wave = uint32_t(c->raygen_samples_per_wave);
+    }
     const size_t nslots = size_t(tiling.tiles) * 64u * size_t(count_iterations);
     if (!pass_fits(c, rect, count_iterations)) {
         return fail("internal: pass of %d iterations exceeds the allocated wavefront state", count_iterations);

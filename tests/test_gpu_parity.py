@@ -401,6 +401,28 @@ def test_light_pick_with_lane_refill_is_bit_identical(gpu_lib, name, monkeypatch
     assert np.array_equal(default.readback(hip.BUF_RAW), chunked.readback(hip.BUF_RAW))
 
 
+@pytest.mark.parametrize("name", ["cornell_principled", "cornell_instances"])
+def test_several_samples_of_a_pixel_in_one_wavefront_are_bit_identical(gpu_lib, name, monkeypatch):
+    """the ray generator of a layered pass puts S samples of each of 64 / S pixels into a wavefront (S = 4 by default,
+    RAYHIP_RAYGEN_SAMPLES = 1 / 16 / 64: one sample of 64 pixels ... 64 samples of one) -- another order of the same rays, so every
+    image is the same bits (passes of 16 and of 12 layers, a rect, and a pass whose layer count is not a multiple of S, which
+    falls back to the plain order)"""
+    ctxs = {}
+    for s in ("1", "4", "16", "64"):
+        monkeypatch.setenv("RAYHIP_RAYGEN_SAMPLES", s)
+        ctxs[s] = util.make_context(gpu_lib, name)
+    monkeypatch.delenv("RAYHIP_RAYGEN_SAMPLES")
+    ctxs["default"] = util.make_context(gpu_lib, name)
+    for ctx in ctxs.values():
+        ctx.render_batch(1, 16)
+        ctx.render_batch(17, 12, rect=(8, 16, 40, 24))
+        ctx.render_batch(29, 6)
+        ctx.render_batch(35, 64)
+    for s, ctx in ctxs.items():
+        for buf in (hip.BUF_RAW, hip.BUF_VARIANCE, hip.BUF_BASE_COLOR, hip.BUF_DEPTH_NORMALS):
+            assert np.array_equal(ctx.readback(buf), ctxs["1"].readback(buf)), (s, buf)
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_unused_ior_plane_is_bit_identical(gpu_lib, name, monkeypatch):
     """a scene without refractive surfaces: its passes neither write nor read the rays' stacks of refractive indices
