@@ -75,48 +75,59 @@ RT_HD f4 tonemap(const AccumParams &p, f4 c) {
 // TonemapRef.h:7-9
 RT_HD f4 reversible_tonemap(f4 c) { return c / (fmaxf(c.x, fmaxf(c.y, c.z)) + 1.0f); }
 
+// One pixel's accumulation state: what an iteration's accumulate step reads and leaves behind (RendererCPU.h:607-658).
+struct AccumPixel {
+    f4 full, half;     // running means over all / over the class-A iterations
+    f4 variance;       // estimate left by the last iteration
+    uint16_t required; // required_samples
+};
+// One iteration folded into the state: the radiance `t` of the iteration joins the running means (if the pixel is still being sampled),
+// the variance estimate and the adaptive-sampling mark follow.  What the iteration would write to raw / final is a function of the state
+// it leaves (accum_outputs), so a pass of many layers keeps the state in registers and writes once (k_accumulate).
+RT_HD void accumulate_step(const AccumParams &p, const float4 t, AccumPixel &s) {
+    if (!(s.required < p.iteration)) {
+        // new_val = temp * {exposure, exposure, exposure, 1}
+        const f4 new_val = {t.x * p.exposure, t.y * p.exposure, t.z * p.exposure, t.w * 1.0f};
+        s.full += (new_val - s.full) * p.mix_factor;
+        if (p.is_class_a) {
+            s.half += (new_val - s.half) * p.half_mix_factor;
+        }
+    }
+    // variance estimate from the two half-sample images, RendererCPU.h:641-645
+    f4 d = 2.0f * s.full - s.half;
+    d = {sse_max(d.x, 0.0f), sse_max(d.y, 0.0f), sse_max(d.z, 0.0f), sse_max(d.w, 0.0f)};
+    const f4 p1 = reversible_tonemap(d);
+    const f4 p2 = reversible_tonemap(s.half);
+    s.variance = 0.5f * (p1 - p2) * (p1 - p2);
+    if (s.variance.x >= p.variance_threshold || s.variance.y >= p.variance_threshold || s.variance.z >= p.variance_threshold ||
+        s.variance.w >= p.variance_threshold) {
+        s.required = uint16_t(p.iteration + 1);
+    }
+}
+RT_HD AccumPixel load_accum_pixel(const int idx, const float4 *full_buf, const float4 *half_buf, const uint16_t *required_samples) {
+    const float4 ff = full_buf[idx], hh = half_buf[idx];
+    return AccumPixel{f4{ff.x, ff.y, ff.z, ff.w}, f4{hh.x, hh.y, hh.z, hh.w}, f4{0.0f, 0.0f, 0.0f, 0.0f}, required_samples[idx]};
+}
+RT_HD void store_accum_pixel(const AccumParams &p, const int idx, const AccumPixel &s, float4 *variance_px, float4 *full_buf, float4 *half_buf,
+                             float4 *raw_buf, float4 *final_buf, uint16_t *required_samples) {
+    const float4 ff = mkfloat4(s.full.x, s.full.y, s.full.z, s.full.w);
+    full_buf[idx] = ff;
+    half_buf[idx] = mkfloat4(s.half.x, s.half.y, s.half.z, s.half.w);
+    raw_buf[idx] = ff;
+    const f4 c = tonemap(p, s.full);
+    final_buf[idx] = mkfloat4(c.x, c.y, c.z, c.w);
+    *variance_px = mkfloat4(s.variance.x, s.variance.y, s.variance.z, s.variance.w);
+    required_samples[idx] = s.required;
+}
+
 // temp_px: this pixel's radiance of the iteration; variance_px: where its variance estimate goes (the reference reuses
 // the temp buffer's element)
 RT_HD void accumulate_pixel(const AccumParams &p, const int x, const int y, const float4 *temp_px, float4 *variance_px,
                             float4 *full_buf, float4 *half_buf, float4 *raw_buf, float4 *final_buf, uint16_t *required_samples) {
     const int idx = y * p.w + x;
-
-    if (!(required_samples[idx] < p.iteration)) {
-        const float4 t = *temp_px;
-        // new_val = temp * {exposure, exposure, exposure, 1}
-        const f4 new_val = {t.x * p.exposure, t.y * p.exposure, t.z * p.exposure, t.w * 1.0f};
-        const float4 ff = full_buf[idx];
-        f4 cur_full = {ff.x, ff.y, ff.z, ff.w};
-        cur_full += (new_val - cur_full) * p.mix_factor;
-        full_buf[idx] = mkfloat4(cur_full.x, cur_full.y, cur_full.z, cur_full.w);
-        if (p.is_class_a) {
-            const float4 hh = half_buf[idx];
-            f4 cur_half = {hh.x, hh.y, hh.z, hh.w};
-            cur_half += (new_val - cur_half) * p.half_mix_factor;
-            half_buf[idx] = mkfloat4(cur_half.x, cur_half.y, cur_half.z, cur_half.w);
-        }
-    }
-
-    const float4 ff = full_buf[idx], hh = half_buf[idx];
-    const f4 full_val = {ff.x, ff.y, ff.z, ff.w}, half_val = {hh.x, hh.y, hh.z, hh.w};
-
-    raw_buf[idx] = ff;
-
-    const f4 c = tonemap(p, full_val);
-    final_buf[idx] = mkfloat4(c.x, c.y, c.z, c.w);
-
-    // variance estimate from the two half-sample images, RendererCPU.h:641-645
-    f4 d = 2.0f * full_val - half_val;
-    d = {sse_max(d.x, 0.0f), sse_max(d.y, 0.0f), sse_max(d.z, 0.0f), sse_max(d.w, 0.0f)};
-    const f4 p1 = reversible_tonemap(d);
-    const f4 p2 = reversible_tonemap(half_val);
-    const f4 variance = 0.5f * (p1 - p2) * (p1 - p2);
-    *variance_px = mkfloat4(variance.x, variance.y, variance.z, variance.w);
-
-    if (variance.x >= p.variance_threshold || variance.y >= p.variance_threshold || variance.z >= p.variance_threshold ||
-        variance.w >= p.variance_threshold) {
-        required_samples[idx] = uint16_t(p.iteration + 1);
-    }
+    AccumPixel s = load_accum_pixel(idx, full_buf, half_buf, required_samples);
+    accumulate_step(p, *temp_px, s);
+    store_accum_pixel(p, idx, s, variance_px, full_buf, half_buf, raw_buf, final_buf, required_samples);
 }
 
 } // namespace rt
