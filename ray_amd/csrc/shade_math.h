@@ -294,22 +294,25 @@ RT_HD f3 rotate_about_axis(const f3 p, const f3 k, const float angle) {
 }
 
 // The four-entry stack of refractive indices a ray is inside of (ray_data_t::ior; negative = free slot; ShadeRef.cpp:360-391)
+// (written with selects over all four entries, not "find the slot, then store": a store through a computed index puts the whole
+// array -- i.e. every ray's stack, in the common case where nothing refracts -- into scratch memory: four stores and four loads per
+// shade point in both halves of k_scatter)
 RT_HD void ior_stack_enter(float stack[4], const float ior) {
-    for (int i = 0; i < 3; ++i) {
-        if (stack[i] < 0.0f) {
-            stack[i] = ior;
-            return;
-        }
-    }
-    stack[3] = ior; // full: the top entry is overwritten
+    // the first free entry from the bottom; a full stack has its top entry overwritten
+    const bool at0 = stack[0] < 0.0f, at1 = !at0 && stack[1] < 0.0f, at2 = !at0 && !at1 && stack[2] < 0.0f, at3 = !at0 && !at1 && !at2;
+    stack[0] = at0 ? ior : stack[0];
+    stack[1] = at1 ? ior : stack[1];
+    stack[2] = at2 ? ior : stack[2];
+    stack[3] = at3 ? ior : stack[3];
 }
 RT_HD void ior_stack_leave(float stack[4]) {
-    for (int i = 3; i >= 0; --i) {
-        if (stack[i] > 0.0f) {
-            stack[i] = -1.0f;
-            return;
-        }
-    }
+    // the topmost occupied entry, if any
+    const bool at3 = stack[3] > 0.0f, at2 = !at3 && stack[2] > 0.0f, at1 = !at3 && !at2 && stack[1] > 0.0f,
+               at0 = !at3 && !at2 && !at1 && stack[0] > 0.0f;
+    stack[3] = at3 ? -1.0f : stack[3];
+    stack[2] = at2 ? -1.0f : stack[2];
+    stack[1] = at1 ? -1.0f : stack[1];
+    stack[0] = at0 ? -1.0f : stack[0];
 }
 // the medium on the far side of the surface: the top of the stack, or the entry below it when the ray is leaving the
 // top medium (skip_top); vacuum when there is none

@@ -5,13 +5,10 @@ OUT=$REPO/gpurun_out/r04t
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp RAY_AMD_CACHE=/tmp/ray_amd_cache
 cd $REPO
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_comm.py tests/test_gpu_renderer_devices.py -m gpu -q -x -k "batch or determin or golden or frame or adaptive or shard or comm or devices or filmic" > $OUT/gputest.log 2>&1; echo "pytest exit $?"; tail -3 $OUT/gputest.log
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_shade_kernel.py tests/test_gpu_baseline_configs.py -m gpu -q -x -k "golden or frame or principled or zoo or refract or shade or ior" > $OUT/gputest.log 2>&1; echo "pytest exit $?"; tail -3 $OUT/gputest.log
 for i in 1 2; do
 timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench$i.json 2> $OUT/bench$i.err; echo "bench exit $?"
 python3 -c "
 import json; d=json.load(open('$OUT/bench$i.json')); print(round(d['value'],1), 'Msamples/s', round(d['ms_per_step'],2), 'ms', {k: round(v) for k,v in d['stage_us_per_spp'].items()}, d.get('parity'))"
 done
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
-grep "k_accumulate\|k_raygen" $(find $OUT/stats -name '*kernel_stats.csv' | head -1) | cut -c1-200
-find $OUT -name '*.csv' -size +6M -delete; find $OUT -name '*.db' -delete
