@@ -143,10 +143,11 @@ RT_HD void load_ray_od(const RaySoA &s, uint32_t i, Ray &r) {
     r.d = {b.x, b.y, b.z};
     r.cone_width = b.w;
 }
-RT_HD Ray load_ray(const RaySoA &s, uint32_t i) {
+// with_ior = false: the plane is not read and the ray gets the stack the camera gives every ray (see store_ray)
+RT_HD Ray load_ray(const RaySoA &s, uint32_t i, const bool with_ior = true) {
     Ray r;
     load_ray_od(s, i, r);
-    const float4 c = s.c_cs[i], io = s.ior[i];
+    const float4 c = s.c_cs[i], io = with_ior ? s.ior[i] : mkfloat4(-1.0f, -1.0f, -1.0f, -1.0f);
     const uint2 xd = s.xy_depth[i];
     r.c = {c.x, c.y, c.z};
     r.cone_spread = c.w;

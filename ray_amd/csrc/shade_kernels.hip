@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(WAVE, RT_SURFACE_MIN_WAVES) k_surface(const Sc
         SurfaceOut so;
         LightPick pick = no_light_pick();
         if (active) {
-            Ray ray = load_ray(rays_in, i);
+            Ray ray = load_ray(rays_in, i, sp.plain_ior == 0u); // (plain_ior: the ior plane is not written -- the mix nodes' Fresnel term reads the stack)
             const Hit hit = load_hit(hits, i);
             const uint32_t xy = ray.xy; // virtual (layered) pixel: where the pixel writes go
             const uint32_t layer = xy_layer(xy, layers);
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(WAVE) k_shade_sky(const SceneView sc, const Sh
             continue;
         }
         const uint32_t i = sky_index[slot0 + lane];
-        Ray ray = load_ray(rays_in, i);
+        Ray ray = load_ray(rays_in, i, sp.plain_ior == 0u);
         const Hit hit = load_hit(hits, i);
         const uint32_t xy = ray.xy, layer = xy_layer(xy, layers);
         const ShadeParams spl = layer_params(sp, layer);

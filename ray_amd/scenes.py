@@ -127,6 +127,25 @@ def cornell_basic(scene, **cam_overrides):
     scene.Finalize()
 
 
+def cornell_fresnel_mix(scene, **cam_overrides):
+    """the Cornell box with its blocks in a Fresnel-weighted mix (a Mix node WITH an ior: its weight takes the medium outside the
+    surface from the ray's ior stack, ShadeRef.cpp mix loop) of a diffuse and a glossy material -- and nothing that refracts: the scene
+    whose passes leave the rays' ior plane alone although one of its nodes asks for the stack"""
+    scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.0, 0.0)))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.0, 0.5, 0.0)))
+    lamp = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=100.0, importance_sample=True))
+    gloss = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=(0.9, 0.9, 0.9), roughness=0.1))
+    coated = scene.AddMaterial(ShadingNode(type=eShadingNode.Mix, strength=1.0, ior=1.5, mix_materials=(grey, gloss)))
+    attrs, idx = cornell_mesh_arrays()
+    groups = [(grey, None, 0, 18), (red, None, 19, 6), (green, None, 25, 6), (lamp, 0xFFFFFFFF, 31, 6), (coated, None, 37, 60)]
+    mesh = scene.AddMesh(attrs, idx, groups)
+    scene.AddMeshInstance(mesh)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
+
+
 def cornell_filmic(scene, **cam_overrides):
     """cornell_basic through a look-up-table view transform (eViewTransform.Filmic_HighContrast = 8, TonemapRef.cpp:15-26)
     and a display gamma: exercises TonemapFilmic + the pow() branch of Tonemap()"""

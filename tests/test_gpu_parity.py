@@ -426,7 +426,7 @@ def test_several_samples_of_a_pixel_in_one_wavefront_are_bit_identical(gpu_lib, 
 @pytest.mark.parametrize("name", SCENES)
 def test_unused_ior_plane_is_bit_identical(gpu_lib, name, monkeypatch):
     """a scene without refractive surfaces: its passes neither write nor read the rays' stacks of refractive indices
-    (ShadeParams::plain_ior) -- every image the same bits as with the plane in use; scenes WITH refraction (cornell_principled)
+    (ShadeParams::plain_ior) -- every image the same bits as with the plane in use; scenes WITH refraction (cornell_lights)
     keep the plane, whatever the switch says"""
     monkeypatch.setenv("RAYHIP_NO_PLAIN_IOR", "1")
     with_plane = util.make_context(gpu_lib, name)
@@ -435,6 +435,35 @@ def test_unused_ior_plane_is_bit_identical(gpu_lib, name, monkeypatch):
     with_plane.render_batch(1, 6), default.render_batch(1, 6)
     for buf in (hip.BUF_RAW, hip.BUF_VARIANCE, hip.BUF_BASE_COLOR, hip.BUF_DEPTH_NORMALS):
         assert np.array_equal(default.readback(buf), with_plane.readback(buf)), buf
+
+
+def test_a_stale_ior_plane_is_never_read(gpu_lib, hostsim_lib):
+    """a context that rendered a scene WITH refraction (its rays' ior planes hold real stacks) and is then handed one without: its
+    passes leave the plane alone (plain_ior), so nothing of that scene may read it -- the Fresnel weight of a mix node takes the medium
+    outside from the stack -- and the frames must equal a fresh context's, and the host build's"""
+    from ray_amd import api, scenes
+    if not os.path.exists(api.HIP_HOST_LIB):
+        pytest.skip("libray_hip.so not built (needs the reference tree at build time)")
+    r = api.CreateRenderer(api.Settings(64, 64), "HIP")
+    s = r.CreateScene()
+    scenes.cornell_fresnel_mix(s)
+    blob = api.export_scene_blob(s)
+    used = util.make_context(gpu_lib, "cornell_lights")
+    used.render_batch(1, 8)  # (a Refractive block: positive entries in the ior planes of both ray buffers)
+    used.upload_scene_blob(blob)
+    fresh = hip.Context(0, gpu_lib)
+    host = hip.Context(0, hostsim_lib)
+    for ctx in (fresh, host):
+        ctx.upload_static(util.pmj())
+        ctx.resize(64, 64)
+        ctx.upload_scene_blob(blob)
+    used.clear(), fresh.clear()
+    used.render_batch(1, 8), fresh.render_batch(1, 8)
+    util.render_frames(host, 8)
+    for buf in (hip.BUF_RAW, hip.BUF_VARIANCE):
+        assert np.array_equal(used.readback(buf), fresh.readback(buf)), buf
+    m = util.frame_metrics(fresh.readback(hip.BUF_RAW), host.readback(hip.BUF_RAW))
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
 
 
 @pytest.mark.parametrize("name", SCENES)

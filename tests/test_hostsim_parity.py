@@ -424,6 +424,17 @@ TIE_SCENE = dict(seed=6012, w=64, h=48, spp=4, pixels={(7, 17), (47, 27)})
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_fresnel_weighted_mix_against_live_reference(lib):
+    """a Mix node with an ior: its weight is multiplied by the dielectric Fresnel term for the medium outside the surface, read from
+    the ray's ior stack (ShadeRef.cpp's mix loop) -- in a scene where nothing refracts (scenes.cornell_fresnel_mix)"""
+    from ray_amd import scenes
+
+    r, s = O.render_ref(scenes.cornell_fresnel_mix, 64, 64, 4)
+    ctx = O.hostsim_context(64, 64, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, 4), r.get_raw_pixels_ref())
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_the_tie_pixels_of_the_refined_leaves_are_pinned(lib, monkeypatch):
     """round 3's device fuzzing found ONE scene in 240 where the default product (leaves refined to <= 2 triangles) leaves the
     reference: two pixels.  Pinned here: with the reference's leaves the wide walk equals RendererRef bit for bit; with refined
