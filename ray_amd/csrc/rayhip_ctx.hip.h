@@ -461,7 +461,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
         c->shade_split = atoi(e) & 15;
     }
-    // The persistent ray-refill form of the closest-hit kernel (kernels.hip.h): lanes whose ray is finished fetch the next one
+    // The persistent ray-refill form of the closest-hit kernel (kernels_closest_refill.hip.h): lanes whose ray is finished fetch the next one
     // instead of idling until the longest walk of their wavefront ends.  RAYHIP_REFILL: 2 = for the secondary
     // bounces (incoherent rays, 45 % of the lane slots of the plain kernel belong to finished rays: K2 2.25 -> 2.05 ms per
     // iteration on the Bistro-class scene), the coherent primary rays keep the plain kernel (refill: 0.52 vs 0.35 ms);

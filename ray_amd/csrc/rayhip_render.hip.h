@@ -220,7 +220,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
                 k_trace_shadow<true, 4><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
             } else if (count) {
                 k_trace_shadow<true, 0><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
-            } else if (wide == 4 && c->shadow_refill) { // the flat persistent form (kernels.hip.h)
+            } else if (wide == 4 && c->shadow_refill) { // the flat persistent form (kernels_shadow.hip.h)
                 k_trace_shadow_refill<<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit, vw, c->px.temp, nullptr, spill, layers);
             } else if (wide == 8 && (c->small_scene || c->tune_shadow_waves == 5)) {
                 k_trace_shadow<false, 8, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
