@@ -207,6 +207,10 @@ typedef struct rayhip_sky {
 } rayhip_sky; /* 256 B */
 
 typedef struct rayhip_scene_desc {
+    /* sizeof(rayhip_scene_desc) as the CALLER compiled it (first member, so that it is readable whatever the rest looks like): the struct
+     * has grown (round 4: the sky members) and will again; an upload whose struct_size is not the library's is refused instead of being read
+     * past its end.  RAYHIP_ABI_VERSION / rayhip_abi_version() say which header a library was built from. */
+    uint32_t struct_size;
     const rayhip_bvh2_node *nodes;
     uint32_t nodes_count;
     const rayhip_tri_accel *tris;
@@ -345,6 +349,11 @@ enum {
 /* thread-local message for the last non-zero status returned on this thread */
 RAYHIP_API const char *rayhip_last_error(void);
 
+/* RAYHIP_ABI_VERSION of the header the library was built from.  Bumped whenever a struct or a signature of this file changes shape
+ * (5: rayhip_scene_desc::struct_size, round 5); a host compares it with its own RAYHIP_ABI_VERSION before the first upload. */
+#define RAYHIP_ABI_VERSION 5
+RAYHIP_API int rayhip_abi_version(void);
+
 /* Number of usable gfx950 devices.  The reference GPU factories throw when no device is present and
  * the caller falls back (Ray.cpp:58-63); Hip::CreateRenderer does the same on a 0 here. */
 RAYHIP_API int rayhip_device_count(void);
@@ -437,13 +446,15 @@ RAYHIP_API int rayhip_set_tonemap_lut(rayhip_ctx *ctx, int view_transform, const
  * non-local-means filter (7x7 window, 3x3 patches) of the reversibly tone-mapped running mean guided by the variance
  * and by the base-colour / depth-normal images, then RAW <- filtered colour, FINAL <- Tonemap(RAW) on `rect`, and the
  * adaptive-sampling flags of the rect's pixels.  `iteration` = RegionContext::iteration of the last RenderScene.
- * SURVEY.md section 8f, N2; the UNet denoiser (DenoiseImage(pass, region)) is not implemented. */
+ * SURVEY.md section 8f, N2; the UNet denoiser (DenoiseImage(pass, region)) is rayhip_unet_init / rayhip_denoise_unet below. */
 RAYHIP_API int rayhip_denoise_nlm(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int iteration);
 
 /* Multi-GPU tile sharding (new): this context renders only the pixels of the tile x tile
- * squares (row-major walk over the frame) whose ordinal % shard_count == shard_index; all other pixels of its
- * buffers stay zero, so that summing the RAW buffers of all ranks (one RCCL reduce) yields the full frame,
- * bit-identical to a single-GPU render.  Default is (64, 1, 0) = everything. */
+ * squares (row-major walk over the frame) whose ordinal % shard_count == shard_index; the other pixels of its
+ * buffers are never written by it.  Every pixel has exactly one owner, so ONE gather of the owned tiles
+ * (rayhip_comm_reduce_framebuffers, or rayhip_export_owned / rayhip_import_owned with the caller's transport)
+ * assembles the full frame on the root, bit-identical to a single-GPU render (a copy, not a sum: rounds 1-2 reduced
+ * zero-padded frames).  Default is (64, 1, 0) = everything. */
 RAYHIP_API int rayhip_set_shard(rayhip_ctx *ctx, int tile, int shard_count, int shard_index);
 
 /* blocking device->host copy, get_pixels_ref & co. (RendererVK.cpp:1698-1757) */

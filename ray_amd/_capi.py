@@ -176,6 +176,7 @@ class CameraDesc(C.Structure):  # ray_camera_desc
 
 class EnvDesc(C.Structure):  # ray_env_desc
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("env_col", C.c_float * 3),
         ("env_map", ray_handle),
         ("back_col", C.c_float * 3),

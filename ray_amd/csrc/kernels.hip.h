@@ -645,6 +645,19 @@ __global__ void __launch_bounds__(256) k_fill_tri_verts(const rayhip_vertex *__r
     }
 }
 
+// Fill of every queue of a pass (sum over the stripe counters), one wavefront per queue: what the next pass sizes its launches from
+// (rayhip_render.hip.h: queue census).  `out` is host memory the device writes directly.
+__global__ void __launch_bounds__(WAVE) k_queue_totals(const uint32_t *__restrict__ counters, uint32_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t n = lane < QUEUE_MAX_STRIPES ? counters[size_t(blockIdx.x) * QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE + lane * QUEUE_COUNTER_STRIDE] : 0u;
+    for (int m = 32; m >= 1; m >>= 1) {
+        n += uint32_t(__shfl_xor(int(n), m));
+    }
+    if (lane == 0) {
+        out[blockIdx.x] = n;
+    }
+}
+
 __global__ void k_fill_u16(uint16_t *p, const uint16_t v, const size_t n) {
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
         p[i] = v;

@@ -48,10 +48,15 @@
 #define RT_REFILL_VOTE_NUM 1
 #define RT_REFILL_VOTE_DEN 1
 #endif
+// chunks per fetch of the dynamic hand-out: one (64 rays) -- a fetch per 75 us and wavefront, ~35 M atomics per second chip-wide
+#ifndef RT_REFILL_RUN
+#define RT_REFILL_RUN 1
+#endif
 template <int WIDE, int MIN_WAIT = RT_REFILL_MIN>
 __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_refill(const SceneView sc, const TraceParams tp, const RaySoA rays,
                                                                const HitSoA hits, const RayQueue queue, const int init_hits,
-                                                               uint32_t *__restrict__ stack_spill, const Layering layers) {
+                                                               uint32_t *__restrict__ stack_spill, const Layering layers,
+                                                               uint32_t *__restrict__ work /* dynamic chunk hand-out (wavefront.hip.h), may be null */) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t lane = threadIdx.x;
 #ifdef RT_PROFILE_TRACE
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(WAVE, RT_REFILL_MIN_WAVES) k_trace_closest_ref
     float t_val = 0.0f;
     // wavefront state (uniform): the chunk being handed out, the next chunk index of this wavefront
     uint32_t pool_slot = 0, pool_left = 0;
-    ChunkWalk walk(queue.live_chunks());
+    ChunkWalk walk(queue.live_chunks(), work, RT_REFILL_RUN);
 
     auto begin_round = [&]() { // IntersectScene loop head + walk prologue at TLAS level
         t_val = h.t;

@@ -62,11 +62,17 @@ __global__ void __launch_bounds__(WAVE, MINW) k_trace_shadow(const SceneView sc,
 #ifndef RT_SHADOW_REFILL_MIN_WAVES
 #define RT_SHADOW_REFILL_MIN_WAVES 6
 #endif
+// chunks per fetch of the dynamic hand-out (wavefront.hip.h: ChunkWalk): a shadow launch takes a chunk every ~11 ns chip-wide -- the rate one
+// counter can hand out runs at -- so four
+#ifndef RT_SHADOW_RUN
+#define RT_SHADOW_RUN 4
+#endif
 template <int MIN_WAIT = RT_SHADOW_REFILL_MIN>
 __global__ void __launch_bounds__(WAVE, RT_SHADOW_REFILL_MIN_WAVES) k_trace_shadow_refill(const SceneView sc, const TraceParams tp, const ShadowSoA shadow,
                                                                                      const RayQueue queue, const float limit, const int img_w,
                                                                                      float4 *__restrict__ temp_buf, float4 *__restrict__ out_rc,
-                                                                                     uint32_t *__restrict__ stack_spill, const Layering layers) {
+                                                                                     uint32_t *__restrict__ stack_spill, const Layering layers,
+                                                                                     uint32_t *__restrict__ work /* dynamic chunk hand-out, may be null */) {
     __shared__ uint32_t lds_stack[LDS_STACK_DEPTH * WAVE];
     const uint32_t lane = threadIdx.x;
     LdsStack st;
@@ -83,7 +89,7 @@ __global__ void __launch_bounds__(WAVE, RT_SHADOW_REFILL_MIN_WAVES) k_trace_shad
     float dist = 0.0f;
     Hit h = make_hit();
     uint32_t pool_slot = 0, pool_left = 0; // (uniform) the chunk being handed out
-    ChunkWalk walk(queue.live_chunks());
+    ChunkWalk walk(queue.live_chunks(), work, RT_SHADOW_RUN);
 
     auto begin_segment = [&]() { // loop head of IntersectScene + prologue of the top-level walk
         h = make_hit();

@@ -81,6 +81,7 @@ struct rayhip_ctx {
     bool small_scene = false; // BLAS nodes + triangles fit one XCD's L2: traversal kernels with the smaller register footprint
     int refill_waves = 0; // largest grid of the persistent closest-hit kernel (blocks); 0 = kernel switched off
     int refill_resident = 0; // ... and the number of its blocks the device holds at once
+    int refill_resident4 = 0; // ... of its 4-wide form (the grid of a launch whose chunks are handed out dynamically)
     int sort_key_mode = 0; // RAYHIP_SORT_KEY (tuning, rt_sort.h)
     // RAYHIP_PRIMARY_WAVES / RAYHIP_SHADOW_WAVES: register footprint of the plain K2 (primary rays) / of K3.  K3 runs at 5 waves per
     // SIMD (96 VGPRs, 32 spilled registers per ray instead of 51 at 6 waves: same time, a third less scratch traffic)
@@ -151,9 +152,75 @@ struct rayhip_ctx {
     HitSoA hits = {};
     ShadowSoA shadow = {};
     DeferredSoA deferred = {};
-    DevBuf counters;      // uint32 [MAX_BOUNCE_SLOTS][5: rays, shadow rays, deferred emitters, shade points, points with a light][QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE]
+    DevBuf counters;      // uint32 [MAX_BOUNCE_SLOTS][QUEUES_PER_BOUNCE = 6: rays, shadow rays, deferred emitters, shade points, points with a light, sky paths][QUEUE_MAX_STRIPES * QUEUE_COUNTER_STRIDE]
     DevBuf trav_counters; // u64 [2][TRAV_COUNTER_WORDS]
+    // Dynamic chunk hand-out (wavefront.hip.h: ChunkWalk, round 5) of the persistent kernels with lane refill (K2's secondary bounces, K3, the
+    // light pick): one counter (a 256-byte line) per such launch of a pass, WORK_PER_BOUNCE per bounce, cleared with the pass's queue counters
+    // and dealt out in launch order.  OPT-IN (RAYHIP_DYNAMIC=1): measured neutral -- K2's secondary bounces 87.3 against 87.4 ms per frame, a rank of
+    // 8 12.5 against 12.6 ms (profiles/r05/experiments/dynamic_chunks.txt): what a launch loses at its end is the latency of its longest ray,
+    // not the balance between blocks.  Bit-identical, kept for the next kernel that is short of balance.
+    static constexpr uint32_t WORK_PER_BOUNCE = 4;
+    DevBuf work_counters;
+    uint32_t work_cursor = 0, work_cleared = 0;
+    bool dynamic_chunks = false;
+    int dyn_mult = 1;        // blocks per resident wave slot of a dynamic launch (RAYHIP_DYN_MULT)
+    int shadow_resident = 0; // blocks of k_trace_shadow_refill the device holds at once
+    uint32_t *next_work() {
+        if (!dynamic_chunks || work_cursor >= work_cleared) {
+            return nullptr; // (a launch without a counter walks statically)
+        }
+        return work_counters.as<uint32_t>() + size_t(work_cursor++) * WORK_COUNTER_STRIDE;
+    }
+    int clear_work(int bounces, hipStream_t s) {
+        work_cursor = 0, work_cleared = 0;
+        if (!dynamic_chunks) {
+            return 0;
+        }
+        const uint32_t n = uint32_t(bounces) * WORK_PER_BOUNCE;
+        if (hipMemsetAsync(work_counters.p, 0, size_t(n) * WORK_COUNTER_STRIDE * sizeof(uint32_t), s) != hipSuccess) {
+            return 1;
+        }
+        work_cleared = n;
+        return 0;
+    }
+    // Queue census (round 5): how full every queue of the last pass was, as a fraction of the pass's ray slots -- what the next pass sizes its
+    // launches from (rays of bounce b, shadow rays, shade points, lit points ... of the same scene and camera vary by a few per cent from pass
+    // to pass; a persistent kernel is correct at ANY grid size, so a stale or missing census only costs time).  The reference sizes every
+    // dispatch from device counters as well (internal/shaders/prepare_indir_args.comp.glsl:17-77, recorded up front at
+    // internal/RendererVK.cpp:641-712); HIP has no indirect dispatch, hence one pass of delay.  k_queue_totals writes the sums straight into
+    // page-locked host memory at the end of a pass; the host looks at them when the next pass starts, if the event says they are there.
+    // RAYHIP_CENSUS=0: every launch at the pass's full grid, as before.
+    uint32_t *census_host = nullptr, *census_dev = nullptr; // [MAX_BOUNCE_SLOTS * QUEUES_PER_BOUNCE], one allocation seen from both sides
+    hipEvent_t census_event = nullptr;
+    bool census_on = true, census_pending = false, census_valid = false;
+    int census_bounces = 0;    // bounces the pending / valid census covers
+    size_t census_slots = 0;   // ray slots of the pass the pending census belongs to
+    std::vector<float> census; // [bounce][queue]: fill / slots of the last census read
+    int chunks_per_block = 8;  // live chunks a block of a streaming kernel should find (RAYHIP_CHUNKS_PER_BLOCK)
+    // live chunks queue `q` (0 rays, 1 shadow rays, 2 deferred emitters, 3 shade points, 4 lit points, 5 sky paths) of bounce `b` is expected to
+    // hold in a pass of `slots` ray slots; 0 = unknown
+    uint32_t expect_chunks(int b, int q, size_t slots, uint32_t stripes) const {
+        if (!census_valid || b >= census_bounces) {
+            return 0u;
+        }
+        const double rays = double(census[size_t(b) * QUEUES_PER_BOUNCE + size_t(q)]) * double(slots) * 1.25;
+        return uint32_t(std::min<double>(double(slots / WAVE + stripes), rays / WAVE + double(stripes))) + 1u;
+    }
     DevBuf stack_spill;   // per-wave overflow slabs of the traversal stack
+    // Round 5: the shadow rays of bounce b (K3: reads the shadow-ray planes, adds to the per-iteration pixel buffer) and the closest-hit launch of
+    // bounce b + 1 (K2: reads the ray planes, writes the hit planes) touch disjoint state, so K3 goes to a second, low-priority stream and fills
+    // the wave slots K2 leaves idle while its last, longest rays finish (a launch ends on the dependent fetch chain of ONE ray: 0.3-0.4 ms at any
+    // launch size -- profiles/r05/timeline_rank0_of_8.txt).  The shade stage of bounce b + 1 waits for both (the order of the pixel additions is
+    // the reference's: ShadeSecondary += after the shadow += of the bounce before).  RAYHIP_OVERLAP_SHADOW=0: one stream, as before.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
+    DevBuf stack_spill2; // K3's own overflow slabs while it runs next to K2
+    bool overlap_shadow = true;
+    struct Interval { // a timed launch on the second stream (resolve_timing)
+        size_t ev0, ev1;
+        int stage, trav;
+    };
+    std::vector<Interval> pending2;
     DevBuf sort_keys[2], sort_idx[2], sort_temp;
     SortGrid sort_grid = {};
 
@@ -353,6 +420,20 @@ struct StageTimer {
         ++c->events_used;
         return 0;
     }
+    // a plain timestamp on stream `s` (second-stream launches: rayhip_ctx::pending2); returns the event's index or -1
+    long stamp(hipStream_t s) {
+        if (c->events_used == c->events.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) {
+                return -1;
+            }
+            c->events.push_back(e);
+        }
+        if (hipEventRecord(c->events[c->events_used], s) != hipSuccess) {
+            return -1;
+        }
+        return long(c->events_used++);
+    }
 };
 
 int resolve_timing(rayhip_ctx *c) {
@@ -360,6 +441,18 @@ int resolve_timing(rayhip_ctx *c) {
         return 0;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (const rayhip_ctx::Interval &iv : c->pending2) { // launches that ran on the second stream, next to the main one: their own time
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->events[iv.ev0], c->events[iv.ev1]));
+        if (iv.stage >= 0) {
+            c->stage_us[iv.stage] += double(ms) * 1000.0;
+        }
+        if (iv.trav >= 0) {
+            c->trav_ms[iv.trav] += double(ms);
+            c->trav_launches[iv.trav] += 1;
+        }
+    }
+    c->pending2.clear();
     for (size_t k = 0; k + 1 < c->pending.size(); ++k) {
         const rayhip_ctx::Mark &a = c->pending[k], &b = c->pending[k + 1];
         if (b.first) {
@@ -402,6 +495,8 @@ extern "C" {
 
 const char *rayhip_last_error(void) { return g_err.c_str(); }
 
+int rayhip_abi_version(void) { return RAYHIP_ABI_VERSION; }
+
 int rayhip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -426,6 +521,16 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         return fail("failed to initialise HIP device %d", device);
     }
     g_touch_stream = c->stream;
+    if (const char *e = getenv("RAYHIP_OVERLAP_SHADOW")) {
+        c->overlap_shadow = atoi(e) != 0;
+    }
+    if (c->overlap_shadow) {
+        int least = 0, greatest = 0; // (numerically: greatest priority <= least priority)
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least) != hipSuccess ||
+            hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming) != hipSuccess) {
+            c->overlap_shadow = false;
+        }
+    }
     // persistent grid of the wave-per-block kernels: as many blocks as are resident (LDS stack + VGPR budget)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_closest<false, 8>, WAVE, 0) != hipSuccess || per_cu <= 0) {
@@ -483,6 +588,13 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
                 refill_mult = std::max(1, std::min(64, atoi(e)));
             }
             c->refill_resident = c->props.multiProcessorCount * per_cu_refill;
+            {
+                int per_cu4 = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, k_trace_closest_refill<4>, WAVE, 0) != hipSuccess || per_cu4 <= 0) {
+                    per_cu4 = per_cu_refill;
+                }
+                c->refill_resident4 = c->props.multiProcessorCount * per_cu4;
+            }
             c->refill_waves = std::min(c->grid_waves, c->refill_resident * refill_mult);
             c->refill_secondary_only = mode == 2 || mode == 3 || mode == 4;
             c->refill_primary_whole = mode == 3 || mode == 4;
@@ -498,13 +610,49 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         }
     }
     // (sized for the shallowest LDS stack any kernel keeps: the pooled closest-hit kernel trades stack entries for its pool)
-    if (c->stack_spill.alloc(size_t(c->grid_waves) * std::max(STACK_SPILL_DEPTH * WAVE, POOL_SLAB_WORDS) * sizeof(uint32_t))) {
+    if (c->stack_spill.alloc(size_t(c->grid_waves) * std::max(STACK_SPILL_DEPTH * WAVE, POOL_SLAB_WORDS) * sizeof(uint32_t)) ||
+        (c->overlap_shadow && c->stack_spill2.alloc(size_t(c->grid_waves) * size_t(STACK_SPILL_DEPTH * WAVE) * sizeof(uint32_t)))) {
         delete c;
         return 1;
     }
-    if (c->counters.alloc(sizeof(uint32_t) * rayhip_ctx::QUEUES_PER_BOUNCE * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS)) {
+    if (c->counters.alloc(sizeof(uint32_t) * rayhip_ctx::QUEUES_PER_BOUNCE * MAX_BOUNCE_SLOTS * rayhip_ctx::QUEUE_WORDS) || c->trav_counters.alloc(sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS) ||
+        c->work_counters.alloc(sizeof(uint32_t) * size_t(MAX_BOUNCE_SLOTS) * rayhip_ctx::WORK_PER_BOUNCE * WORK_COUNTER_STRIDE)) {
         delete c;
         return 1;
+    }
+    if (const char *e = getenv("RAYHIP_DYNAMIC")) {
+        c->dynamic_chunks = atoi(e) != 0;
+    }
+    if (const char *e = getenv("RAYHIP_DYN_MULT")) {
+        c->dyn_mult = std::max(1, std::min(16, atoi(e)));
+    }
+    if (const char *e = getenv("RAYHIP_CENSUS")) {
+        c->census_on = atoi(e) != 0;
+    }
+    if (const char *e = getenv("RAYHIP_CHUNKS_PER_BLOCK")) {
+        c->chunks_per_block = std::max(1, std::min(1024, atoi(e)));
+    }
+    if (c->census_on) {
+        void *hp = nullptr, *dp = nullptr;
+        const size_t bytes = sizeof(uint32_t) * size_t(MAX_BOUNCE_SLOTS) * rayhip_ctx::QUEUES_PER_BOUNCE;
+        if (hipHostMalloc(&hp, bytes, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess ||
+            hipEventCreateWithFlags(&c->census_event, hipEventDisableTiming) != hipSuccess) {
+            if (hp) {
+                (void)hipHostFree(hp);
+            }
+            c->census_on = false; // (a tuning aid: without it the launches keep their full grids)
+        } else {
+            c->census_host = static_cast<uint32_t *>(hp), c->census_dev = static_cast<uint32_t *>(dp);
+            memset(hp, 0, bytes);
+            c->census.assign(size_t(MAX_BOUNCE_SLOTS) * rayhip_ctx::QUEUES_PER_BOUNCE, 0.0f);
+        }
+    }
+    {
+        int per_cu_shadow = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_shadow, k_trace_shadow_refill<>, WAVE, 0) != hipSuccess || per_cu_shadow <= 0) {
+            per_cu_shadow = per_cu;
+        }
+        c->shadow_resident = c->props.multiProcessorCount * per_cu_shadow;
     }
     (void)hipMemsetAsync(c->trav_counters.p, 0, sizeof(unsigned long long) * 2 * TRAV_COUNTER_WORDS, c->stream);
     // the stage stopwatch's events exist up front: creating them lazily put ~30 ms of runtime initialisation into the first
@@ -526,8 +674,24 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
     }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamDestroy(c->stream2);
+    }
+    for (hipEvent_t e : {c->fork_event, c->join_event}) {
+        if (e) {
+            (void)hipEventDestroy(e);
+        }
+    }
+    c->stack_spill2.release();
     for (hipEvent_t e : c->events) {
         (void)hipEventDestroy(e);
+    }
+    if (c->census_event) {
+        (void)hipEventDestroy(c->census_event);
+    }
+    if (c->census_host) {
+        (void)hipHostFree(c->census_host);
     }
     DevBuf *all[] = {&c->pmj, &c->filter_table, &c->nodes, &c->tris, &c->tri_indices, &c->tri_materials, &c->materials,
                      &c->vertices, &c->vtx_indices, &c->mesh_instances, &c->lights, &c->li_indices, &c->light_cwnodes, &c->light_children, &c->light_tri_geom, &c->tri_verts, &c->tri_bitangents, &c->nodes4, &c->nodes8, &c->blas_root4, &c->env_qtree,
@@ -535,7 +699,7 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
                      &c->px_dn, &c->px_req, &c->px_aux_base, &c->px_aux_dn, &c->px_variance, &c->nlm_tm, &c->nlm_var_h, &c->nlm_var,
                      &c->tonemap_lut, &c->hit_planes[0], &c->hit_planes[1], &c->shadow_planes[0], &c->shadow_planes[1],
                      &c->shadow_planes[2], &c->deferred_planes[0], &c->deferred_planes[1], &c->counters, &c->trav_counters, &c->stack_spill,
-                     &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->sort_temp, &c->shard_stage};
+                     &c->sort_keys[0], &c->sort_keys[1], &c->sort_idx[0], &c->sort_idx[1], &c->sort_temp, &c->shard_stage, &c->work_counters};
     for (DevBuf *b : all) {
         b->release();
     }

@@ -103,9 +103,9 @@ int rayhip_k_intersect_closest(rayhip_ctx *c, const rayhip_camera *cam, rayhip_r
         } else if (c->wide == 4 && c->refill_pool && c->pool_scene) { // what rayhip_render launches (the pooled form also takes preset hits)
             k_trace_closest_pool<><<<std::max(1, std::min(g, c->pool_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
         } else if (c->wide == 8 && c->refill_waves) {
-            k_trace_closest_refill<8><<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
+            k_trace_closest_refill<8><<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h), nullptr);
         } else if (c->wide == 4 && c->refill_waves) {
-            k_trace_closest_refill<4><<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
+            k_trace_closest_refill<4><<<std::max(1, std::min(g, c->refill_waves)), WAVE, 0, s>>>(c->sc, tp, c->rays[0], c->hits, q, 0, c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h), nullptr);
         } else if (c->wide == 8) {
             k_trace_closest<false, 8><<<gg, WAVE, 0, s>>>(KK_ARGS);
         } else if (c->wide == 4) {
@@ -176,7 +176,7 @@ int rayhip_k_intersect_shadow(rayhip_ctx *c, const rayhip_camera *cam, const ray
     // results land in the (otherwise idle) hit plane
     if (getenv("RAYHIP_HOOK_SHADOW_REFILL") && c->wide == 4) { // the product's flat persistent form over the 4-wide tree (no counters)
         k_trace_shadow_refill<<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
-                                                       c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h));
+                                                       c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), single_layer(c->w, c->h), nullptr);
     } else {
         k_trace_shadow<true, 0><<<g ? g : 1, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(0, size_t(count), 1), FLT_MAX, c->w, c->px.temp,
                                                         c->hit_planes[0].as<float4>(), c->stack_spill.as<uint32_t>(), tc, single_layer(c->w, c->h));

@@ -30,7 +30,7 @@ static int ensure_pass(rayhip_ctx *c, const int rect[4], int n) {
 // other ray buffer, shadow rays into shadow queue `bounce`, radiance into the per-iteration pixel buffer.  One place for
 // rayhip_render and the kernel-level hook rayhip_k_shade.
 static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration, int bounce, int cur, size_t nslots, uint32_t stripes,
-                         int gtrace, int vw, float mix_factor, const Layering &layers, bool plain_ior = false) {
+                         int gtrace, int vw, float mix_factor, const Layering &layers, bool plain_ior = false, bool sized = false) {
     ShadeLaunch a;
     a.sc = c->sc;
     a.sp = make_shade_params(cam, iteration, bounce);
@@ -43,6 +43,13 @@ static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration,
     a.out_sky = c->sky_queue(bounce, nslots, stripes), a.sky_index = c->sky_index.as<uint32_t>();
     a.px = c->px, a.layers = layers, a.vw = vw, a.mix_factor = mix_factor;
     a.bounce = bounce, a.grid = gtrace, a.split = c->shade_split, a.stream = c->stream;
+    if (sized) { // a pass (not a kernel-level hook): grids from the queue census, the persistent pick with a work counter
+        a.expect[EXPECT_RAYS] = bounce == 0 ? uint32_t(nslots / WAVE + stripes) : c->expect_chunks(bounce, 0, nslots, stripes);
+        a.expect[EXPECT_POINTS] = c->expect_chunks(bounce, 3, nslots, stripes), a.expect[EXPECT_LIT] = c->expect_chunks(bounce, 4, nslots, stripes);
+        a.expect[EXPECT_DEFERRED] = c->expect_chunks(bounce, 2, nslots, stripes), a.expect[EXPECT_SKY] = c->expect_chunks(bounce, 5, nslots, stripes);
+        a.chunks_per_block = c->chunks_per_block;
+        a.work = c->next_work(), a.chunks = uint32_t((nslots + WAVE - 1) / WAVE + stripes), a.dyn_mult = c->dyn_mult;
+    }
     shade::launch(a);
 }
 
@@ -99,6 +106,29 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
 
     // striped queues unless a stage needs one dense ray array (the sort)
     const uint32_t stripes = sort_rays ? 1u : QUEUE_MAX_STRIPES;
+    // The queue census of the previous pass, if it has arrived (rayhip_ctx: census): fractions of that pass's ray slots
+    if (c->census_on && c->census_pending && hipEventQuery(c->census_event) == hipSuccess) {
+        const double inv = c->census_slots ? 1.0 / double(c->census_slots) : 0.0;
+        for (int k = 0; k < c->census_bounces * rayhip_ctx::QUEUES_PER_BOUNCE; ++k) {
+            c->census[size_t(k)] = float(double(c->census_host[k]) * inv);
+        }
+        c->census_valid = true, c->census_pending = false;
+    }
+    int bounce_now = 0; // (the launchers below size their grids for the bounce being enqueued)
+    // grid of a persistent kernel whose chunks are handed out dynamically: what the device holds at once (x RAYHIP_DYN_MULT), never more blocks
+    // than chunks are expected (every block takes chunk blockIdx.x first), never more than the spill slabs allow
+    auto dyn_grid = [&](int resident, uint32_t expect) {
+        const size_t chunks = expect ? size_t(expect) : (nslots + WAVE - 1) / WAVE + stripes;
+        return int(std::max<size_t>(1, std::min<size_t>({size_t(gw), size_t(std::max(resident, 1)) * size_t(c->dyn_mult), chunks})));
+    };
+    // ... and of one that walks statically: chunks_per_block live chunks per block, at least a block per wave slot while there are chunks
+    auto static_grid = [&](int full, int resident, uint32_t expect) {
+        if (!expect) {
+            return full;
+        }
+        const uint32_t want = std::max(std::min(expect, uint32_t(std::max(resident, 1))), expect / uint32_t(c->chunks_per_block));
+        return int(std::min<uint32_t>(uint32_t(full), std::max(want, 1u)));
+    };
     // K2 launcher (instrumented variant on request)
     auto launch_closest = [&](const RaySoA &r, const RayQueue &q, int init_hits) {
         const int wide = c->wide;
@@ -111,10 +141,11 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             k_trace_closest<true, 0><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
         } else if (wide && c->refill_waves && c->refill_primary_whole && !init_hits) {
             // primary rays (coherent): the flat kernel, chunks taken whole (RAYHIP_REFILL=3)
+            // (static walk: this launch takes a chunk every ~8 ns chip-wide, more than one counter can hand out -- wavefront.hip.h)
             if (wide == 8) {
-                k_trace_closest_refill<8, WAVE><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
+                k_trace_closest_refill<8, WAVE><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers, nullptr);
             } else {
-                k_trace_closest_refill<4, WAVE><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
+                k_trace_closest_refill<4, WAVE><<<gtrace, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers, nullptr);
             }
         } else if (wide == 4 && c->refill_pool && c->pool_scene && init_hits) {
             // secondary bounces, pooled kernel (grid: as for the refill kernel below)
@@ -125,10 +156,16 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             // block gets fewer than ~8 chunks of 64 rays -- below that the kernel degenerates into the plain one with extra
             // set-up per block (a rank of 8 at 20 spp: 5.2 M rays per pass; 16 blocks per slot 6.6 ms, 4: 5.97, plain 5.98)
             const int want = int(std::min<size_t>(size_t(c->refill_waves), std::max<size_t>(size_t(c->refill_resident), nslots / WAVE / 8)));
+            // round 5: chunks handed out dynamically -- as many blocks as the device holds, every wavefront refills its lanes until the
+            // queue is empty and drains once (wavefront.hip.h: ChunkWalk)
+            uint32_t *work = c->next_work();
+            const uint32_t expect = c->expect_chunks(bounce_now, 0, nslots, stripes);
+            const int resident = wide == 4 ? c->refill_resident4 : c->refill_resident;
+            const int grid = work ? dyn_grid(resident, expect) : static_grid(std::min(gtrace, want), resident, expect);
             if (wide == 8) {
-                k_trace_closest_refill<8><<<std::min(gtrace, want), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
+                k_trace_closest_refill<8><<<grid, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers, work);
             } else {
-                k_trace_closest_refill<4><<<std::min(gtrace, want), WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers);
+                k_trace_closest_refill<4><<<grid, WAVE, 0, s>>>(c->sc, tp_, r, c->hits, q, init_hits, spill, layers, work);
             }
         } else if (wide == 8 && (c->small_scene || c->tune_primary_waves == 5)) {
             k_trace_closest<false, 8, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(K2_ARGS);
@@ -146,7 +183,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
 
     StageTimer tm(c, stats != nullptr || (flags & RAYHIP_FLAG_TIME_STAGES) != 0);
 
-    if (c->clear_queues(max_depth + 2, s)) {
+    if (c->clear_queues(max_depth + 2, s) || c->clear_work(max_depth + 2, s)) {
         return fail("queue counter clear failed");
     }
 
@@ -176,7 +213,9 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         launch_closest(c->rays[0], c->ray_queue(0, nslots, stripes), 0);
     }
     int cur = 0;
+    bool side_pending = false; // a K3 launch on the second stream that the main stream has not waited for yet
     for (int bounce = 0; bounce <= max_depth; ++bounce) {
+        bounce_now = bounce;
         if (bounce > 0) {
             if (sort_rays) {
                 // K6-K8 (RendererVK.cpp:641-652): key -> radix sort of (key, index) -> gather into the idle ray buffer
@@ -200,16 +239,31 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
                 k_intersect_area_lights<<<gtrace, WAVE, 0, s>>>(c->sc, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes));
             }
         }
+        if (side_pending) { // the shadow rays of the bounce before have to be through: pixel additions keep the reference's order
+            HIP_TRY(hipStreamWaitEvent(s, c->join_event, 0));
+            side_pending = false;
+        }
         if (tm.mark(bounce == 0 ? ST_PSHADE : ST_SSHADE, -1)) {
             return 1;
         }
-        launch_shade(c, *cam, iteration, bounce, cur, nslots, stripes, gtrace, vw, mix_factor, layers, c->plain_ior);
-        if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
+        launch_shade(c, *cam, iteration, bounce, cur, nslots, stripes, gtrace, vw, mix_factor, layers, c->plain_ior, true);
+        // K3 of this bounce: on the second stream, next to the closest-hit launch of the next bounce (rayhip_ctx: stream2), when it is the flat
+        // persistent form and nothing is being counted
+        const bool side = c->overlap_shadow && c->wide == 4 && c->shadow_refill && !count && !count_wide;
+        hipStream_t ss = side ? c->stream2 : s;
+        long side_t0 = -1;
+        if (side) {
+            HIP_TRY(hipEventRecord(c->fork_event, s));
+            HIP_TRY(hipStreamWaitEvent(ss, c->fork_event, 0));
+            if (tm.on) {
+                side_t0 = tm.stamp(ss);
+            }
+        } else if (tm.mark(bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1)) {
             return 1;
         }
         const float limit = shadow_clamp_limit(*cam, bounce);
         if (c->sc.blocker_lights_count != 0) {
-            k_shadow_blockers<<<gtrace, WAVE, 0, s>>>(c->sc, c->shadow, c->shadow_queue(bounce, nslots, stripes));
+            k_shadow_blockers<<<gtrace, WAVE, 0, ss>>>(c->sc, c->shadow, c->shadow_queue(bounce, nslots, stripes));
         }
         {
             const int wide = c->wide;
@@ -221,7 +275,10 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             } else if (count) {
                 k_trace_shadow<true, 0><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
             } else if (wide == 4 && c->shadow_refill) { // the flat persistent form (kernels_shadow.hip.h)
-                k_trace_shadow_refill<<<gtrace, WAVE, 0, s>>>(c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit, vw, c->px.temp, nullptr, spill, layers);
+                uint32_t *work = c->next_work();
+                const uint32_t expect = c->expect_chunks(bounce, 1, nslots, stripes);
+                k_trace_shadow_refill<<<work ? dyn_grid(c->shadow_resident, expect) : static_grid(gtrace, c->shadow_resident, expect), WAVE, 0, ss>>>(
+                    c->sc, tp, c->shadow, c->shadow_queue(bounce, nslots, stripes), limit, vw, c->px.temp, nullptr, side ? c->stack_spill2.as<uint32_t>() : spill, layers, work);
             } else if (wide == 8 && (c->small_scene || c->tune_shadow_waves == 5)) {
                 k_trace_shadow<false, 8, RT_TRACE_SMALL_WAVES><<<gtrace, WAVE, 0, s>>>(K3_ARGS);
             } else if (wide == 8) {
@@ -235,7 +292,21 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             }
 #undef K3_ARGS
         }
+        if (side) {
+            if (tm.on) {
+                const long side_t1 = tm.stamp(ss);
+                if (side_t0 >= 0 && side_t1 >= 0) {
+                    c->pending2.push_back({size_t(side_t0), size_t(side_t1), bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1});
+                }
+            }
+            HIP_TRY(hipEventRecord(c->join_event, ss));
+            side_pending = true;
+        }
         cur ^= 1;
+    }
+    if (side_pending) {
+        HIP_TRY(hipStreamWaitEvent(s, c->join_event, 0));
+        side_pending = false;
     }
     if (tm.mark(-1, -1)) {
         return 1;
@@ -250,6 +321,12 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             per_layer.l[k] = AccumLayer{al.iteration, al.mix_factor, al.half_mix_factor, al.is_class_a, al.variance_threshold};
         }
         k_accumulate<<<grid_for(c, npix, 256), 256, 0, s>>>(ap, c->px, layers, per_layer, base, n);
+    }
+    if (c->census_on && !count && !count_wide) { // what the queues of this pass held: the next pass sizes its launches from it
+        const int queues = (max_depth + 1) * rayhip_ctx::QUEUES_PER_BOUNCE;
+        k_queue_totals<<<queues, WAVE, 0, s>>>(c->counters.as<uint32_t>(), c->census_dev);
+        HIP_TRY(hipEventRecord(c->census_event, s));
+        c->census_pending = true, c->census_bounces = max_depth + 1, c->census_slots = nslots;
     }
     HIP_TRY(hipGetLastError());
     if (tm.mark(-1, -1)) {

@@ -154,6 +154,10 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
     if (use_device(c)) {
         return 1;
     }
+    if (d_in->struct_size != sizeof(rayhip_scene_desc)) { // (before anything else of the struct is looked at)
+        return fail("rayhip_scene_desc::struct_size is %u, this library's struct has %zu bytes (ABI version %d): the caller was built against another rayhip.h",
+                    d_in->struct_size, sizeof(rayhip_scene_desc), RAYHIP_ABI_VERSION);
+    }
     const auto upload_t0 = std::chrono::steady_clock::now();
     (void)upload_t0;
     UPLOAD_TRACE("begin")
@@ -426,6 +430,7 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         refresh_scene_view(c, d, tlas_root, root_box, count_top_level_instances(d->nodes, d->nodes_count, d->tlas_root));
     }
     c->have_scene = true;
+    c->census_valid = false; // (another scene: its queues fill differently; the next pass runs at full grids and takes a new census)
     UPLOAD_TRACE("done")
     return 0;
 }
@@ -450,6 +455,10 @@ int rayhip_closest_hit_form(rayhip_ctx *c) {
 int rayhip_scene_update_instances(rayhip_ctx *c, const rayhip_scene_desc *d) {
     if (use_device(c)) {
         return 1;
+    }
+    if (d->struct_size != sizeof(rayhip_scene_desc)) {
+        return fail("rayhip_scene_desc::struct_size is %u, this library's struct has %zu bytes (ABI version %d): the caller was built against another rayhip.h",
+                    d->struct_size, sizeof(rayhip_scene_desc), RAYHIP_ABI_VERSION);
     }
     if (!c->have_scene) {
         (void)fail("rayhip_scene_update_instances before rayhip_scene_upload");

@@ -142,6 +142,7 @@ inline bool deserialize(const void *blob, size_t size, rayhip_scene_desc &d, ray
         return false;
     }
     d = {};
+    d.struct_size = uint32_t(sizeof(rayhip_scene_desc));
     bool have_scalars = false, have_cam = false;
     for (uint32_t i = 0; i < h.section_count; ++i) {
         Section s;

@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #ifdef RT_PROFILE_SHADE
 // tuning build (tools/variants.py "+shade:-DRT_PROFILE_SHADE"): which branches of the scatter stage run, and with how many lanes
@@ -217,12 +220,17 @@ __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick(const Sc
 #ifndef RT_PICK_REFILL_MIN
 #define RT_PICK_REFILL_MIN 16
 #endif
+// chunks per fetch of the dynamic hand-out (wavefront.hip.h: ChunkWalk): this kernel takes a chunk every ~4.5 ns chip-wide, one counter hands out
+// a run every ~11.5 ns -- with 1 the launch took 10 ms instead of 4 (profiles/r05/experiments/dynamic_chunks.txt)
+#ifndef RT_PICK_RUN
+#define RT_PICK_RUN 8
+#endif
 template <bool COMPACT>
 __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick_refill(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
                                                                               const PointSoA points, const RayQueue queue, const RayQueue nee,
-                                                                              const Layering layers) {
+                                                                              const Layering layers, uint32_t *__restrict__ work /* dynamic chunk hand-out, may be null */) {
     const uint32_t lane = threadIdx.x;
-    ChunkWalk walk(queue.live_chunks());
+    ChunkWalk walk(queue.live_chunks(), work, RT_PICK_RUN);
     uint32_t pool_slot = 0, pool_left = 0, pool_stripe = 0; // (uniform) the chunk being handed out
     bool exhausted = false;                                  // (uniform) no chunk left to hand out
     // lane state
@@ -464,58 +472,120 @@ __global__ void __launch_bounds__(WAVE) k_shade_sky(const SceneView sc, const Sh
 // into a 64-byte line, and that costs more than the idle lanes did.  profiles/r04/experiments/shade_by_class.txt; code: commit e0e002d.)
 
 // ---- launcher ---------------------------------------------------------------------------------------------------------------
+// blocks of `kernel` the device holds at once (one wavefront per block), per device and kernel; 0 if the runtime will not say
+static int resident_blocks(const void *kernel) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(dev, kernel);
+    const auto it = cache.find(key);
+    if (it != cache.end()) {
+        return it->second;
+    }
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, 0) != hipSuccess || per_cu <= 0 ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        per_cu = 0;
+    }
+    return cache[key] = per_cu * cus;
+}
+
 void launch(const ShadeLaunch &a) {
     hipStream_t s = a.stream;
     const int g = a.grid;
+    // Grid of one launch of the stage.  Round 5: sized from what its queue is EXPECTED to hold (a.expect: live chunks, from the counts the
+    // previous pass left behind; 0 = unknown -> the pass's full grid) -- a.chunks_per_block live chunks per block, but at least one block
+    // per wave slot of the device while there are chunks for them.  The kernels walk their queue with any grid; before, every launch
+    // dispatched the full 32 k blocks of the pass (~20 us even when the queue holds a few hundred rays: the late bounces, a rank of 8).
+    auto sized = [&](auto kernel, const uint32_t expect, const int cap) {
+        int grid = std::min(g, cap);
+        if (expect != 0u && a.chunks_per_block > 0) {
+            const int resident = std::max(1, resident_blocks(reinterpret_cast<const void *>(kernel)));
+            const uint32_t want = std::max(std::min(expect, uint32_t(resident)), expect / uint32_t(a.chunks_per_block));
+            grid = int(std::min<uint32_t>(uint32_t(grid), std::max(want, 1u)));
+        }
+        return grid;
+    };
+    const int all = 1 << 30;
     const bool pick_apart = (a.split & 1) != 0 && a.sc.light_cwnodes_count != 0;
     // stage 1: what was hit (SKY: the environment is the physical sky -- narrow rays that leave the scene are queued for k_shade_sky)
 #define RT_SURFACE_ARGS a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers, a.sky_index, a.out_sky
+#define RT_SURFACE(...) k_surface<__VA_ARGS__><<<sized(k_surface<__VA_ARGS__>, a.expect[EXPECT_RAYS], all), WAVE, 0, s>>>(RT_SURFACE_ARGS)
     const bool sky = a.sc.sky.desc != nullptr;
     if (a.bounce == 0) {
         if (sky) {
-            pick_apart ? k_surface<true, false, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS) : k_surface<true, true, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS);
+            if (pick_apart) {
+                RT_SURFACE(true, false, true);
+            } else {
+                RT_SURFACE(true, true, true);
+            }
+        } else if (pick_apart) {
+            RT_SURFACE(true, false);
         } else {
-            pick_apart ? k_surface<true, false><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS) : k_surface<true, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS);
+            RT_SURFACE(true, true);
         }
     } else {
         if (sky) {
-            pick_apart ? k_surface<false, false, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS) : k_surface<false, true, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS);
+            if (pick_apart) {
+                RT_SURFACE(false, false, true);
+            } else {
+                RT_SURFACE(false, true, true);
+            }
+        } else if (pick_apart) {
+            RT_SURFACE(false, false);
         } else {
-            pick_apart ? k_surface<false, false><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS) : k_surface<false, true><<<g, WAVE, 0, s>>>(RT_SURFACE_ARGS);
+            RT_SURFACE(false, true);
         }
     }
+#undef RT_SURFACE
 #undef RT_SURFACE_ARGS
-    if (a.sc.sky.desc != nullptr) { // paths that ended in the physical sky
-        k_shade_sky<<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.sky_index, a.out_sky, a.px, a.vw, a.layers);
+    if (a.sc.sky.desc != nullptr) { // paths that ended in the physical sky: diffuse bounces and wide cones never defer to it, so the queue is
+                                    // often empty -- the grid is capped like the emissive kernel's
+        k_shade_sky<<<sized(k_shade_sky, a.expect[EXPECT_SKY], 4096), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.sky_index, a.out_sky, a.px, a.vw, a.layers);
     }
     // emitter hits whose MIS weight was deferred; an empty queue costs a few microseconds
-    k_shade_emissive<<<std::min(g, 2048), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.deferred, a.out_deferred, a.px, a.vw);
+    k_shade_emissive<<<sized(k_shade_emissive, a.expect[EXPECT_DEFERRED], 2048), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.deferred, a.out_deferred, a.px, a.vw);
     // stage 2: which light
     const bool nee_compact = pick_apart && (a.split & 4) != 0;
     const bool pick_refill = (a.split & 8) != 0;
-    if (nee_compact && pick_refill) {
-        k_light_pick_refill<true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
-    } else if (pick_apart && pick_refill) {
-        k_light_pick_refill<false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
+    if (pick_apart && pick_refill) {
+        // the persistent pick: with a work counter its chunks are handed out dynamically (wavefront.hip.h: ChunkWalk) and the grid is what the
+        // device holds at once
+        auto go = [&](auto kernel) {
+            int grid = sized(kernel, a.expect[EXPECT_POINTS], all);
+            if (a.work) {
+                const int resident = std::max(1, resident_blocks(reinterpret_cast<const void *>(kernel))) * std::max(1, a.dyn_mult);
+                const uint32_t bound = a.expect[EXPECT_POINTS] != 0u ? a.expect[EXPECT_POINTS] : a.chunks;
+                grid = int(std::max<uint32_t>(1u, std::min<uint32_t>({uint32_t(g), uint32_t(resident), std::max(bound, 1u)})));
+            }
+            kernel<<<grid, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers, a.work);
+        };
+        nee_compact ? go(k_light_pick_refill<true>) : go(k_light_pick_refill<false>);
     } else if (nee_compact) {
-        k_light_pick<true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
+        k_light_pick<true><<<sized(k_light_pick<true>, a.expect[EXPECT_POINTS], all), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
     } else if (pick_apart) {
-        k_light_pick<false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
+        k_light_pick<false><<<sized(k_light_pick<false>, a.expect[EXPECT_POINTS], all), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
     }
     // stage 3: shadow ray + continuation
+#define RT_SCATTER_ARGS(queue) a.sc, a.sp, a.rays_in, a.points, queue, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee
+#define RT_SCATTER(queue, expect, ...) k_scatter<__VA_ARGS__><<<sized(k_scatter<__VA_ARGS__>, expect, all), WAVE, 0, s>>>(RT_SCATTER_ARGS(queue))
     if (nee_compact) {
         // the next-event estimation runs over the points that have a light to sample -- full wavefronts instead of the 11 of 64
         // lanes that take that branch in the combined kernel (Bistro-class scene) -- the continuation over all points; or, when
         // most points are lit, the combined kernel (lit_points_are_sparse)
-        k_scatter<true, false, true, 1><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.nee, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
-        k_scatter<false, true, false, 1><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
-        k_scatter<true, true, false, 2><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
+        RT_SCATTER(a.nee, a.expect[EXPECT_LIT], true, false, true, 1);
+        RT_SCATTER(a.pts, a.expect[EXPECT_POINTS], false, true, false, 1);
+        RT_SCATTER(a.pts, a.expect[EXPECT_POINTS], true, true, false, 2);
     } else if ((a.split & 2) != 0) {
-        k_scatter<true, false><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
-        k_scatter<false, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
+        RT_SCATTER(a.pts, a.expect[EXPECT_POINTS], true, false);
+        RT_SCATTER(a.pts, a.expect[EXPECT_POINTS], false, true);
     } else {
-        k_scatter<true, true><<<g, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
+        RT_SCATTER(a.pts, a.expect[EXPECT_POINTS], true, true);
     }
+#undef RT_SCATTER
+#undef RT_SCATTER_ARGS
 }
 
 } // namespace shade

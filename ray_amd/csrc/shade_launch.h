@@ -36,11 +36,18 @@ struct ShadeLaunch {
     int vw;           // row pitch of the per-iteration pixel buffers (virtual frame width)
     float mix_factor; // 1 / iteration: blend of the first-hit feature images (single-layer passes)
     int bounce, grid;
+    // round 5: grids sized from what the queues are expected to hold (live chunks of 64, from the counts of the previous pass; 0: unknown)
+    uint32_t expect[5] = {0, 0, 0, 0, 0}; // EXPECT_*
+    int chunks_per_block = 0;             // live chunks a block of a streaming kernel should find (0: the pass's full grid, as before round 5)
+    uint32_t *work = nullptr;             // the persistent light pick: zeroed counter of the dynamic chunk hand-out (wavefront.hip.h), or null
+    uint32_t chunks = 0;                  // upper bound of the chunks a queue of the pass holds (slots / 64)
+    int dyn_mult = 1;                     // with `work`: blocks per resident wave slot
     int split;        // bit 0: the light pick as its own kernel; bit 1: next-event estimation and continuation as two launches;
                       // bit 2 (with bit 0): next-event estimation as its own launch over the points that GOT a light, densely packed;
                       // bit 3 (with bit 0): the light pick as a persistent kernel whose lanes take the next point when theirs is through
     hipStream_t stream;
 };
+enum { EXPECT_RAYS = 0, EXPECT_POINTS, EXPECT_LIT, EXPECT_DEFERRED, EXPECT_SKY };
 namespace shade {
 void launch(const ShadeLaunch &a);
 }

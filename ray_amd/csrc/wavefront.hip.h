@@ -89,10 +89,29 @@ struct RayQueue {
 #ifndef RT_XCD_CHUNKS
 #define RT_XCD_CHUNKS 0
 #endif
+// Round 5 -- chunks handed out DYNAMICALLY (the persistent kernels with lane refill: K2, K3, the light pick).  With `work` set, a block takes
+// chunk blockIdx.x as before and every further one from a shared counter (one atomic per run of `run` chunks, issued by lane 0) instead of
+// a fixed share.  Why: a wavefront that refills its lanes idles through the tail of its longest ray ONCE PER BLOCK, when its share is used up;
+// with a fixed share per block the grid has to be many times what the device holds to even out the end of the launch (16 x: a block of a rank
+// of 8 then owns three or four live chunks -- three or four rays per lane -- and drains after each).  Dynamically, a grid of resident blocks
+// ends when the LAST CHUNK is done, and every wavefront drains once.
+// What it costs, and why only those kernels use it (profiles/r05/experiments/dynamic_chunks.txt): read-modify-writes on ONE address retire
+// every ~11.5 ns chip-wide (tools/atomic_bench.hip) -- enough for K2's secondary bounces (a chunk per wavefront every ~100 us, ~35 M fetches
+// per second), not for a kernel that streams (the primary K2 launch: 2 M chunks in 16 ms) -- and the wait for the fetched index is a wait for
+// ALL of the wavefront's outstanding memory operations (vmcnt counts loads and stores alike), which a streaming kernel cannot afford: its
+// stores of chunk k overlap its loads of chunk k + 1.  First form tried: every chunk fetched, a second counter to re-arm the first -- 2 x 6 k
+// serialized atomics = 140 us in every launch, empty or not.  Hence: the first chunk of a block costs nothing (a launch with no more chunks
+// than blocks issues no atomic at all), and the host clears the counters of a pass together with its queue counters.
+// The order in which chunks are taken has no influence on results (every ray's pixel, slot stripe and arithmetic are its own).
+// `work` == nullptr is the static walk.  Wavefront-collective: all 64 lanes active.
+constexpr uint32_t WORK_COUNTER_STRIDE = 64; // uint32 words between the counters of consecutive launches (a 256-byte line each)
 struct ChunkWalk {
     uint32_t base, n, grid, x, local;
-    __device__ __forceinline__ explicit ChunkWalk(const uint32_t n_chunks) : base(0), n(n_chunks) {
-        const bool remap = RT_XCD_CHUNKS != 0 && gridDim.x >= 8u;
+    uint32_t *work;
+    uint32_t run, run_next, run_left;
+    __device__ __forceinline__ explicit ChunkWalk(const uint32_t n_chunks, uint32_t *work_counter = nullptr, const uint32_t run_length = 1u)
+        : base(0), n(n_chunks), work(work_counter), run(run_length), run_next(0), run_left(0) {
+        const bool remap = RT_XCD_CHUNKS != 0 && gridDim.x >= 8u && work_counter == nullptr;
         grid = remap ? (gridDim.x & ~7u) : gridDim.x; // (up to seven surplus blocks of a grid that is not a multiple of 8 idle)
         x = remap ? (blockIdx.x & 7u) : 0u;
         local = remap ? (blockIdx.x >> 3) : blockIdx.x;
@@ -104,6 +123,35 @@ struct ChunkWalk {
     uint32_t parts;
     // the next chunk of this block (wave-uniform); false when there is none left
     __device__ __forceinline__ bool next(uint32_t &c) {
+        if (work != nullptr) {
+            if (base == 0u) { // the first chunk of a block is its own
+                base = 1u;
+                c = blockIdx.x;
+                if (c >= n || gridDim.x >= n) { // (nothing, or nothing beyond the first chunks: no atomic from this block)
+                    base = 2u;
+                }
+                return c < n;
+            }
+            if (run_left != 0u) {
+                c = run_next++;
+                --run_left;
+                return true;
+            }
+            if (base == 2u) {
+                return false;
+            }
+            uint32_t v = 0u;
+            if (__lane_id() == 0u) {
+                v = atomicAdd(work, run);
+            }
+            c = gridDim.x + uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
+            if (c >= n) {
+                base = 2u;
+                return false;
+            }
+            run_next = c + 1u, run_left = min(run, n - c) - 1u;
+            return true;
+        }
         while (base < n) {
             const uint32_t width = min(grid, n - base), per = (width + parts - 1u) / parts;
             const uint32_t off = x * per + local;

@@ -75,7 +75,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 
 # every symbol include/rayhip.h declares (tests check that the built library exports all of them)
 ENTRY_POINTS = (
-    "last_error", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
+    "last_error", "abi_version", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
     "scene_upload", "scene_bvh_width", "closest_hit_form", "scene_upload_blob", "scene_update_instances", "scene_update_instances_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand", "k_shade",
@@ -158,6 +158,10 @@ class Library:
 
     def device_count(self) -> int:
         return int(self.fn("device_count")())
+
+    def abi_version(self) -> int:
+        """RAYHIP_ABI_VERSION of the header the library was built from (include/rayhip.h)"""
+        return int(self.fn("abi_version")())
 
     def check(self, status: int):
         if status != 0:

@@ -137,6 +137,7 @@ void ray_default_camera(ray_camera_desc *d) {
 }
 void ray_default_env(ray_env_desc *d) {
     memset(d, 0, sizeof(*d));
+    d->struct_size = uint32_t(sizeof(*d));
     d->env_map = d->back_map = RAY_INVALID_HANDLE;
     d->importance_sample = 1;
     const Ray::environment_desc_t e;
@@ -296,6 +297,10 @@ void ray_region_set_iteration(ray_region *g, int it) { g->ctx.iteration = it; }
 void ray_scene_destroy(ray_scene *s) { delete s; }
 
 void ray_scene_set_environment(ray_scene *s, const ray_env_desc *d) {
+    if (d->struct_size != sizeof(ray_env_desc)) { // (a caller built against the shorter struct of round 3)
+        g_err = "ray_env_desc::struct_size does not match this library's struct: start from ray_default_env of THIS ray_capi.h";
+        return;
+    }
     Ray::environment_desc_t e;
     memcpy(e.env_col, d->env_col, 12);
     e.env_map = to_handle<Ray::TextureHandle>(d->env_map);

@@ -137,6 +137,8 @@ typedef struct ray_camera_desc { /* Ray::camera_desc_t, SceneBase.h:264-311 */
 
 #define RAY_PHYSICAL_SKY_TEXTURE 0xfffffffeull /* Ray::PhysicalSkyTexture (SceneBase.h:35): as env_map / back_map, the analytic sky */
 typedef struct ray_env_desc { /* Ray::environment_desc_t, SceneBase.h:343-353; of the atmosphere the fields tests vary, the rest at defaults */
+    uint32_t struct_size; /* sizeof(ray_env_desc) as the caller compiled it (ray_default_env fills it in): the struct grew in round 4 and
+                           * a caller built against the shorter one must be refused, not read past its end */
     float env_col[3];
     ray_handle env_map;
     float back_col[3];
@@ -193,7 +195,8 @@ int ray_region_iteration(ray_region *g);
 void ray_region_set_iteration(ray_region *g, int it);
 
 void ray_scene_destroy(ray_scene *s);
-void ray_scene_set_environment(ray_scene *s, const ray_env_desc *d);                 /* SceneBase::SetEnvironment */
+/* SceneBase::SetEnvironment; a descriptor whose struct_size is not this library's is ignored and ray_last_error says so */
+void ray_scene_set_environment(ray_scene *s, const ray_env_desc *d);
 ray_handle ray_scene_add_texture(ray_scene *s, const ray_tex_desc *d);               /* SceneBase::AddTexture */
 ray_handle ray_scene_add_material_node(ray_scene *s, const ray_shading_node_desc *d); /* AddMaterial(shading_node_desc_t) */
 ray_handle ray_scene_add_material_principled(ray_scene *s, const ray_principled_mat_desc *d);

@@ -159,6 +159,7 @@ class SceneAccess : public Cpu::Scene {
         }
         rayhip_scene_desc &d = out.desc;
         d = {};
+        d.struct_size = uint32_t(sizeof(rayhip_scene_desc));
 #define SPARSE(field, member, type)                                                                                    \
     d.field = reinterpret_cast<const type *>(s.member.data());                                                        \
     d.field##_count = s.member.capacity();

@@ -639,10 +639,11 @@ def _procedural_texture(res: int, seed: int, kind: str) -> np.ndarray:
 
 
 def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = False, tex_res: int = 1024, compress: bool = False,
-           one_material_type: bool = False):
+           one_material_type: bool = False, spatial_splits: bool = False, fast_bvh_build: bool = False):
     """Synthetic atrium, 30 x 12 x 18 (SURVEY.md section 8d input 3/4).  Triangle count ~ 250k * detail.
     textured=True: every large surface gets its own mip-mapped base-colour map, the stone also a normal map, the floor a
-    roughness map (11 maps of tex_res^2: the material -> texture gathers a textured asset set causes in the shade stage)."""
+    roughness map (11 maps of tex_res^2: the material -> texture gathers a textured asset set causes in the shade stage).
+    spatial_splits / fast_bvh_build: mesh_desc_t::allow_spatial_splits / use_fast_bvh_build (SceneBase.h:130-131) of the one mesh."""
     d = max(detail, 0.02)
     s = math.sqrt(d)
     scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
@@ -759,7 +760,7 @@ def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = Fals
         mb.add(a, i, emit, back=0xFFFFFFFF)
 
     attrs, idx, groups = mb.finish()
-    mesh = scene.AddMesh(attrs, idx, groups)
+    mesh = scene.AddMesh(attrs, idx, groups, allow_spatial_splits=spatial_splits, use_fast_bvh_build=fast_bvh_build)
     scene.AddMeshInstance(mesh)
     kw = dict(type=0, origin=(-X / 2 + 2.5, 2.2, 0.6), fwd=_unit((1.0, 0.12, -0.08)), fov=60.0)
     kw.update(cam_overrides or {})
@@ -767,6 +768,69 @@ def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = Fals
     scene.set_current_cam(cam)
     scene.Finalize()
     return int(len(idx) // 3)
+
+
+def cornell_needles(scene, spatial_splits: bool = False, fast_bvh_build: bool = False, seed: int = 5, **cam_overrides):
+    """The Cornell room (big wall triangles) with ~300 long thin slivers strung diagonally through it and a carpet of small triangles on the
+    floor, all ONE mesh: the case mesh_desc_t::allow_spatial_splits exists for (BVHSplit.cpp:323-470 -- a sliver's box covers half the room,
+    so the builder duplicates its reference into several leaves), which is exactly what the leaf refinement, the layout permutation and
+    the 4-wide collapse on the upload path must survive.  use_fast_bvh_build selects the reference's binned builder."""
+    rs = np.random.RandomState(9100 + seed)
+    scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
+    grey = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.5, 0.5)))
+    red = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.5, 0.0, 0.0)))
+    green = scene.AddMaterial(ShadingNode(type=eShadingNode.Diffuse, base_color=(0.0, 0.5, 0.0)))
+    lamp = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=100.0, importance_sample=True))
+    gloss = scene.AddMaterial(ShadingNode(type=eShadingNode.Glossy, base_color=(0.8, 0.7, 0.3), roughness=0.2))
+    attrs, idx = cornell_mesh_arrays(_CORNELL_QUADS)
+    attrs, idx = [attrs], [idx]
+    n_room = int(attrs[0].shape[0])
+    groups = [(grey, None, 0, 18), (red, None, 19, 6), (green, None, 25, 6), (lamp, 0xFFFFFFFF, 31, 6)]
+    base = n_room
+    n_idx = 37  # (the room's index list: 6 quads x 6 + the sample's off-by-one start of every group, kept as the reference sample has it)
+    n_idx = int(idx[0].size)
+
+    def add_tris(tri_pts, mat):
+        nonlocal base, n_idx
+        tri_pts = np.asarray(tri_pts, dtype=np.float32).reshape(-1, 3, 3)
+        nrm = np.cross(tri_pts[:, 1] - tri_pts[:, 0], tri_pts[:, 2] - tri_pts[:, 0])
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=-1, keepdims=True), 1e-12)
+        a = np.zeros((tri_pts.shape[0] * 3, 8), dtype=np.float32)
+        a[:, 0:3] = tri_pts.reshape(-1, 3)
+        a[:, 3:6] = np.repeat(nrm, 3, axis=0)
+        attrs.append(a)
+        idx.append(np.arange(base, base + a.shape[0], dtype=np.uint32))
+        groups.append((mat, mat, n_idx, a.shape[0]))
+        base += a.shape[0]
+        n_idx += a.shape[0]
+
+    # slivers: 0.5 long, 0.004 wide -- half of them axis-aligned planks over the carpet (their boxes overlap hundreds of small triangles' boxes:
+    # what the builder's spatial split is for), half random diagonals through the room
+    lo, hi = np.array([-0.54, 0.02, -0.54]), np.array([-0.02, 0.52, -0.02])
+    p0 = lo + rs.uniform(size=(300, 3)) * (hi - lo)
+    p1 = lo + rs.uniform(size=(300, 3)) * (hi - lo)
+    planks = np.arange(300) < 150
+    along_x = planks & (np.arange(300) % 2 == 0)
+    along_z = planks & ~along_x
+    p0[planks, 1] = p1[planks, 1] = 0.012 + 0.0004 * np.arange(150)
+    p0[along_x, 0], p1[along_x, 0], p1[along_x, 2] = -0.535, -0.025, p0[along_x, 2]
+    p0[along_z, 2], p1[along_z, 2], p1[along_z, 0] = -0.535, -0.025, p0[along_z, 0]
+    side = np.cross(p1 - p0, np.where(planks[:, None], np.array([0.0, 1.0, 0.0]), rs.normal(size=(300, 3))))
+    side *= 0.002 / np.maximum(np.linalg.norm(side, axis=-1, keepdims=True), 1e-9)
+    add_tris(np.stack([p0 - side, p0 + side, p1], axis=1), gloss)
+    # carpet: a 40 x 40 grid of small triangles just above the floor
+    g = np.linspace(-0.53, -0.03, 41)
+    x0, z0 = np.meshgrid(g[:-1], g[:-1], indexing="ij")
+    d = g[1] - g[0]
+    y = 0.004 + 0.003 * np.sin(x0 * 60.0) * np.cos(z0 * 45.0)
+    a = np.stack([x0, y, z0], -1).reshape(-1, 3)
+    b = a + np.array([d, 0.0, 0.0])
+    c = a + np.array([0.0, 0.0, d])
+    add_tris(np.stack([a, c, b], axis=1), grey)
+    mesh = scene.AddMesh(np.concatenate(attrs), np.concatenate(idx), groups, allow_spatial_splits=spatial_splits, use_fast_bvh_build=fast_bvh_build)
+    scene.AddMeshInstance(mesh)
+    _cornell_camera(scene, **cam_overrides)
+    scene.Finalize()
 
 
 def _unit(v):

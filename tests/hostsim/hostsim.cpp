@@ -143,6 +143,10 @@ HS_API int hostsim_clear(hostsim_ctx *c, const float rgba[4]) { // RendererCPU.h
     return 0;
 }
 HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
+    if (d_in->struct_size != sizeof(rayhip_scene_desc)) { // (the library's own check: rayhip_scene_upload)
+        g_err = "rayhip_scene_desc::struct_size does not match this build's struct";
+        return 1;
+    }
     const rayhip_layout::AlignedDesc aligned0(*d_in);
     if (!rayhip_validate::validate(aligned0.d, g_err)) {
         return 1;

@@ -385,6 +385,52 @@ def test_refill_kernel_is_bit_identical(gpu_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("name", SCENES)
+def test_sized_launches_and_dynamic_chunks_are_bit_identical(gpu_lib, name, monkeypatch):
+    """round 5: (1) every launch of a pass is sized from the queue census of the pass before (RAYHIP_CENSUS=0: the full grid every time),
+    (2) the shadow rays of a bounce are traced on a second stream next to the closest-hit launch of the next bounce
+    (RAYHIP_OVERLAP_SHADOW=0: one stream), (3) opt-in, the persistent kernels with lane refill -- K2's secondary bounces, K3, the light pick --
+    take their chunks from a shared counter (wavefront.hip.h: ChunkWalk with a work counter; RAYHIP_DYNAMIC=1).  Which block walks which
+    chunk, how many blocks there are and which stream a launch sits on is invisible in every image: layered and single passes, a census
+    that has arrived (sync between passes) or not, one live chunk per block, four blocks per wave slot, shards and rects must all give
+    the bits of the round-4 schedule."""
+    w, h = 96, 80
+    monkeypatch.setenv("RAYHIP_CENSUS", "0"), monkeypatch.setenv("RAYHIP_OVERLAP_SHADOW", "0")
+    old = util.make_context(gpu_lib, name, w, h)  # the round-4 schedule
+    monkeypatch.delenv("RAYHIP_CENSUS")
+    census_only = util.make_context(gpu_lib, name, w, h)
+    monkeypatch.delenv("RAYHIP_OVERLAP_SHADOW")
+    default = util.make_context(gpu_lib, name, w, h)  # census + K3 next to K2 on a second stream
+    monkeypatch.setenv("RAYHIP_DYNAMIC", "1")
+    dynamic = util.make_context(gpu_lib, name, w, h)
+    monkeypatch.setenv("RAYHIP_DYN_MULT", "4"), monkeypatch.setenv("RAYHIP_CHUNKS_PER_BLOCK", "1")
+    many_blocks = util.make_context(gpu_lib, name, w, h)
+    monkeypatch.delenv("RAYHIP_DYN_MULT"), monkeypatch.delenv("RAYHIP_DYNAMIC"), monkeypatch.setenv("RAYHIP_CHUNKS_PER_BLOCK", "1000")
+    few_blocks = util.make_context(gpu_lib, name, w, h)
+    monkeypatch.delenv("RAYHIP_CHUNKS_PER_BLOCK")
+    ctxs = (old, census_only, default, dynamic, many_blocks, few_blocks)
+    for ctx in ctxs:
+        ctx.render_batch(1, 6)
+        ctx.sync()  # (the census of the first pass is there when the second starts)
+        ctx.render_batch(7, 6)
+        for it in range(13, 16):  # single-layer passes, census in flight
+            ctx.render(it)
+        ctx.sync()
+        ctx.render_batch(16, 40)  # a pass eight times the size of the one its census comes from
+    for buf in (hip.BUF_RAW, hip.BUF_FINAL, hip.BUF_BASE_COLOR, hip.BUF_DEPTH_NORMALS, hip.BUF_VARIANCE):
+        ref = old.readback(buf)
+        for k, ctx in enumerate(ctxs[1:]):
+            assert np.array_equal(ctx.readback(buf), ref), (buf, k)
+    a = util.make_context(gpu_lib, name, w, h)
+    monkeypatch.setenv("RAYHIP_OVERLAP_SHADOW", "0"), monkeypatch.setenv("RAYHIP_CENSUS", "0")
+    b = util.make_context(gpu_lib, name, w, h)
+    a.set_shard(32, 2, 1), b.set_shard(32, 2, 1)
+    for first in (1, 6):
+        a.render_batch(first, 5, rect=(8, 16, 80, 48)), b.render_batch(first, 5, rect=(8, 16, 80, 48))
+        a.sync()
+    assert np.array_equal(a.readback(hip.BUF_RAW), b.readback(hip.BUF_RAW))
+
+
+@pytest.mark.parametrize("name", SCENES)
 def test_light_pick_with_lane_refill_is_bit_identical(gpu_lib, name, monkeypatch):
     """the light pick as a persistent kernel whose lanes take the next point when their descent is over (k_light_pick_refill, the
     default) against the chunk-at-a-time kernel: per point the same descent, so every image is the same bits (the list of lit

@@ -37,8 +37,9 @@ def main():
             ctx.reserve_batch(batch)
             ctx.render_batch(1, batch)  # set-up pass of the timed shape, like bench.py
             ctx.sync()
+            ctx.stage_times(reset=True)
             t0 = time.perf_counter()
-            multigpu.render_sharded(ctx, range(batch + 1, batch + 1 + K), 0, world, batch=batch)
+            multigpu.render_sharded(ctx, range(batch + 1, batch + 1 + K), 0, world, batch=batch, flags=hip.FLAG_TIME_STAGES)
             # this rank's operand of the frame reduce (the collective itself: 33 MB over xGMI, not emulated here)
             ctx.export_shard_device(hip.BUF_RAW, frame.data_ptr())
             ctx.sync()
@@ -47,6 +48,8 @@ def main():
             base = base or rate
             print(f"N={world} iterations/pass {batch:4d}  rays/pass {W * H // world * batch / 1e6:6.1f} M  rank time {dt * 1e3:8.1f} ms  "
                   f"projected {rate:7.1f} Msamples/s  efficiency {rate / (base * world):5.3f}", flush=True)
+            st = ctx.stage_times(reset=True)
+            print("      stage ms: " + "  ".join(f"{k.replace('primary_', 'p.').replace('secondary_', 's.')} {v / 1e3:.2f}" for k, v in st.items() if v), flush=True)
             ctx.close()
 
 
