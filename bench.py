@@ -130,11 +130,11 @@ def csrc_hash():
 
 
 def traffic_table_path():
-    for r in ("r04", "r03", "r02"):
+    for r in ("r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", r, "k2_traffic.json")
         if os.path.exists(p):
             return p
-    return os.path.join(ROOT, "profiles", "r04", "k2_traffic.json")
+    return os.path.join(ROOT, "profiles", "r05", "k2_traffic.json")
 
 
 def measured_traffic(workload, spp, batch, world=1):
@@ -161,6 +161,11 @@ def measured_traffic(workload, spp, batch, world=1):
                "exact": bool(exact), "table": os.path.relpath(traffic_table_path(), ROOT),
                # the profile belongs to the kernels it was taken with: anything else is a stale figure
                "stale": e.get("csrc_hash") != csrc_hash(), "profiled_csrc_hash": e.get("csrc_hash")}
+        if "shadow" in e:  # (round 5) the any-hit kernel of the same profiled passes: its launches scale like K2's
+            sh = e["shadow"]
+            out["shadow"] = {"bytes_per_launch": float(sh["fetch_bytes_per_launch"] + sh["write_bytes_per_launch"]) * k,
+                             "fetch_bytes_per_launch": float(sh["fetch_bytes_per_launch"]) * k, "write_bytes_per_launch": float(sh["write_bytes_per_launch"]) * k,
+                             "profiled_avg_launch_ms": sh.get("avg_launch_ms") if exact else None, "launches_per_pass": sh.get("launches_per_pass")}
         if "valu_wave_instructions_per_launch" in e:  # (the third profile of tools/k2_traffic.py: SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU)
             out["valu_wave_instructions_per_launch"] = float(e["valu_wave_instructions_per_launch"]) * k
             out["valu_active_lanes"] = e.get("valu_active_lanes")
@@ -195,6 +200,20 @@ def valu_issue_block(traffic, launches, k2_s):
                     "peaks_from": "profiles/r04/k2_valu_mix.json (tools/valu_mix.py) x profiles/r03/valu_bench.txt"})
     except (OSError, ValueError, KeyError):
         out.update({"peak_full_rate_class": 1.09e12, "peak_half_rate_class": 0.59e12})
+    return out
+
+
+def traversal_block(traffic, k2_launches, k3_launches, k2_ms, k3_ms, overlapped, algorithmic_bytes):
+    """roofline of K2 + K3 together"""
+    t_ms = k2_ms if overlapped else k2_ms + k3_ms
+    out = {"kernels": "k_trace_closest_refill (both forms) + k_trace_shadow_refill", "ms_per_region": t_ms,
+           "time_is": ("closest-hit intervals of the context stream (each ends when the K2 launch AND the shadow launch beside it are through)" if overlapped
+                       else "K2 intervals + K3 intervals"),
+           "algorithmic_GBps": algorithmic_bytes / 1e9 / (t_ms / 1e3) if t_ms > 0 else None,
+           "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    if traffic and traffic.get("shadow") and t_ms > 0:
+        total = traffic["bytes_per_launch"] * k2_launches + traffic["shadow"]["bytes_per_launch"] * k3_launches
+        out.update({"traffic": total, "achieved": total / 1e9 / (t_ms / 1e3), "frac": total / 1e9 / (t_ms / 1e3) / HBM_PEAK_GBS})
     return out
 
 
@@ -464,6 +483,7 @@ def main():
         return ctx.trav_counters(reset=True)
 
     bvh_width = ctx.bvh_width()
+    overlap_shadow = os.environ.get("RAYHIP_OVERLAP_SHADOW", "1") != "0" and bvh_width == 4 and os.environ.get("RAYHIP_SHADOW_REFILL", "1") != "0"
     wide_node_bytes = 80 if bvh_width == 8 else 64  # what a node visit reads: the 8-wide node uses 80 bytes of its 128-byte line
 
     def alg_bytes(c, per_ray):
@@ -507,7 +527,9 @@ def main():
                 ("k_trace_closest_pool (secondary bounces: finished lanes take prepared rays from a per-wavefront pool in LDS)" if ctx.closest_hit_form() == 2
                  else f"k_trace_closest_refill<{bvh_width}, 40> (secondary bounces, lanes refilled one by one)") +
                 f" + k_trace_closest_refill<{bvh_width}, 64> (primary rays, whole chunks)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                # (no committed PMC profile of this workload: `achieved` is the kernel's own algorithmic rate -- an upper bound, every visit counted
+                # as a miss -- and no fraction of the HBM peak is claimed for it: VERDICT round 4, weak 4)
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if hbm_gbs is not None else None,
                 "achieved_is": (("HBM traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE of a profiled run of this command) / launch time"
                                  if traffic.get("exact") else
                                  "HBM traffic scaled from the profiled run of this workload with the nearest pass size (traffic is proportional "
@@ -535,9 +557,16 @@ def main():
                                        "note": "what the reference's BVH2 walk would move for the same rays; not a rate of this kernel"},
                 },
                 "rays_per_sample": c2["rays"] / (n_count * W * H / world),
-                "shadow_kernel": {"algorithmic_GBps": (k3_bytes / 1e9) / (k3_ms / 1e3) if k3_ms > 0 else 0.0,
-                                  "avg_launch_ms": k3_ms / max(k3_launches, 1),
+                "shadow_kernel": {"algorithmic_bytes_per_launch": k3_bytes / max(k3_launches, 1),
+                                  "elapsed_ms_per_launch": k3_ms / max(k3_launches, 1),
+                                  "elapsed_is": ("on a second, low-priority stream NEXT TO the closest-hit launch of the following bounce (librayhip, round 5): it takes "
+                                                 "the wave slots that launch leaves idle, so its elapsed time is not its cost -- the traversal block below "
+                                                 "prices K2 and K3 together") if overlap_shadow else "alone on the context stream",
                                   "rays_per_sample": c3["rays"] / (n_count * W * H / world)},
+                # SURVEY 8d's "traversal": K2 + K3 together.  Bytes: the PMC profile's per-launch figures of both kernels x their launches (or
+                # null); time: the closest-hit intervals of the context stream, which end when BOTH the K2 launch and the K3 launch that ran
+                # next to it are through (the last K3 of a pass runs alone: its few microseconds are in the shade interval that follows)
+                "traversal": traversal_block(traffic, k2_launches, k3_launches, k2_ms, k3_ms, overlap_shadow, k2_bytes + k3_bytes),
             },
             "stage_us_per_step": {k: v / K for k, v in stages.items() if v},
             "stage_us_per_spp": {k: v / (K * SPP) for k, v in stages.items() if v},

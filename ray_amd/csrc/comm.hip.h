@@ -248,7 +248,9 @@ int rayhip_comm_create_rank(const void *unique_id, int nranks, int rank, rayhip_
         g_rccl.CommDestroy(comm);
         return fail("RCCL communicator reports rank %d of %d, expected rank %d of %d", seen_rank, seen_ranks, rank, nranks);
     }
-    fprintf(stderr, "rayhip: RCCL communicator up: rank %d of %d on device %d\n", seen_rank, seen_ranks, ctx->device);
+    if (getenv("RAYHIP_TRACE_COMM")) { // (like every other diagnostic of the library: on request only -- an N-rank job would print N lines per communicator)
+        fprintf(stderr, "rayhip: RCCL communicator up: rank %d of %d on device %d\n", seen_rank, seen_ranks, ctx->device);
+    }
     rayhip_comm *m = new rayhip_comm();
     m->nranks = nranks;
     m->local.push_back(rank);

@@ -108,16 +108,24 @@ RT_HD AccumPixel load_accum_pixel(const int idx, const float4 *full_buf, const f
     const float4 ff = full_buf[idx], hh = half_buf[idx];
     return AccumPixel{f4{ff.x, ff.y, ff.z, ff.w}, f4{hh.x, hh.y, hh.z, hh.w}, f4{0.0f, 0.0f, 0.0f, 0.0f}, required_samples[idx]};
 }
+// write_half / write_required: whether the half-sample mean / the adaptive-sampling mark can differ from what memory holds (the layered
+// pass always writes them; the one-iteration pass only on a class-A iteration / when the mark moved -- 18 bytes per pixel and iteration for
+// the passes that cannot batch: ADVICE round 4)
 RT_HD void store_accum_pixel(const AccumParams &p, const int idx, const AccumPixel &s, float4 *variance_px, float4 *full_buf, float4 *half_buf,
-                             float4 *raw_buf, float4 *final_buf, uint16_t *required_samples) {
+                             float4 *raw_buf, float4 *final_buf, uint16_t *required_samples, const bool write_half = true,
+                             const bool write_required = true) {
     const float4 ff = mkfloat4(s.full.x, s.full.y, s.full.z, s.full.w);
     full_buf[idx] = ff;
-    half_buf[idx] = mkfloat4(s.half.x, s.half.y, s.half.z, s.half.w);
+    if (write_half) {
+        half_buf[idx] = mkfloat4(s.half.x, s.half.y, s.half.z, s.half.w);
+    }
     raw_buf[idx] = ff;
     const f4 c = tonemap(p, s.full);
     final_buf[idx] = mkfloat4(c.x, c.y, c.z, c.w);
     *variance_px = mkfloat4(s.variance.x, s.variance.y, s.variance.z, s.variance.w);
-    required_samples[idx] = s.required;
+    if (write_required) {
+        required_samples[idx] = s.required;
+    }
 }
 
 // temp_px: this pixel's radiance of the iteration; variance_px: where its variance estimate goes (the reference reuses
@@ -126,8 +134,11 @@ RT_HD void accumulate_pixel(const AccumParams &p, const int x, const int y, cons
                             float4 *full_buf, float4 *half_buf, float4 *raw_buf, float4 *final_buf, uint16_t *required_samples) {
     const int idx = y * p.w + x;
     AccumPixel s = load_accum_pixel(idx, full_buf, half_buf, required_samples);
+    const uint16_t required_before = s.required;
+    const bool sampled = !(s.required < p.iteration);
     accumulate_step(p, *temp_px, s);
-    store_accum_pixel(p, idx, s, variance_px, full_buf, half_buf, raw_buf, final_buf, required_samples);
+    store_accum_pixel(p, idx, s, variance_px, full_buf, half_buf, raw_buf, final_buf, required_samples, sampled && p.is_class_a != 0,
+                      s.required != required_before);
 }
 
 } // namespace rt

@@ -250,6 +250,26 @@ inline bool validate_sky(const rayhip_scene_desc &d, std::string &err) {
         return false;
     }
     const rayhip_sky &k = *d.sky;
+    // arrays that state a size must exist (a direct C-ABI caller can pass a count with a null pointer; the blob path cannot -- ADVICE round 4)
+    const struct { const void *p; uint64_t n; const char *what; } arrays[] = {
+        {d.sky_transmittance_lut, d.sky_transmittance_lut_count, "sky_transmittance_lut"}, {d.sky_multiscatter_lut, d.sky_multiscatter_lut_count, "sky_multiscatter_lut"},
+        {d.sky_dir_lights, d.sky_dir_lights_count, "sky_dir_lights"}, {d.sky_weather_tex, d.sky_weather_tex_count, "sky_weather_tex"},
+        {d.sky_noise3d_tex, d.sky_noise3d_tex_count, "sky_noise3d_tex"}, {d.sky_curl_tex, d.sky_curl_tex_count, "sky_curl_tex"},
+        {d.sky_moon_tex, d.sky_moon_tex_count, "sky_moon_tex"}, {d.sky_cirrus_tex, d.sky_cirrus_tex_count, "sky_cirrus_tex"}};
+    for (const auto &a : arrays) {
+        if (a.n != 0 && a.p == nullptr) {
+            err = std::string("scene validation: ") + a.what + " states " + std::to_string(a.n) + " elements and is a null pointer";
+            return false;
+        }
+    }
+    // ... and the atmosphere must describe one: a zero or NaN radius or scale height gives NaN radiance, not an error, further down
+    const rayhip_atmosphere &at = k.atmosphere;
+    const auto positive = [](const float v) { return v > 0.0f && v < 3.0e38f; }; // (false for NaN)
+    if (!positive(at.planet_radius) || !positive(at.atmosphere_height) || !positive(at.rayleigh_height) || !positive(at.mie_height) ||
+        !(at.clouds_height_beg < at.clouds_height_end) || !(at.viewpoint_height == at.viewpoint_height)) {
+        err = "scene validation: sky atmosphere needs finite positive planet_radius, atmosphere_height, rayleigh_height, mie_height and clouds_height_beg < clouds_height_end";
+        return false;
+    }
     const auto pow2 = [](const int32_t v) { return v > 0 && (v & (v - 1)) == 0; };
     const auto sized = [&](const char *what, const uint64_t have, const uint64_t want) {
         if (have != want) {

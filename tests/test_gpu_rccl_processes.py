@@ -24,7 +24,8 @@ def test_ranks_in_separate_processes_gather_over_rccl(ranks):
     have = _device_count()
     if have < ranks:
         pytest.skip(f"{ranks} RCCL ranks need {ranks} devices, {have} visible")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAYHIP_TRACE_COMM="1")
+    env.pop("RAYHIP_RCCL_LIB", None)  # the real library
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
            "--master-port", str(29560 + ranks), os.path.join(HERE, "rccl_ranks_worker.py")]
     done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -34,3 +35,36 @@ def test_ranks_in_separate_processes_gather_over_rccl(ranks):
     # every rank reported what RCCL itself said about the communicator
     for r in range(ranks):
         assert f"RCCL communicator up: rank {r} of {ranks}" in done.stderr
+
+
+FAKE_RCCL = os.path.join(HERE, "fake_rccl", "_build", "libfake_rccl.so")
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_the_rccl_code_path_with_a_stand_in_transport(ranks, tmp_path):
+    """VERDICT round 4, task 4: the product's per-process exchange -- rayhip_comm_create_rank (communicator checked against what the library
+    reports), rayhip_comm_reduce_framebuffers (region offsets and counts per rank, ONE ncclSend per rank and N - 1 ncclRecv on the root inside
+    one group, unpack, re-tonemap) -- executed with N > 1 ranks on whatever devices the box has, through tests/fake_rccl loaded by the
+    existing RAYHIP_RCCL_LIB override (a stand-in for the eleven nccl* symbols comm.hip.h resolves: messages travel through shared host
+    memory, so two ranks may share device 0).  Rank 0 compares all five images with an unsharded render bit for bit, twice (the root holds
+    a combined frame when the second round starts); the log of the stand-in shows the group each rank really posted."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.skip("tests/fake_rccl not built (run __graft_entry__.build())")
+    log = os.path.join(str(tmp_path), "ops.log")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RAYHIP_RCCL_LIB=FAKE_RCCL, RAYHIP_TRACE_COMM="1", FAKE_RCCL_LOG=log)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29570 + ranks), os.path.join(HERE, "rccl_ranks_worker.py")]
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    sys.stderr.write(done.stderr[-4000:])
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
+    assert f"RCCL_RANKS_OK {ranks}" in done.stdout
+    for r in range(ranks):
+        assert f"RCCL communicator up: rank {r} of {ranks}" in done.stderr
+    with open(log) as f:
+        ops = [line.split() for line in f]
+    # two exchanges: every rank but the root sent once per exchange, to the root; the root received once from each of them, the sizes agree
+    sends = [(int(o[1]), int(o[3]), int(o[6])) for o in ops if o[2] == "send"]
+    recvs = [(int(o[1]), int(o[3]), int(o[6])) for o in ops if o[2] == "recv"]
+    assert sorted(r for r, _, _ in sends) == sorted(list(range(1, ranks)) * 2) and all(peer == 0 for _, _, peer in sends)
+    assert all(r == 0 for r, _, _ in recvs) and sorted(peer for _, _, peer in recvs) == sorted(list(range(1, ranks)) * 2)
+    assert sorted(n for _, n, _ in sends) == sorted(n for _, n, _ in recvs) and all(n > 0 and n % 16 == 0 for _, n, _ in sends)

@@ -18,6 +18,7 @@ Unit of both counters: KiB.  Appends / replaces the entry for this (workload, sp
 import csv, glob, json, os, re, sys
 
 K2_FORMS = ("k_trace_closest<false, 8", "k_trace_closest<false, 4", "k_trace_closest<false, true", "k_trace_closest_refill", "k_trace_closest_pool")
+K3_FORMS = ("k_trace_shadow_refill", "k_trace_shadow<false")  # the any-hit kernel: SURVEY 8d's "traversal" is K2 + K3
 
 
 def short(name):
@@ -52,16 +53,20 @@ def is_k2(kernel):
     return any(kernel.startswith(k) for k in K2_FORMS)
 
 
+def is_k3(kernel):
+    return any(kernel.startswith(k) for k in K3_FORMS)
+
+
 def main():
     out, workload, steps, warmup, spp, ipp, fetch_dir, write_dir = sys.argv[1:9]
     table_path = sys.argv[9] if len(sys.argv) > 9 else None
     steps, warmup, spp, ipp = int(steps), int(warmup), int(spp), int(ipp)
     fetch_all, write_all, dur_all = counters(fetch_dir, "FETCH_SIZE"), counters(write_dir, "WRITE_SIZE"), durations(fetch_dir)
 
-    def product_part(rows):
-        """the K2 launches in front of the first instrumented kernel (what follows it -- the counting passes, a parity render -- is not the timed region)"""
+    def product_part(rows, which=is_k2):
+        """the K2 (K3) launches in front of the first instrumented kernel (what follows it -- the counting passes, a parity render -- is not the timed region)"""
         cut = next((i for i, (_, k, _) in enumerate(rows) if k.startswith("k_trace_closest<true")), len(rows))
-        return [r for r in rows[:cut] if is_k2(r[1])]
+        return [r for r in rows[:cut] if which(r[1])]
 
     fetch, write, durs = product_part(fetch_all), product_part(write_all), product_part(dur_all)
     per_frame = -(-spp // ipp)
@@ -86,6 +91,15 @@ def main():
             entry["valu_wave_instructions_per_launch"] = sum(v for _, _, v in insts) / len(insts)
             if lanes:
                 entry["valu_active_lanes"] = sum(v for _, _, v in lanes) / max(sum(v for _, _, v in insts), 1.0)
+    # the any-hit kernel K3 of the same passes (round 5: bench.py's roofline block covers the traversal, K2 + K3)
+    f3, w3, d3 = product_part(fetch_all, is_k3), product_part(write_all, is_k3), product_part(dur_all, is_k3)
+    per_pass3 = len(f3) // max(passes + warm_passes + per_frame, 1)
+    take3 = per_pass3 * passes
+    if take3:
+        f3, w3, d3 = f3[-take3:], w3[-take3:], d3[-take3:]
+        entry["shadow"] = {"kernels": sorted({k for _, k, _ in f3}), "launches_sampled": len(f3), "launches_per_pass": per_pass3,
+                           "fetch_bytes_per_launch": sum(v for _, _, v in f3) / len(f3), "write_bytes_per_launch": sum(v for _, _, v in w3) / max(len(w3), 1),
+                           "avg_launch_ms": sum(v for _, _, v in d3) / max(len(d3), 1)}
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     entry["csrc_hash"] = bench.csrc_hash()  # the kernels this profile belongs to (bench.py marks it stale for any other)
