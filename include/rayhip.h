@@ -476,6 +476,12 @@ RAYHIP_API int rayhip_set_raw_device(rayhip_ctx *ctx, const void *src_device_rgb
  * `rect` (corner a multiple of 16); the last pass writes RAW (alpha untouched) and FINAL = Tonemap(RAW) with `cam`. */
 RAYHIP_API int rayhip_unet_init(rayhip_ctx *ctx, const float *weights, int weights_count, const int32_t offsets[32], int alignment);
 RAYHIP_API int rayhip_denoise_unet(rayhip_ctx *ctx, const rayhip_camera *cam, const int rect[4], int pass);
+/* Which arithmetic the passes run in (takes effect with the next rayhip_denoise_unet; switch between frames, not between the passes of one):
+ *   0  f32 tensors and weights on v_mfma_f32_16x16x4_f32 -- the exact form (default of the C ABI: every pass within 2e-5 of the CPU reference)
+ *   1  f16 tensors and weights, f32 accumulators, on v_mfma_f32_16x16x32_f16 -- what the reference's own GPU backends run where the device has
+ *      half-precision (matrix) arithmetic (internal/RendererVK.cpp:254-263, 1834-1844; RendererGPU.h:533-545): 12.8 x the matrix rate, half the
+ *      tensor traffic; RendererHIP selects it like they do (RAY_HIP_UNET_F32=1 keeps the exact form). */
+RAYHIP_API int rayhip_unet_set_precision(rayhip_ctx *ctx, int half);
 /* test hook: activation tensor `which` (0 .. 14 in the order of unet_filter_tensors_t) incl. its one-pixel border, NHWC */
 RAYHIP_API int rayhip_unet_read_tensor(rayhip_ctx *ctx, int which, float *dst, size_t capacity_floats, int out_dims[3]);
 

@@ -105,8 +105,12 @@ struct rayhip_ctx {
     // UNet denoiser (unet.h): per pass the repacked weights + bias, and the fifteen activation tensors of the current frame size
     struct UNetPass {
         DevBuf weights, bias;
+        DevBuf weights_h; // the f16 form (unet.h: ConvParamsH): [chunk of 32][tap][out channel][32], rows swizzled
         int n_tiles = 0;
     };
+    DevBuf unet_tensor_h[15], unet_images_h; // activation tensors of the f16 form
+    int unet_half = 0;                       // rayhip_unet_set_precision: 0 = the exact f32 form, 1 = f16 tensors / weights, f32 accumulate
+    int unet_h_w = 0, unet_h_h = 0;          // frame size the f16 tensors were sized for
     UNetPass unet_pass[16];
     DevBuf unet_tensor[15];
     DevBuf sky_desc, sky_transmittance_lut, sky_multiscatter_lut, sky_dir_lights, sky_weather, sky_noise3d, sky_curl, sky_moon, sky_cirrus; // the physical sky (rt_sky.h)
@@ -714,12 +718,17 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
     c->nee_index.release();
     for (auto &up : c->unet_pass) { // (the UNet's weights and its fifteen tensors -- 1.3 GB at 1080p -- were leaked)
         up.weights.release();
+        up.weights_h.release();
         up.bias.release();
     }
     for (DevBuf &b : c->unet_tensor) {
         b.release();
     }
+    for (DevBuf &b : c->unet_tensor_h) {
+        b.release();
+    }
     c->unet_images.release();
+    c->unet_images_h.release();
     for (DevBuf *b : {&c->sky_desc, &c->sky_transmittance_lut, &c->sky_multiscatter_lut, &c->sky_dir_lights, &c->sky_weather, &c->sky_noise3d, &c->sky_curl, &c->sky_moon,
                       &c->sky_cirrus, &c->sky_index}) {
         b->release();

@@ -117,12 +117,38 @@ int rayhip_unet_init(rayhip_ctx *c, const float *weights, int weights_count, con
                 }
             }
         }
+        // the f16 form's weights (unet.h: ConvParamsH): per input its own chunks of 32 channels (the last one of an odd multiple of 16 half
+        // empty), [chunk][tap][out channel (16 n_tiles)][32], the 16-byte units of every 64-byte row in the order the kernel's operand
+        // reads expect them (swizzle_h) -- the reference's fp16 backends convert the same blob (SetupUNetWeights<uint16_t>, RendererGPU.h:533-545)
+        using rt::unet::CHUNK_H;
+        const int ch1 = c1 ? (c1 + CHUNK_H - 1) / CHUNK_H : 0, c2_dev = d.b >= 0 ? d.b_ch : (d.img ? CHUNK : 0), ch2 = c2_dev ? (c2_dev + CHUNK_H - 1) / CHUNK_H : 0;
+        const int rows = 9 * n_tiles * 16;
+        std::vector<_Float16> wh(size_t(ch1 + ch2) * size_t(rows) * CHUNK_H, _Float16(0.0f));
+        for (int n = 0; n < d.cout; ++n) {
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3, L = tap * (n_tiles * 16) + n;
+                for (int cin = 0; cin < c1 + c2; ++cin) {
+                    float v;
+                    int chunk, k;
+                    if (cin < c1) {
+                        v = weights[w_off + int64_t(n) * per_out + ky * rt1 + kx * c1 + cin];
+                        chunk = cin / CHUNK_H, k = cin % CHUNK_H;
+                    } else {
+                        const int kk = cin - c1;
+                        v = weights[w_off + int64_t(n) * per_out + 3 * rt1 + ky * rt2 + kx * c2 + kk];
+                        chunk = ch1 + kk / CHUNK_H, k = kk % CHUNK_H;
+                    }
+                    wh[(size_t(chunk) * size_t(rows) + size_t(L)) * CHUNK_H + size_t(rt::unet::swizzle_h(n, k / 8) * 8 + k % 8)] = _Float16(v);
+                }
+            }
+        }
         if (upload(c, c->unet_pass[pass].weights, w.data(), w.size() * sizeof(float)) ||
-            upload(c, c->unet_pass[pass].bias, b.data(), b.size() * sizeof(float))) {
+            upload(c, c->unet_pass[pass].bias, b.data(), b.size() * sizeof(float)) ||
+            upload(c, c->unet_pass[pass].weights_h, wh.data(), wh.size() * sizeof(_Float16))) {
             return 1;
         }
         c->unet_pass[pass].n_tiles = n_tiles;
-        HIP_TRY(hipStreamSynchronize(c->stream)); // (w, b go out of scope)
+        HIP_TRY(hipStreamSynchronize(c->stream)); // (w, b, wh go out of scope)
     }
     c->unet_ready = true;
     return 0;
@@ -154,6 +180,31 @@ float *unet_interior(rayhip_ctx *c, const int t) {
     const int wr = round_up16(c->w);
     return c->unet_tensor[t].as<float>() + size_t(wr / UNET_TENSOR_DIV[t] + 3) * size_t(UNET_TENSOR_CH[t]);
 }
+// ... of the f16 form
+int unet_tensors_h(rayhip_ctx *c) {
+    if (c->unet_h_w == c->w && c->unet_h_h == c->h) {
+        return 0;
+    }
+    const int wr = round_up16(c->w), hr = round_up16(c->h);
+    c->unet_h_w = c->unet_h_h = 0;
+    for (int t = 0; t < 15; ++t) {
+        const size_t n = size_t(wr / UNET_TENSOR_DIV[t] + 2) * size_t(hr / UNET_TENSOR_DIV[t] + 2) * size_t(UNET_TENSOR_CH[t]);
+        c->unet_tensor_h[t].release(); // a fresh, zeroed allocation: the borders must be zero
+        if (c->unet_tensor_h[t].alloc(n * sizeof(uint16_t) + 64)) { // (+ 64: a 16-byte piece read of the last border pixel's upper channels stays inside)
+            return 1;
+        }
+    }
+    c->unet_images_h.release();
+    if (c->unet_images_h.alloc(size_t(wr + 2) * size_t(hr + 2) * size_t(rt::unet::CHUNK) * sizeof(uint16_t) + 64)) {
+        return 1;
+    }
+    c->unet_h_w = c->w, c->unet_h_h = c->h;
+    return 0;
+}
+uint16_t *unet_interior_h(rayhip_ctx *c, const int t) {
+    const int wr = round_up16(c->w);
+    return c->unet_tensor_h[t].as<uint16_t>() + size_t(wr / UNET_TENSOR_DIV[t] + 3) * size_t(UNET_TENSOR_CH[t]);
+}
 } // namespace
 
 int rayhip_denoise_unet(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4], int pass) {
@@ -178,11 +229,54 @@ int rayhip_denoise_unet(rayhip_ctx *c, const rayhip_camera *cam, const int rect[
     if (cam->view_transform != 0 && cam->view_transform != c->lut_transform) {
         return fail("view transform %d needs its look-up table: rayhip_set_tonemap_lut", int(cam->view_transform));
     }
-    if (unet_tensors(c)) {
+    if (c->unet_half ? unet_tensors_h(c) : unet_tensors(c)) {
         return 1;
     }
     const int wr = round_up16(c->w), hr = round_up16(c->h);
-    for (int p = (pass < 0 ? 0 : pass); p <= (pass < 0 ? 15 : pass); ++p) {
+    for (int p = (pass < 0 ? 0 : pass); c->unet_half && p <= (pass < 0 ? 15 : pass); ++p) { // the f16 form (unet.h: ConvParamsH): the same schedule
+        const UNetPassDesc &d = UNET_PASSES[p];
+        int rx = rect[0], ry = rect[1], rw = rect[2], rh = rect[3];
+        if (p < 15) {
+            rw = round_up16(rw), rh = round_up16(rh);
+        }
+        rx /= d.div, ry /= d.div, rw = (rw + d.div - 1) / d.div, rh = (rh + d.div - 1) / d.div;
+        rt::unet::ConvParamsH cp = {};
+        if (d.a >= 0) {
+            cp.a = unet_interior_h(c, d.a), cp.a_stride = wr / UNET_TENSOR_DIV[d.a] + 2, cp.a_ch = d.a_ch, cp.a_up = d.up;
+        }
+        if (d.b >= 0) {
+            cp.b = unet_interior_h(c, d.b), cp.b_stride = wr / UNET_TENSOR_DIV[d.b] + 2, cp.b_ch = d.b_ch;
+        }
+        if (d.img) {
+            uint16_t *img16 = c->unet_images_h.as<uint16_t>() + size_t(wr + 3) * size_t(rt::unet::CHUNK);
+            if (pass >= 0 || p == 0) { // (all passes in one call: the tensor pass 0 made is still there for dec_conv1a -- nothing in between touches the images)
+                HIP_TRY(rt::unet::launch_image_inputs_h(c->px.full, c->px.base_color, c->px.depth_normals, c->w, c->h, img16, wr + 2,
+                                                        grid_for(c, size_t(c->w) * size_t(c->h), 256), c->stream));
+            }
+            if (d.a >= 0) {
+                cp.b = img16, cp.b_stride = wr + 2, cp.b_ch = rt::unet::CHUNK;
+            } else {
+                cp.a = img16, cp.a_stride = wr + 2, cp.a_ch = rt::unet::CHUNK, cp.a_up = 0;
+            }
+        }
+        cp.weights = c->unet_pass[p].weights_h.p, cp.bias = c->unet_pass[p].bias.as<float>();
+        cp.x0 = rx, cp.y0 = ry, cp.w = rw, cp.h = rh;
+        cp.in_w = wr / d.div, cp.in_h = hr / d.div;
+        cp.pool = d.pool;
+        if (d.out >= 0) {
+            cp.out = unet_interior_h(c, d.out), cp.out_stride = wr / UNET_TENSOR_DIV[d.out] + 2, cp.out_ch = d.cout;
+        } else {
+            cp.out = c->px.raw, cp.out_stride = c->w, cp.out_ch = 3, cp.final_image = 1;
+        }
+        HIP_TRY(rt::unet::launch_conv_h(cp, c->unet_pass[p].n_tiles, c->stream));
+        if (p == 15) {
+            AccumParams tone = make_accum_params(*cam, c->w, rect, 1, c->shard);
+            tone.lut = c->tonemap_lut.as<uint32_t>(), tone.lut_dims = c->lut_dims;
+            k_tonemap_raw_rect<<<grid_for(c, size_t(rect[2]) * size_t(rect[3]), 256), 256, 0, c->stream>>>(tone, c->px);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    for (int p = (pass < 0 ? 0 : pass); !c->unet_half && p <= (pass < 0 ? 15 : pass); ++p) {
         const UNetPassDesc &d = UNET_PASSES[p];
         // the region of this pass in its own resolution (RendererCPU.h:797-802 and the head of every case)
         int rx = rect[0], ry = rect[1], rw = rect[2], rh = rect[3];
@@ -227,12 +321,20 @@ int rayhip_denoise_unet(rayhip_ctx *c, const rayhip_camera *cam, const int rect[
     return 0;
 }
 
+int rayhip_unet_set_precision(rayhip_ctx *c, int half) {
+    if (!c || (half != 0 && half != 1)) {
+        return fail("rayhip_unet_set_precision: 0 (f32, exact) or 1 (f16 tensors and weights, f32 accumulate)");
+    }
+    c->unet_half = half;
+    return 0;
+}
+
 // test hook: one activation tensor (0 .. 14, the order of unet_filter_tensors_t) with its border, NHWC; dims = {rows, columns, channels}
 int rayhip_unet_read_tensor(rayhip_ctx *c, int which, float *dst, size_t capacity_floats, int out_dims[3]) {
     if (use_device(c)) {
         return 1;
     }
-    if (which < 0 || which > 14 || c->unet_w != c->w || !c->unet_tensor[which].p) {
+    if (which < 0 || which > 14 || (c->unet_half ? (c->unet_h_w != c->w || !c->unet_tensor_h[which].p) : (c->unet_w != c->w || !c->unet_tensor[which].p))) {
         return fail("rayhip_unet_read_tensor: no such tensor (run rayhip_denoise_unet first)");
     }
     const int wr = round_up16(c->w), hr = round_up16(c->h);
@@ -240,6 +342,15 @@ int rayhip_unet_read_tensor(rayhip_ctx *c, int which, float *dst, size_t capacit
     const size_t n = size_t(out_dims[0]) * out_dims[1] * out_dims[2];
     if (n > capacity_floats) {
         return fail("rayhip_unet_read_tensor: %zu floats needed", n);
+    }
+    if (c->unet_half) { // the f16 form's tensor, widened on the host
+        std::vector<_Float16> h(n);
+        HIP_TRY(hipMemcpyAsync(h.data(), c->unet_tensor_h[which].p, n * sizeof(_Float16), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < n; ++i) {
+            dst[i] = float(h[i]);
+        }
+        return 0;
     }
     HIP_TRY(hipMemcpyAsync(dst, c->unet_tensor[which].p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -52,5 +52,37 @@ hipError_t launch_image_inputs(const float4 *full, const float4 *base, const flo
 // n_tiles = out channels / 16 rounded up (1 .. 7)
 hipError_t launch_conv(const ConvParams &p, int n_tiles, hipStream_t stream);
 
+// ---- the f16 form (round 5): f16 tensors and weights, f32 accumulators, v_mfma_f32_16x16x32_f16 ------------------------------------------
+// What the reference's own GPU backends run where the device has half-precision matrix hardware (internal/RendererVK.cpp:254-263, 1834-1844:
+// the convolution_*_fp16 / *_coop_16x16x16_CF16 shader sets; tensors and weights are 16-bit there too, RendererGPU.h:533-545, 569, 632).  The f32
+// form above stays the exact one (parity against the CPU oracle to 2e-5); this one is 12.8 x the matrix rate and half the tensor traffic, and is
+// held to an fp16-appropriate bound against the same oracle (tests/test_gpu_unet.py).
+constexpr int CHUNK_H = 32; // input channels staged through LDS at a time: one v_mfma_f32_16x16x32_f16 per (tap, chunk, 16 x 16 output tile)
+
+struct ConvParamsH {
+    const void *a; // f16 tensors (interior pointers), channel counts multiples of 16
+    int a_stride, a_ch, a_up;
+    const void *b;
+    int b_stride, b_ch;
+    const void *weights; // f16 [chunk of 32 in][tap][out channel (16 n_tiles)][32 in], the 16-byte units of a row swizzled as the kernel reads them (swizzle_h)
+    const float *bias;   // [16 n_tiles] f32
+    void *out;           // f16 tensor interior, or the float4 image of the last pass
+    int out_stride, out_ch;
+    int x0, y0, w, h, in_w, in_h, pool, final_image;
+};
+// position (in 16-byte units, 0 .. 3) of unit `u` (input channels 8 u .. 8 u + 7 of a 32-channel row) of the row in column `col` (a patch pixel's
+// column, or an out channel for the weights) in LDS.  Rows are 64 bytes, no padding; a lane's A or B operand is ONE ds_read_b128.  That
+// instruction serves its 64 lanes in four groups of 16 -- lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32
+// (MI355X_MICROARCH.md, LDS table) -- i.e. columns c, c + 12 with operand quarter kq and columns c + 4, c + 8 with quarter kq ^ 1 share four
+// 16-byte bank slots; u ^ 2 ((col >> 2) & 1) puts the four on different ones whatever c is (the only functions of (col >> 2) & 3 that do, by
+// enumeration), so the A reads of all three horizontal taps and the B reads are free of bank conflicts.  (First version: 8-byte pieces swizzled
+// for ds_read_b64's 2 x 32-lane service -- the compiler fused the pairs into ds_read2_b64, which is served 4 x 16 lanes on 32 banks: 44 % of
+// the LDS cycles were conflicts, profiles/r05/unet_f16_pmc_first_version.txt.)
+__host__ __device__ constexpr int swizzle_h(const int col, const int u) { return u ^ (((col >> 2) & 1) << 1); }
+
+hipError_t launch_image_inputs_h(const float4 *full, const float4 *base, const float4 *dn, int w, int h, void *out, int out_stride, int blocks,
+                                 hipStream_t stream);
+hipError_t launch_conv_h(const ConvParamsH &p, int n_tiles, hipStream_t stream);
+
 } // namespace unet
 } // namespace rt

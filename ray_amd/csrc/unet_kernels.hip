@@ -297,5 +297,280 @@ hipError_t launch_conv(const ConvParams &p, const int n_tiles, hipStream_t strea
     return hipGetLastError();
 }
 
+
+// ---- the f16 form (unet.h): the same tiling, v_mfma_f32_16x16x32_f16 ------------------------------------------------------------------------------
+// Workgroup = 4 wavefronts = a (4 ROWS) x 16 tile of output pixels x all output channels, K walked in chunks of 32 input channels: per tap and
+// chunk ONE matrix instruction per (pixel row, 16 output channels) where the f32 form issues four per 16 channels.
+//   A operand  lane l: pixel m = l & 15 of the row, input channels 8 (l >> 4) .. + 7 of the chunk   (8 halves = one 16-byte LDS read)
+//   B operand  lane l: out channel n = l & 15,      input channels 8 (l >> 4) .. + 7
+//   D          as the f32 form: out channel l & 15, pixels 4 (l >> 4) + 0 .. 3
+// (A and B distribute k over lanes and elements in the same way, so the sum over k does not depend on what that way is.)  LDS rows -- a patch
+// pixel's 32 channels, an output channel's 32 weights of one tap -- are 64 bytes, no padding; their 16-byte units are swizzled (unet.h:
+// swizzle_h) so that the operand reads (one ds_read_b128 each) are conflict-free.  The weights arrive from HBM already in that order (rayhip_unet_init), the patch is
+// swizzled by its stagers.  Channel counts that are odd multiples of 16 (the 16-channel image tensor, 48, 80, 112) leave the upper half of their
+// last chunk zero.  Staging is software-pipelined through registers like the f32 form's.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int ROWS> __global__ void __launch_bounds__(256, 2) k_conv3x3_h(const ConvParamsH p) {
+    constexpr int TILE_H = 4 * ROWS, PATCH_H = TILE_H + 2;
+    constexpr int P16 = PATCH_H * PATCH_W * 4, P16_PER_THREAD = (P16 + 255) / 256; // 16-byte pieces of a patch chunk (4 per pixel)
+    constexpr int W16 = 9 * NT * 16 * 4, W16_PER_THREAD = (W16 + 255) / 256;       // ... of a weight chunk (4 per (tap, out channel))
+    // LDS rows (a patch pixel's 32 channels; an out channel's 32 weights of a tap) are 64 bytes, their 16-byte units swizzled by the column
+    // (unet.h: swizzle_h): a lane's operand is one conflict-free ds_read_b128 whose address is (a per-lane value that depends on kx only) +
+    // (a compile-time offset for the row and the tap).
+    constexpr int PATCH_LDS_W = PATCH_W;
+    __shared__ __attribute__((aligned(16))) _Float16 s_patch[PATCH_H * PATCH_LDS_W * CHUNK_H];
+    __shared__ __attribute__((aligned(16))) _Float16 s_w[9 * NT * 16 * CHUNK_H];
+
+    const int tiles_x = (p.w + TILE_W - 1) / TILE_W;
+    const int tx0 = p.x0 + int(blockIdx.x % tiles_x) * TILE_W, ty0 = p.y0 + int(blockIdx.x / tiles_x) * TILE_H;
+    const int tid = int(threadIdx.x), lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int r0 = ROWS * wave;
+
+    // (the weights are the matrix instruction's A operand, the pixels its B operand: D = W^T x patch^T, so a lane ends up with FOUR CONSECUTIVE out
+    // channels 16 nt + 4 kq + 0 .. 3 of ONE pixel m of the row -- 8 contiguous bytes of the NHWC output, one store -- where the f32 form, pixels as A,
+    // holds four pixels of one channel and stores them one 2- or 4-byte element at a time: first version of this kernel, 64 store instructions and
+    // ~1000 instructions of address arithmetic per wavefront and tile, 40 % on top of the matrix phase)
+    f32x4 acc[ROWS][NT];
+    for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + nt * 16 + 4 * kq);
+        for (int r = 0; r < ROWS; ++r) {
+            acc[r][nt] = bias;
+        }
+    }
+    const int chunks_a = p.a ? (p.a_ch + CHUNK_H - 1) / CHUNK_H : 0, chunks_b = p.b ? (p.b_ch + CHUNK_H - 1) / CHUNK_H : 0;
+    const int n_chunks = chunks_a + chunks_b;
+
+    static_assert(P16_PER_THREAD <= 8, "piece indices are kept in 8-wide native vectors");
+    i32x8 piece_a = {0, 0, 0, 0, 0, 0, 0, 0}, piece_b = piece_a;
+    uint32_t inside = 0;
+#pragma unroll
+    for (int j = 0; j < P16_PER_THREAD; ++j) {
+        const int e = tid + 256 * j, pixel = e >> 2;
+        const int px = pixel % PATCH_W, py = pixel / PATCH_W;
+        const int X = tx0 - 1 + px, Y = ty0 - 1 + py;
+        const bool in = e < P16 && X >= -1 && X <= p.in_w && Y >= -1 && Y <= p.in_h;
+        inside |= in ? (1u << j) : 0u;
+        const int sx = p.a_up ? (X >> 1) : X, sy = p.a_up ? (Y >> 1) : Y;
+        piece_a[j] = in ? sy * p.a_stride + sx : 0;
+        piece_b[j] = in ? Y * p.b_stride + X : 0;
+    }
+    const int q = tid & 3; // (256 is a multiple of 4: every piece of a thread is the same quarter of its pixel's 32 channels)
+
+    h8 held_patch[P16_PER_THREAD], held_w[W16_PER_THREAD];
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool held_have = false; // the chunk in the registers has channels for this thread's quarter (the upper half of a last, 16-channel chunk is zero)
+    // chunk `ch` -> registers.  Every load is UNCONDITIONAL and from a valid address (a piece outside the tensor reads pixel 0, a quarter past the
+    // tensor's channels the neighbouring pixel's: the allocations carry 64 bytes of slack); what must be zero is zeroed at commit time.  (A load
+    // under `if (inside)` merges with the zero at the end of the branch, and the compiler waits for it THERE: six serialized round trips per
+    // chunk and thread -- the wavefronts of the first version were parked in s_waitcnt 53 % of their time.)
+    auto fetch = [&](const int ch) __attribute__((always_inline)) {
+        const bool from_a = ch < chunks_a;
+        const int n_ch = from_a ? p.a_ch : p.b_ch;
+        const int c0 = (from_a ? ch : ch - chunks_a) * CHUNK_H + 8 * q; // first channel of this thread's pieces
+        const _Float16 *src = static_cast<const _Float16 *>(from_a ? p.a : p.b) + c0;
+        held_have = c0 < n_ch;
+#pragma unroll
+        for (int j = 0; j < P16_PER_THREAD; ++j) {
+            held_patch[j] = *reinterpret_cast<const h8 *>(src + ptrdiff_t(from_a ? piece_a[j] : piece_b[j]) * n_ch);
+        }
+        const h8 *wsrc = reinterpret_cast<const h8 *>(static_cast<const _Float16 *>(p.weights) + size_t(ch) * size_t(9 * NT * 16 * CHUNK_H));
+#pragma unroll
+        for (int j = 0; j < W16_PER_THREAD; ++j) {
+            const int i = tid + 256 * j;
+            held_w[j] = wsrc[(W16 % 256 == 0 || i < W16) ? i : W16 - 1];
+        }
+    };
+    // where this thread's patch pieces go in LDS (fixed over the chunks): unit q of the pixel in column `col` -> unit swizzle_h(col, q)
+    i32x8 patch_dst = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < P16_PER_THREAD; ++j) {
+        const int e = tid + 256 * j, pixel = e >> 2, col = pixel % PATCH_W, row = pixel / PATCH_W;
+        patch_dst[j] = (row * PATCH_LDS_W + col) * CHUNK_H + swizzle_h(col, q) * 8;
+    }
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < P16_PER_THREAD; ++j) {
+            const int e = tid + 256 * j;
+            if (P16 % 256 == 0 || e < P16) {
+                *reinterpret_cast<h8 *>(&s_patch[patch_dst[j]]) = (held_have && ((inside >> j) & 1u)) ? held_patch[j] : zero8;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < W16_PER_THREAD; ++j) {
+            const int i = tid + 256 * j;
+            if (W16 % 256 == 0 || i < W16) {
+                reinterpret_cast<h8 *>(s_w)[i] = held_w[j];
+            }
+        }
+    };
+    // a lane's operand = unit kq of a row: per-lane bases (A: one per kx, the wavefront's first row folded in; B: one), everything else of the
+    // address is a compile-time offset
+    const _Float16 *a_base[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int col = m + kx;
+        a_base[kx] = s_patch + (r0 * PATCH_LDS_W + col) * CHUNK_H + swizzle_h(col, kq) * 8;
+    }
+    const _Float16 *b_base = s_w + m * CHUNK_H + swizzle_h(m, kq) * 8;
+    fetch(0);
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (ch + 1 < n_chunks) {
+            fetch(ch + 1);
+        }
+        // nine taps of ROWS x NT matrix instructions each.  The operands of tap t + 1 are requested from LDS BEFORE the matrix instructions of tap t
+        // are issued and waited for after them (left alone, the compiler put every ds_read a few instructions in front of its use: an LDS round
+        // trip per four or five matrix instructions); the scheduling barriers pin that order.
+        h8 a_now[ROWS], b_now[NT], a_next[ROWS], b_next[NT];
+        auto operands = [&](const int tap, h8 (&a)[ROWS], h8 (&b)[NT]) __attribute__((always_inline)) {
+            constexpr int ROW_HALVES = PATCH_LDS_W * CHUNK_H;
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                a[r] = *reinterpret_cast<const h8 *>(a_base[kx] + (r + ky) * ROW_HALVES);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                b[nt] = *reinterpret_cast<const h8 *>(b_base + (tap * (NT * 16) + nt * 16) * CHUNK_H);
+            }
+        };
+        operands(0, a_now, b_now);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
+                operands(tap + 1, a_next, b_next);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b_now[nt], a_now[r], acc[r][nt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                a_now[r] = a_next[r];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                b_now[nt] = b_next[nt];
+            }
+        }
+    }
+
+    // ---- epilogue: lane (m, kq) holds out channels 16 nt + 4 kq + 0 .. 3 of pixel x = tx0 + m in rows ty0 + r0 .. + ROWS - 1
+    const int xe = p.x0 + p.w, ye = p.y0 + p.h;
+    const int x = tx0 + m;
+    if (p.final_image) { // 3 channels through the inverse HDR transfer into the float4 image (alpha stays): lanes kq = 0 of tile 0
+        if (kq == 0 && x < xe) {
+            float *out_f = static_cast<float *>(p.out);
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int y = ty0 + r0 + rr;
+                if (y < ye) {
+                    float *o = out_f + (ptrdiff_t(y) * p.out_stride + x) * 4;
+                    o[0] = transfer_out_hdr(fmaxf(0.0f, acc[rr][0][0])), o[1] = transfer_out_hdr(fmaxf(0.0f, acc[rr][0][1]));
+                    o[2] = transfer_out_hdr(fmaxf(0.0f, acc[rr][0][2]));
+                }
+            }
+        }
+        return;
+    }
+    _Float16 *out_h = static_cast<_Float16 *>(p.out);
+    if (p.pool) { // 2 x 2 max over rows (rp, rp + 1) -- this lane's registers -- and pixels (m, m ^ 1) -- the neighbouring lane; even m writes
+#pragma unroll
+        for (int rp = 0; rp < ROWS; rp += 2) {
+            const int y = ty0 + r0 + rp;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                h4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float mine = fmaxf(fmaxf(acc[rp][nt][i], 0.0f), fmaxf(acc[rp + 1][nt][i], 0.0f));
+                    v[i] = _Float16(fmaxf(mine, __shfl_xor(mine, 1)));
+                }
+                if ((m & 1) == 0 && x < xe && y < ye && nt * 16 < p.out_ch) {
+                    *reinterpret_cast<h4 *>(out_h + (ptrdiff_t(y / 2) * p.out_stride + (x / 2)) * p.out_ch + nt * 16 + 4 * kq) = v;
+                }
+            }
+        }
+    } else if (x < xe) {
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int y = ty0 + r0 + rr;
+            if (y >= ye) {
+                continue;
+            }
+            _Float16 *o = out_h + (ptrdiff_t(y) * p.out_stride + x) * p.out_ch + 4 * kq;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt * 16 < p.out_ch) {
+                    *reinterpret_cast<h4 *>(o + nt * 16) = h4{_Float16(fmaxf(0.0f, acc[rr][nt][0])), _Float16(fmaxf(0.0f, acc[rr][nt][1])),
+                                                             _Float16(fmaxf(0.0f, acc[rr][nt][2])), _Float16(fmaxf(0.0f, acc[rr][nt][3]))};
+                }
+            }
+        }
+    }
+}
+
+// the renderer's three images as one 16-channel f16 tensor (k_image_inputs above, halves)
+__global__ void __launch_bounds__(256) k_image_inputs_h(const float4 *__restrict__ full, const float4 *__restrict__ base, const float4 *__restrict__ dn,
+                                                       const int w, const int h, _Float16 *__restrict__ out, const int out_stride) {
+    const int n = w * h;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int x = i % w, y = i / w;
+        const float4 a = full[i], b = base[i], c = dn[i];
+        h8 *o = reinterpret_cast<h8 *>(out + (ptrdiff_t(y) * out_stride + x) * CHUNK);
+        o[0] = h8{_Float16(transfer_in_hdr(a.x)), _Float16(transfer_in_hdr(a.y)), _Float16(transfer_in_hdr(a.z)), _Float16(b.x),
+                  _Float16(b.y), _Float16(b.z), _Float16(0.5f * c.x + 0.5f), _Float16(0.5f * c.y + 0.5f)};
+        o[1] = h8{_Float16(0.5f * c.z + 0.5f), 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+hipError_t launch_image_inputs_h(const float4 *full, const float4 *base, const float4 *dn, const int w, const int h, void *out, const int out_stride,
+                                 const int blocks, hipStream_t stream) {
+    k_image_inputs_h<<<blocks, 256, 0, stream>>>(full, base, dn, w, h, static_cast<_Float16 *>(out), out_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_h(const ConvParamsH &p, const int n_tiles, hipStream_t stream) {
+    if (n_tiles < 1 || n_tiles > 7 || p.w <= 0 || p.h <= 0) {
+        return n_tiles < 1 || n_tiles > 7 ? hipErrorInvalidValue : hipSuccess;
+    }
+    const int rows = n_tiles <= 4 ? 4 : 2, tile_h = 4 * rows;
+    const int tiles = ((p.w + TILE_W - 1) / TILE_W) * ((p.h + tile_h - 1) / tile_h);
+    switch (n_tiles) {
+    case 1:
+        k_conv3x3_h<1, 4><<<tiles, 256, 0, stream>>>(p);
+        break;
+    case 2:
+        k_conv3x3_h<2, 4><<<tiles, 256, 0, stream>>>(p);
+        break;
+    case 3:
+        k_conv3x3_h<3, 4><<<tiles, 256, 0, stream>>>(p);
+        break;
+    case 4:
+        k_conv3x3_h<4, 4><<<tiles, 256, 0, stream>>>(p);
+        break;
+    case 5:
+        k_conv3x3_h<5, 2><<<tiles, 256, 0, stream>>>(p);
+        break;
+    case 6:
+        k_conv3x3_h<6, 2><<<tiles, 256, 0, stream>>>(p);
+        break;
+    default:
+        k_conv3x3_h<7, 2><<<tiles, 256, 0, stream>>>(p);
+        break;
+    }
+    return hipGetLastError();
+}
+
 } // namespace unet
 } // namespace rt

@@ -80,7 +80,7 @@ ENTRY_POINTS = (
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand", "k_shade",
     "comm_create", "comm_unique_id", "comm_create_rank", "comm_bind", "comm_reduce_framebuffers", "comm_destroy",
-    "unet_init", "denoise_unet", "unet_read_tensor",
+    "unet_init", "denoise_unet", "unet_set_precision", "unet_read_tensor",
     "export_shard_device", "owned_bytes", "export_owned", "import_owned", "finish_import",
 )
 
@@ -140,6 +140,7 @@ class Library:
             f("unet_init").argtypes = [vp, vp, C.c_int, vp, C.c_int]
             f("denoise_unet").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int]
             f("unet_read_tensor").argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_int * 3)]
+            f("unet_set_precision").argtypes = [vp, C.c_int]
             f("readback_device").argtypes = [vp, C.c_int, vp, C.c_int]
             f("set_raw_device").argtypes = [vp, vp, C.c_int, C.POINTER(Camera)]
             f("export_shard_device").argtypes = [vp, C.c_int, vp]
@@ -312,6 +313,10 @@ class Context:
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
         assert offsets.size == 32
         self.L.check(self.L.fn("unet_init")(self._ctx, weights.ctypes.data, weights.size, offsets.ctypes.data, alignment))
+
+    def unet_precision(self, half: bool):
+        """False: the exact f32 form (default); True: f16 tensors / weights with f32 accumulators (what the reference's GPU backends run)"""
+        self.L.check(self.L.fn("unet_set_precision")(self._ctx, int(bool(half))))
 
     def denoise_unet(self, pass_index: int = -1, rect=None, cam: Camera = None):
         r = (C.c_int * 4)(*((0, 0, self.w, self.h) if rect is None else rect))

@@ -508,6 +508,10 @@ class Renderer final : public RendererBase {
         SetupUNetWeights(8, &offsets, weights.data());
         static_assert(sizeof(offsets) == 32 * sizeof(int32_t), "unet_weight_offsets_t is 32 ints");
         check(rayhip_unet_init(ctx_, weights.data(), int(weights.size()), reinterpret_cast<const int32_t *>(&offsets), 8), "rayhip_unet_init");
+        // half precision where the device has the matrix hardware for it -- every gfx950 has -- as the reference's GPU backends choose
+        // (RendererVK.cpp:254-263, 1834-1844: use_fp16_ / use_coop_matrix_ select the fp16 shader set); RAY_HIP_UNET_F32=1 keeps the exact f32 form
+        const char *f32 = getenv("RAY_HIP_UNET_F32");
+        check(rayhip_unet_set_precision(ctx_, (f32 && f32[0] == '1') ? 0 : 1), "rayhip_unet_set_precision");
         unet_ready_ = true;
         unet_filter_properties_t props;
         props.pass_count = UNetFilterPasses;

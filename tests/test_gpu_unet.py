@@ -85,12 +85,17 @@ def test_all_passes_in_one_call_and_a_second_frame_size():
     assert (np.abs(got[..., :3] - ref[..., :3]) / np.maximum(1.0, np.abs(ref[..., :3]))).max() <= 5 * TOL
 
 
-def test_renderer_hip_unet_through_the_ray_api():
+@pytest.mark.parametrize("f32", [True, False])
+def test_renderer_hip_unet_through_the_ray_api(f32, monkeypatch):
     """InitUNetFilter + DenoiseImage(pass, region) x 16 behind the Ray API, against the Reference renderer doing the same on
-    ITS frame (the two frames differ in the last bits, and the random network amplifies that: a looser bar)"""
+    ITS frame (the two frames differ in the last bits, and the random network amplifies that: a looser bar).  RendererHIP runs the
+    f16 form by default, as the reference's GPU backends do on hardware with half-precision matrix arithmetic; RAY_HIP_UNET_F32=1
+    keeps the exact form."""
     import os
     if not os.path.exists(api.HIP_HOST_LIB):
         pytest.fail("ray_amd/host/_build/libray_hip.so is missing")
+    if f32:
+        monkeypatch.setenv("RAY_HIP_UNET_F32", "1")
     w, h, spp = 96, 64, 4
     ref, rs = O.render_ref(scenes.cornell_lights, w, h, spp)
     assert ref.InitUNetFilter() == 16
@@ -107,10 +112,14 @@ def test_renderer_hip_unet_through_the_ray_api():
         ref.DenoiseImageUNet(p, ref_region)
     a, b = r.get_raw_pixels_ref(), ref.get_raw_pixels_ref()
     err = np.abs(a[..., :3] - b[..., :3]) / np.maximum(1.0, np.abs(b[..., :3]))
-    print("RendererHIP UNet vs RendererRef UNet:", float(err.max()), float(err.mean()))
-    assert err.max() <= 2e-2 and err.mean() <= 1e-4
+    print(f"RendererHIP UNet ({'f32' if f32 else 'f16'} form) vs RendererRef UNet:", float(err.max()), float(err.mean()))
+    if f32:
+        assert err.max() <= 2e-2 and err.mean() <= 1e-4
+    else:
+        assert err.max() <= 1e-1 and err.mean() <= 2e-3
     m = util.frame_metrics(r.get_pixels_ref(), ref.get_pixels_ref())
-    assert m["frac_within"] >= 0.99, m
+    print("tone-mapped image:", m)
+    assert (m["frac_within"] >= 0.99) if f32 else (m["psnr"] >= 45.0), m  # (a half resolves 1e-3 of its value: the 1e-3 band is the f32 form's bar)
 
 
 def test_unet_time_at_1080p():
@@ -127,3 +136,84 @@ def test_unet_time_at_1080p():
     flops = 2 * 125406 * 1920 * 1080  # multiply-adds per pixel of the sixteen convolutions x 2
     print(f"UNet 1080p: {ms:.2f} ms per frame, {flops / ms / 1e9:.1f} TFLOP/s (f32 matrix peak 157)")
     assert ms < 100.0
+
+
+# ---- the f16 form (rayhip_unet_set_precision(1): f16 tensors and weights, f32 accumulators, v_mfma_f32_16x16x32_f16) ------------------------------
+# Bound: a half has 11 significant bits (unit round-off 4.9e-4).  Every pass rounds its inputs (the previous pass's outputs) and its weights to
+# halves -- the generated stand-in weights ARE halves, so only the activations lose bits -- and accumulates 144 .. 1440 products in f32; the errors
+# of a pass feed the next one, fifteen deep.  Stated per tensor as  max |got - ref| <= F16_TOL * max(1, max |ref|)  (relative to the tensor's
+# scale: a half cannot resolve an activation of 1e-3 next to one of 30 any better) and as a mean relative error; the final image additionally as
+# PSNR against the f32 form's image.
+F16_TOL = 4e-3
+F16_MEAN_TOL = 2e-3
+
+
+@pytest.mark.parametrize("w,h", [(200, 136), (64, 48)])
+def test_f16_form_every_pass_within_a_half_precision_bound(w, h):
+    ctx = _ctx(w, h)
+    full, base, dn = ctx.readback(hip.BUF_RAW), ctx.readback(hip.BUF_BASE_COLOR), ctx.readback(hip.BUF_DEPTH_NORMALS)
+    ctx.unet_precision(True)
+    lines, bad = [], False
+    for p in range(15):
+        ctx.denoise_unet(p)
+        got = ctx.unet_read_tensor(OUT_TENSOR[p])
+        ref = O.ref_unet_passes(full, base, dn, p)
+        assert got.shape == ref.shape, (p, got.shape, ref.shape)
+        scale = max(1.0, float(np.abs(ref).max()))
+        worst, mean = float(np.abs(got - ref).max()) / scale, float(np.abs(got - ref).mean()) / max(float(np.abs(ref).mean()), 1e-12)
+        lines.append(f"pass {p:2d}: max |ref| {float(np.abs(ref).max()):9.3f}  max err / scale {worst:.2e}  mean err / mean |ref| {mean:.2e}")
+        assert np.isfinite(got).all(), p
+        bad = bad or not (worst <= F16_TOL and mean <= F16_MEAN_TOL)
+        assert not got[0].any() and not got[-1].any() and not got[:, 0].any() and not got[:, -1].any(), p
+    ctx.denoise_unet(15)
+    got = ctx.readback(hip.BUF_RAW)
+    ref = O.ref_unet_passes(full, base, dn, 15)
+    err = np.abs(got[..., :3] - ref[..., :3]) / np.maximum(1.0, np.abs(ref[..., :3]))
+    print("\n".join(lines))
+    assert not bad, "\n".join(lines)
+    print(f"{w}x{h} f16 form: filtered image max rel err {err.max():.2e}, mean {err.mean():.2e}")
+    assert err.max() <= 1e-1 and err.mean() <= 2e-3  # (the inverse HDR transfer is an exponential: it stretches what the last tensor lost)
+    assert np.array_equal(got[..., 3], full[..., 3])
+    # against the exact form on the same frame: PSNR of the tone-mapped image
+    final_h = ctx.readback(hip.BUF_FINAL)
+    ctx.unet_precision(False)
+    ctx.denoise_unet(-1)  # (pass 0 reads `full`, which the last pass left alone: RAW is the output, the running mean the input)
+    m = util.frame_metrics(final_h, ctx.readback(hip.BUF_FINAL))
+    print(f"{w}x{h}: f16 form against the f32 form, FINAL image: PSNR {m['psnr']:.1f} dB, within tolerance {m['frac_within']:.4f}")
+    assert m["psnr"] >= 50.0, m
+
+
+def test_f16_form_all_passes_in_one_call_rects_and_switching_back():
+    ctx = _ctx(200, 136)
+    full, base, dn = ctx.readback(hip.BUF_RAW), ctx.readback(hip.BUF_BASE_COLOR), ctx.readback(hip.BUF_DEPTH_NORMALS)
+    ref = O.ref_unet_passes(full, base, dn, 15)
+    ctx.unet_precision(True)
+    ctx.denoise_unet(-1)
+    got_h = ctx.readback(hip.BUF_RAW)
+    assert (np.abs(got_h[..., :3] - ref[..., :3]) / np.maximum(1.0, np.abs(ref[..., :3]))).max() <= 1e-1  # (the inverse HDR transfer is an exponential)
+    ctx.unet_precision(False)  # the exact form is still exact after the f16 tensors have been in use
+    ctx.denoise_unet(-1)
+    got = ctx.readback(hip.BUF_RAW)
+    assert (np.abs(got[..., :3] - ref[..., :3]) / np.maximum(1.0, np.abs(ref[..., :3]))).max() <= 5 * TOL
+    assert not np.array_equal(got, got_h)
+
+
+def test_f16_unet_time_at_1080p():
+    """the f16 form's sixteen passes on a 1920 x 1080 frame (task 6: <= 1.0 ms asked for; the ceiling here is generous,
+    the number is printed and profiled under profiles/r05/)"""
+    ctx = _ctx(1920, 1080, spp=1)
+    out = {}
+    for half in (False, True):
+        ctx.unet_precision(half)
+        ctx.denoise_unet(-1)
+        ctx.sync()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            ctx.denoise_unet(-1)
+        ctx.sync()
+        out[half] = (time.perf_counter() - t0) / n * 1e3
+    flops = 2 * 125406 * 1920 * 1080
+    print(f"UNet 1080p: f32 form {out[False]:.2f} ms ({flops / out[False] / 1e9:.1f} TFLOP/s), f16 form {out[True]:.2f} ms "
+          f"({flops / out[True] / 1e9:.1f} TFLOP/s of the network's own arithmetic)")
+    assert out[True] < out[False]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The sixteen UNet passes on a 1920 x 1080 frame, N times (for rocprofv3: per-pass kernel times, matrix-core busy cycles).
-    python tools/unet_bench.py [n]"""
+    python tools/unet_bench.py [n] [f32|f16]"""
 import os
 import sys
 import time
@@ -19,6 +19,8 @@ ctx = util.make_context(hip.Library(), "cornell_lights", 1920, 1080)
 ctx.render_batch(1, 1)
 weights, offsets = O.ref_unet_weights()
 ctx.unet_init(weights, offsets, 8)
+half = len(sys.argv) > 2 and sys.argv[2] == "f16"
+ctx.unet_precision(half)
 ctx.denoise_unet(-1)
 ctx.sync()
 t0 = time.perf_counter()
@@ -27,4 +29,6 @@ for _ in range(n):
 ctx.sync()
 ms = (time.perf_counter() - t0) / n * 1e3
 flops = 2 * 125406 * 1920 * 1080
-print(f"UNet 1080p: {ms:.2f} ms per frame, {flops / ms / 1e9:.1f} TFLOP/s = {100 * flops / ms / 1e9 / 157:.1f} % of the f32 matrix peak (157)")
+peak = 2500.0 if half else 157.0
+print(f"UNet 1080p, {'f16' if half else 'f32'} form: {ms:.2f} ms per frame, {flops / ms / 1e9:.1f} TFLOP/s = {100 * flops / ms / 1e9 / peak:.1f} % of the "
+      f"{'f16' if half else 'f32'} matrix peak ({peak:.0f})")
