@@ -467,6 +467,16 @@ RAYHIP_API int rayhip_readback_device(rayhip_ctx *ctx, int which, void *dst_devi
 RAYHIP_API int rayhip_set_raw_device(rayhip_ctx *ctx, const void *src_device_rgba, int pitch_px,
                                      const rayhip_camera *cam);
 
+/* The sky environment map of a physical-sky scene baked ON THE DEVICE: what Scene::PrepareSkyEnvMap_nolock produces on the host
+ * (internal/SceneCPU.cpp:1017-1056 over CalcSkyEnvTexture, SceneCommon.cpp:286-361; the reference's GPU scene runs it as a compute pass,
+ * SceneGPU.h:1697-1768).  `desc`: only its sky members (sky, the two tables, the five textures, sky_dir_lights, env.sky_map_spread_angle > 0)
+ * and `lights` are read; `out_rgbe8`: w * h texels, shared-exponent RGBE bytes as the reference's RGBA8 texture storage takes them.  The scene
+ * that is on the device is not touched.  SceneHIP::Finalize calls it when the scene belongs to a renderer (a scene built without one bakes on
+ * the host). */
+RAYHIP_API int rayhip_bake_sky(rayhip_ctx *ctx, const rayhip_scene_desc *desc, int w, int h, uint32_t *out_rgbe8);
+/* the same from a serialised scene (ray_amd/csrc/scene_blob.h) */
+RAYHIP_API int rayhip_bake_sky_blob(rayhip_ctx *ctx, const void *blob, size_t blob_size, int w, int h, uint32_t *out_rgbe8);
+
 /* ---- UNet denoiser (RendererBase::InitUNetFilter + DenoiseImage(int pass, const RegionContext &), RendererBase.h:199-227;
  * reference implementation RendererCPU.h:790-1007, 1261-1310 over internal/Convolution.h; GPU twin shaders/convolution.comp.glsl) ----
  * Sixteen 3 x 3 convolution passes of OIDN's UNet over (running mean, base colour, depth-normals), each one implicit GEMM on

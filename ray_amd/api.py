@@ -252,6 +252,12 @@ class SceneBase:
     def node_count(self) -> int:
         return int(self._lib.ray_scene_node_count(self._ptr))
 
+    def sky_bake_info(self) -> str:
+        """SceneHIP only: where the last Finalize baked the sky environment map -- "device", "host" or "none" (Ray::Hip::SkyBakedOn)"""
+        f = self._lib.ray_hip_sky_baked_on
+        f.restype, f.argtypes = C.c_char_p, [C.c_void_p]
+        return f(self._ptr).decode()
+
 
 @dataclass
 class ShadingNode:  # Ray::shading_node_desc_t (only the fields set here override the C++ defaults)

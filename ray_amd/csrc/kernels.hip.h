@@ -645,6 +645,15 @@ __global__ void __launch_bounds__(256) k_fill_tri_verts(const rayhip_vertex *__r
     }
 }
 
+// The baked sky map on the device (rt_sky.h: sky_bake_texel; the reference's GPU scene does the same in a compute pass, SceneGPU.h:1697-1768): one
+// thread per texel -- a texel is a view-ray integral through air, the cloud layer (48 steps with a 24-step shadow march each) and cirrus per light.
+__global__ void __launch_bounds__(64) k_bake_sky(const SkyView sky, const rayhip_light *__restrict__ lights, const int w, const int h, uint32_t *__restrict__ out) {
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < w * h) {
+        out[i] = sky_bake_texel(sky, lights, i % w, i / w, w, h);
+    }
+}
+
 // Fill of every queue of a pass (sum over the stripe counters), one wavefront per queue: what the next pass sizes its launches from
 // (rayhip_render.hip.h: queue census).  `out` is host memory the device writes directly.
 __global__ void __launch_bounds__(WAVE) k_queue_totals(const uint32_t *__restrict__ counters, uint32_t *__restrict__ out) {

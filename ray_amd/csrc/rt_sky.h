@@ -489,6 +489,52 @@ RT_HD f4 sky_radiance_for_light(const SkyView &s, f4 start, const f4 dir, float 
     return radiance;
 }
 
+// ---- one texel of the BAKED sky map (CalcSkyEnvTexture, SceneCommon.cpp:286-361; the reference's GPU scene runs the same per texel in a
+// compute pass, SceneGPU.h:1697-1768): latitude-longitude direction of texel (x, y), the view-ray integral above summed over the directional
+// lights (a light narrower than SKY_SUN_MIN_ANGLE is widened to it, its disk radiance rescaled), shared-exponent 8-bit encoding (rgb_to_rgbe,
+// SceneCommon.cpp:7-17).  Same operations in the same order as the reference's host loop: the host build of this function is compared with the
+// reference's baked map byte for byte (tests/test_sky_bake.py).
+RT_HD uint32_t sky_rgbe8(const f4 rgb) {
+    const float max_component = fmaxf(fmaxf(rgb.x, rgb.y), rgb.z);
+    if (max_component < 1e-32) {
+        return 0u;
+    }
+    int exponent;
+    const float factor = frexpf(max_component, &exponent) * 256.0f / max_component;
+    const f4 e = {rgb.x * factor, rgb.y * factor, rgb.z * factor, float(exponent + 128)};
+    return uint32_t(uint8_t(e.x)) | (uint32_t(uint8_t(e.y)) << 8) | (uint32_t(uint8_t(e.z)) << 16) | (uint32_t(uint8_t(e.w)) << 24);
+}
+RT_HD uint32_t sky_bake_texel(const SkyView &s, const rayhip_light *lights, const int x, const int y, const int w, const int h) {
+    const rayhip_atmosphere &at = s.desc->atmosphere;
+    const float theta = PI * float(y) / float(h);
+    const uint32_t px_hash = hash(uint32_t((x << 16) | y));
+    const float phi = 2.0f * PI * (float(x) + 0.5f) / float(w);
+    const f2 sincos_theta = portable_sincos(theta), sincos_phi = portable_sincos(phi);
+    const f4 dir = {sincos_theta.x * sincos_phi.y, sincos_theta.y, sincos_theta.x * sincos_phi.x, 0.0f};
+    const f4 eye = {0.0f, at.viewpoint_height, 0.0f, 0.0f};
+    f4 color = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (s.dir_lights_count != 0) {
+        for (uint32_t k = 0; k < s.dir_lights_count; ++k) {
+            const rayhip_light &l = lights[s.dir_lights[k]];
+            const f4 light_dir = {l.params[0], l.params[1], l.params[2], 0.0f};
+            f4 light_col = {l.col[0], l.col[1], l.col[2], 0.0f}, point_col = light_col;
+            if (l.params[4] != 0.0f) {
+                const float radius = l.params[4];
+                point_col *= (PI * radius * radius);
+            }
+            if (l.params[5] < SKY_SUN_MIN_ANGLE) {
+                const float div = PI * tanf(SKY_SUN_MIN_ANGLE) * tanf(SKY_SUN_MIN_ANGLE);
+                light_col = point_col / div;
+            }
+            color += sky_radiance_for_light(s, eye, dir, MAX_DIST, light_dir, l.params[5], light_col, point_col, px_hash);
+        }
+    } else if (at.stars_brightness > 0.0f) { // no sun: a stand-in below the horizon lights the moon
+        const f4 light_dir = {0.0f, -1.0f, 0.0f, 0.0f}, light_col = {144809.859f, 129443.617f, 127098.89f, 0.0f};
+        color += sky_radiance_for_light(s, eye, dir, MAX_DIST, light_dir, 0.0f, light_col, light_col, px_hash);
+    }
+    return sky_rgbe8(color);
+}
+
 // ---- what a deferred ray adds to its pixel (ShadeSky, AtmosphereRef.cpp:928-1010) ---------------------------------------------------
 // `iteration`: the RenderScene iteration (the sky's random offsets are keyed by hash(iteration), not by the pass's rand_seed);
 // `limit`: 3 x the direct / indirect clamp of the bounce, FLT_MAX without one

@@ -76,7 +76,7 @@ assert RAY_DTYPE.itemsize == 72 and SHADOW_RAY_DTYPE.itemsize == 48 and HIT_DTYP
 # every symbol include/rayhip.h declares (tests check that the built library exports all of them)
 ENTRY_POINTS = (
     "last_error", "abi_version", "device_count", "ctx_create", "ctx_destroy", "ctx_device_name", "upload_static", "resize", "clear",
-    "scene_upload", "scene_bvh_width", "closest_hit_form", "scene_upload_blob", "scene_update_instances", "scene_update_instances_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
+    "scene_upload", "bake_sky", "bake_sky_blob", "scene_bvh_width", "closest_hit_form", "scene_upload_blob", "scene_update_instances", "scene_update_instances_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand", "k_shade",
     "comm_create", "comm_unique_id", "comm_create_rank", "comm_bind", "comm_reduce_framebuffers", "comm_destroy",
@@ -111,6 +111,11 @@ class Library:
         f("clear").argtypes = [vp, C.POINTER(C.c_float * 4)]
         f("scene_upload_blob").argtypes = [vp, vp, C.c_size_t, C.POINTER(Camera)]
         f("set_filter_table").argtypes = [vp, vp, C.c_int]
+        if prefix == "rayhip_":
+            f("bake_sky_blob").argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
+        else:
+            f("bake_sky").argtypes = [vp, C.c_int, C.c_int, vp]
+            f("env_map_texels").argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_int * 2)]
         f("render").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_uint32, C.POINTER(Stats)]
         f("render_batch").argtypes = [vp, C.POINTER(Camera), C.POINTER(C.c_int * 4), C.c_int, C.c_int, C.c_uint32, C.POINTER(Stats)]
         f("max_batch").argtypes = [vp]
@@ -214,6 +219,24 @@ class Context:
         self.L.check(self.L.fn("scene_upload_blob")(self._ctx, self._blob.ctypes.data, self._blob.size, C.byref(cam)))
         self.cam = cam
         return cam
+
+    def bake_sky(self, w: int, h: int, blob: bytes = None) -> np.ndarray:
+        """the sky environment map ([h, w, 4] uint8: shared-exponent RGBE) of a physical-sky scene: on the device from `blob` (default: the blob
+        this context uploaded last) -- rayhip_bake_sky_blob; with the host build of the kernels, from the uploaded scene"""
+        out = np.zeros((h, w), dtype=np.uint32)
+        if self.L.prefix == "rayhip_":
+            b = self._blob if blob is None else _aligned_copy(blob)
+            self.L.check(self.L.fn("bake_sky_blob")(self._ctx, b.ctypes.data, b.size, w, h, out.ctypes.data))
+        else:
+            self.L.check(self.L.fn("bake_sky")(self._ctx, w, h, out.ctypes.data))
+        return out.view(np.uint8).reshape(h, w, 4)
+
+    def env_map_texels(self) -> np.ndarray:
+        """(host build only) the texels of the environment map the uploaded scene came with, [h, w, 4] uint8"""
+        buf = np.zeros(4096 * 2048, dtype=np.uint32)
+        wh = (C.c_int * 2)()
+        self.L.check(self.L.fn("env_map_texels")(self._ctx, buf.ctypes.data, buf.size, C.byref(wh)))
+        return buf[:wh[0] * wh[1]].view(np.uint8).reshape(wh[1], wh[0], 4).copy()
 
     def update_instances(self, blob: bytes) -> int:
         """instances / lights / environment of `blob` over the geometry that is on the device; the top level is rebuilt

@@ -89,9 +89,88 @@ class Scene final : public Cpu::Scene {
     BUMP(MeshInstanceHandle, AddMeshInstance, (const mesh_instance_desc_t &mi), (mi))
     BUMP(void, SetMeshInstanceTransform, (MeshInstanceHandle mi, const float *xform), (mi, xform))
     BUMP(void, RemoveMeshInstance, (MeshInstanceHandle mi), (mi))
-    BUMP(void, Finalize, (const std::function<void(int, int, ParallelForFunction &&)> &parallel_for), (parallel_for))
 #undef BUMP_GEOMETRY
 #undef BUMP
+
+    // The sky environment map is baked ON THE DEVICE when the scene belongs to a renderer (round 5): `sky_baker_` is rayhip_bake_sky on the
+    // renderer's root context.  What follows is Cpu::Scene::Finalize (SceneCPU.cpp:882-926) with PrepareSkyEnvMap_nolock (:1017-1056) spelt
+    // out and its CalcSkyEnvTexture call (the host loop over IntegrateScattering) replaced -- as the reference's own GPU scene replaces it by a
+    // compute pass (SceneGPU.h:1697-1768).  A scene without a renderer (Hip::CreateScene: tools that build blobs on a machine without a GPU), or
+    // RAY_HIP_SKY_BAKE_ON_HOST=1, keeps the reference's host loop.
+    std::function<bool(const rayhip_scene_desc &, int, int, uint32_t *)> sky_baker_;
+    const char *sky_baked_on_ = "none";
+
+  public:
+    void set_sky_baker(std::function<bool(const rayhip_scene_desc &, int, int, uint32_t *)> f) { sky_baker_ = std::move(f); }
+    const char *sky_baked_on() const { return sky_baked_on_; }
+
+    void Finalize(const std::function<void(int, int, ParallelForFunction &&)> &parallel_for) override {
+        version_ = next_scene_version();
+        const char *on_host = getenv("RAY_HIP_SKY_BAKE_ON_HOST");
+        const bool physical_sky = env_.env_map != InvalidTextureHandle._index &&
+                                  (env_.env_map == PhysicalSkyTexture._index || env_.env_map == physical_sky_texture_._index);
+        if (!sky_baker_ || (on_host && on_host[0] == '1') || !physical_sky) {
+            sky_baked_on_ = physical_sky ? "host" : "none";
+            Cpu::Scene::Finalize(parallel_for);
+            return;
+        }
+        std::unique_lock<std::shared_timed_mutex> lock(mtx_);
+        if (env_map_light_ != InvalidLightHandle) {
+            lights_.Erase(env_map_light_._block);
+        }
+        env_map_qtree_ = {};
+        env_.qtree_levels = 0;
+        env_.light_index = 0xffffffff;
+        env_.env_map_rotation = 0.0f;
+        if (env_.back_map == env_.env_map) {
+            env_.back_map_rotation = 0.0f;
+        }
+        env_.sky_map_spread_angle = 2 * PI / float(env_.envmap_resolution);
+        { // PrepareSkyEnvMap_nolock
+            if (physical_sky_texture_ != InvalidTextureHandle) {
+                tex_storages_[physical_sky_texture_._index >> 24]->Free(physical_sky_texture_._index & 0x00ffffff);
+            }
+            dir_lights_.clear();
+            for (auto it = lights_.cbegin(); it != lights_.cend(); ++it) {
+                if (it->type == LIGHT_TYPE_DIR) {
+                    dir_lights_.push_back(it.index());
+                }
+            }
+            const int res[] = {env_.envmap_resolution, env_.envmap_resolution / 2};
+            std::vector<color_rgba8_t> rgbe_pixels(size_t(res[0]) * size_t(res[1]));
+            static_assert(sizeof(color_rgba8_t) == sizeof(uint32_t), "RGBE texels are four bytes");
+            FlatScene sky_only;
+            SceneAccess::ExportSkyForBake(*this, sky_only);
+            if (!sky_baker_(sky_only.desc, res[0], res[1], reinterpret_cast<uint32_t *>(rgbe_pixels.data()))) {
+                throw std::runtime_error(std::string("SceneHIP::Finalize: the sky bake failed on the device: ") + rayhip_last_error());
+            }
+            sky_baked_on_ = "device";
+            const int index = tex_storage_rgba_.Allocate(rgbe_pixels, res, false);
+            physical_sky_texture_._index = (uint32_t(0) << 28) | uint32_t(index);
+            env_.env_map = physical_sky_texture_._index;
+            if (env_.back_map == PhysicalSkyTexture._index) {
+                env_.back_map = physical_sky_texture_._index;
+            }
+        }
+        if (env_.importance_sample && env_.env_col[0] > 0.0f && env_.env_col[1] > 0.0f && env_.env_col[2] > 0.0f) {
+            if (env_.env_map != InvalidTextureHandle._index) {
+                PrepareEnvMapQTree_nolock(parallel_for);
+            }
+            light_t l = {}; // the environment as a light source
+            l.type = LIGHT_TYPE_ENV;
+            l.visible = 1;
+            l.cast_shadow = 1;
+            l.col[0] = l.col[1] = l.col[2] = 1.0f;
+            l.ray_visibility |= RAY_TYPE_DIFFUSE_BIT;
+            l.ray_visibility |= RAY_TYPE_SPECULAR_BIT;
+            l.ray_visibility |= RAY_TYPE_REFR_BIT;
+            const std::pair<uint32_t, uint32_t> li = lights_.push(l);
+            env_map_light_ = LightHandle{li.first, li.second};
+            env_.light_index = env_map_light_._index;
+        }
+        RebuildTLAS_nolock();
+        RebuildLightTree_nolock();
+    }
 };
 
 // One device, or several (RAY_HIP_DEVICES=0,1,2,3 | all; settings_t::preferred_device takes the same list): the scene is
@@ -345,7 +424,12 @@ class Renderer final : public RendererBase {
         }
     }
 
-    SceneBase *CreateScene() override { return new Scene(log_, use_tex_compression_); }
+    SceneBase *CreateScene() override {
+        Scene *s = new Scene(log_, use_tex_compression_);
+        rayhip_ctx *ctx = ctx_; // (a scene must not outlive the renderer that made it: the reference's GPU scenes hold their renderer's context too)
+        s->set_sky_baker([ctx](const rayhip_scene_desc &d, int w, int h, uint32_t *out) { return rayhip_bake_sky(ctx, &d, w, h, out) == 0; });
+        return s;
+    }
 
     void RenderScene(const SceneBase &scene, RegionContext &region) override {
         const auto *s = dynamic_cast<const Scene *>(&scene);
@@ -525,6 +609,11 @@ class Renderer final : public RendererBase {
 RendererBase *CreateRenderer(const settings_t &s, ILog *log) { return new Renderer(s, log); }
 
 SceneBase *CreateScene(ILog *log, const bool use_tex_compression) { return new Scene(log, use_tex_compression); }
+
+const char *SkyBakedOn(const SceneBase &scene) {
+    const auto *s = dynamic_cast<const Scene *>(&scene);
+    return s ? s->sky_baked_on() : "none";
+}
 
 std::vector<uint8_t> ExportSceneBlob(const SceneBase &scene) {
     const auto *s = dynamic_cast<const Cpu::Scene *>(&scene);

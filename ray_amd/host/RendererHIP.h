@@ -28,5 +28,8 @@ RendererBase *CreateRenderer(const settings_t &s, ILog *log);
 // (ray_amd/csrc/scene_blob.h): what rayhip_scene_upload_blob consumes.
 SceneBase *CreateScene(ILog *log, bool use_tex_compression = false);
 std::vector<uint8_t> ExportSceneBlob(const SceneBase &scene);
+// where the last Finalize baked the sky environment map of a SceneHIP: "device" (rayhip_bake_sky, a scene made by a renderer), "host" (the
+// reference's loop: a scene without a renderer) or "none" (no physical sky)
+const char *SkyBakedOn(const SceneBase &scene);
 } // namespace Hip
 } // namespace Ray

@@ -522,6 +522,7 @@ int ray_hip_export_scene(ray_scene *s, void **out_blob, uint64_t *out_size) {
         return 1;
     }
 }
+const char *ray_hip_sky_baked_on(ray_scene *s) { return Ray::Hip::SkyBakedOn(*s->s); }
 void ray_hip_free(void *p) { free(p); }
 void ray_hip_pmj_table(const uint32_t **out_ptr, uint32_t *out_count) {
     *out_ptr = Ray::__pmj02_samples;

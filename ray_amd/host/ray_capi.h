@@ -221,6 +221,7 @@ uint32_t ray_scene_node_count(ray_scene *s);
  * ray_amd/csrc/scene_blob.h; the blob is what rayhip_scene_upload_blob takes.  This is how one scene build is
  * replicated to the 8 GPUs of a node (one process per GPU) and how big procedural scenes are cached on disk. */
 ray_scene *ray_hip_create_scene(int verbose);
+const char *ray_hip_sky_baked_on(ray_scene *s); /* Ray::Hip::SkyBakedOn: "device" / "host" / "none" */
 ray_scene *ray_hip_create_scene_ex(int verbose, int use_tex_compression); /* settings_t::use_tex_compression for the scene's textures */
 int ray_hip_export_scene(ray_scene *s, void **out_blob, uint64_t *out_size);
 void ray_hip_free(void *p);

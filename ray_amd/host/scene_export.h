@@ -151,6 +151,41 @@ class SceneAccess : public Cpu::Scene {
         const char *e = getenv("RAY_HIP_DECODE_BC");
         return !(e && e[0] == '1');
     }
+    // the physical sky: what the analytic evaluation of narrow rays (rayhip_sky; AtmosphereRef.cpp: ShadeSky) and the bake of the sky map need
+    static void ExportSkyMembers(const SceneAccess &s, FlatScene &out, rayhip_scene_desc &d) {
+        const environment_t &e = s.env_;
+        d.sky = nullptr, d.sky_count = 0;
+        if (e.sky_map_spread_angle > 0.0f) {
+            rayhip_sky &k = out.sky;
+            k = {};
+            memcpy(&k.atmosphere, &e.atmosphere, sizeof(k.atmosphere));
+            k.transmittance_lut_w = SKY_TRANSMITTANCE_LUT_W, k.transmittance_lut_h = SKY_TRANSMITTANCE_LUT_H;
+            k.multiscatter_lut_res = s.sky_multiscatter_lut_.empty() ? 0 : SKY_MULTISCATTER_LUT_RES;
+            k.weather_res = WEATHER_TEX_RES, k.noise3d_res = NOISE_3D_RES, k.curl_res = CURL_TEX_RES;
+            k.moon_w = MOON_TEX_W, k.moon_h = MOON_TEX_H, k.cirrus_res = CIRRUS_TEX_RES;
+            d.sky = &k, d.sky_count = 1;
+            d.sky_transmittance_lut = s.sky_transmittance_lut_.data(), d.sky_transmittance_lut_count = uint32_t(s.sky_transmittance_lut_.size());
+            d.sky_multiscatter_lut = s.sky_multiscatter_lut_.data(), d.sky_multiscatter_lut_count = uint32_t(s.sky_multiscatter_lut_.size());
+            d.sky_dir_lights = s.dir_lights_.data(), d.sky_dir_lights_count = uint32_t(s.dir_lights_.size());
+            d.sky_weather_tex = __weather_tex, d.sky_weather_tex_count = uint32_t(3 * WEATHER_TEX_RES * WEATHER_TEX_RES);
+            d.sky_noise3d_tex = __3d_noise_tex, d.sky_noise3d_tex_count = uint32_t(NOISE_3D_RES * NOISE_3D_RES * NOISE_3D_RES);
+            d.sky_curl_tex = __curl_tex, d.sky_curl_tex_count = uint32_t(3 * CURL_TEX_RES * CURL_TEX_RES);
+            d.sky_moon_tex = __moon_tex, d.sky_moon_tex_count = uint32_t(3 * MOON_TEX_W * MOON_TEX_H);
+            d.sky_cirrus_tex = __cirrus_tex, d.sky_cirrus_tex_count = uint32_t(2 * CIRRUS_TEX_RES * CIRRUS_TEX_RES);
+        }
+    }
+    // ... for rayhip_bake_sky: the sky members + the light array, nothing else (called from SceneHIP::Finalize with the scene locked)
+    static void ExportSkyForBake(const Cpu::Scene &_s, FlatScene &out) {
+        const auto &s = static_cast<const SceneAccess &>(_s);
+        rayhip_scene_desc &d = out.desc;
+        d = {};
+        d.struct_size = uint32_t(sizeof(rayhip_scene_desc));
+        d.lights = reinterpret_cast<const rayhip_light *>(s.lights_.data());
+        d.lights_count = s.lights_.capacity();
+        d.env.sky_map_spread_angle = s.env_.sky_map_spread_angle;
+        ExportSkyMembers(s, out, d);
+    }
+
     static void Export(const Cpu::Scene &_s, FlatScene &out, const bool with_textures = true, const bool raw_blocks = RawBlocksByDefault()) {
         // NOTE: the cast never touches SceneAccess-specific state (there is none); it only names the members
         const auto &s = static_cast<const SceneAccess &>(_s);
@@ -231,26 +266,7 @@ class SceneAccess : public Cpu::Scene {
         d.env.sky_map_spread_angle = e.sky_map_spread_angle;
         d.env.qtree_levels = e.qtree_levels;
 
-        // the physical sky: what the analytic evaluation of narrow rays needs (rayhip_sky; AtmosphereRef.cpp: ShadeSky)
-        d.sky = nullptr, d.sky_count = 0;
-        if (e.sky_map_spread_angle > 0.0f) {
-            rayhip_sky &k = out.sky;
-            k = {};
-            memcpy(&k.atmosphere, &e.atmosphere, sizeof(k.atmosphere));
-            k.transmittance_lut_w = SKY_TRANSMITTANCE_LUT_W, k.transmittance_lut_h = SKY_TRANSMITTANCE_LUT_H;
-            k.multiscatter_lut_res = s.sky_multiscatter_lut_.empty() ? 0 : SKY_MULTISCATTER_LUT_RES;
-            k.weather_res = WEATHER_TEX_RES, k.noise3d_res = NOISE_3D_RES, k.curl_res = CURL_TEX_RES;
-            k.moon_w = MOON_TEX_W, k.moon_h = MOON_TEX_H, k.cirrus_res = CIRRUS_TEX_RES;
-            d.sky = &k, d.sky_count = 1;
-            d.sky_transmittance_lut = s.sky_transmittance_lut_.data(), d.sky_transmittance_lut_count = uint32_t(s.sky_transmittance_lut_.size());
-            d.sky_multiscatter_lut = s.sky_multiscatter_lut_.data(), d.sky_multiscatter_lut_count = uint32_t(s.sky_multiscatter_lut_.size());
-            d.sky_dir_lights = s.dir_lights_.data(), d.sky_dir_lights_count = uint32_t(s.dir_lights_.size());
-            d.sky_weather_tex = __weather_tex, d.sky_weather_tex_count = uint32_t(3 * WEATHER_TEX_RES * WEATHER_TEX_RES);
-            d.sky_noise3d_tex = __3d_noise_tex, d.sky_noise3d_tex_count = uint32_t(NOISE_3D_RES * NOISE_3D_RES * NOISE_3D_RES);
-            d.sky_curl_tex = __curl_tex, d.sky_curl_tex_count = uint32_t(3 * CURL_TEX_RES * CURL_TEX_RES);
-            d.sky_moon_tex = __moon_tex, d.sky_moon_tex_count = uint32_t(3 * MOON_TEX_W * MOON_TEX_H);
-            d.sky_cirrus_tex = __cirrus_tex, d.sky_cirrus_tex_count = uint32_t(2 * CIRRUS_TEX_RES * CIRRUS_TEX_RES);
-        }
+        ExportSkyMembers(s, out, d);
 
         d.tlas_root = s.tlas_root_;
         d.visible_lights_count = s.visible_lights_count_;

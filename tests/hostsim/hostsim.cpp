@@ -412,6 +412,37 @@ HS_API int hostsim_set_tonemap_lut(hostsim_ctx *c, int view_transform, const uin
     return 0;
 }
 
+// the baked sky map: the host build of sky_bake_texel (rt_sky.h) over the uploaded scene's sky, and -- to compare it with -- the texels of the
+// environment map the scene came with (baked by the reference's CalcSkyEnvTexture when the scene was finalized)
+HS_API int hostsim_bake_sky(hostsim_ctx *c, int w, int h, uint32_t *out_rgbe8) {
+    if (!c->have_scene || c->sc.sky.desc == nullptr) {
+        g_err = "hostsim_bake_sky: the uploaded scene has no physical sky";
+        return 1;
+    }
+    for (int y = 0; y < h; ++y) {
+        for (int x = 0; x < w; ++x) {
+            out_rgbe8[size_t(y) * size_t(w) + size_t(x)] = sky_bake_texel(c->sc.sky, c->sc.lights, x, y, w, h);
+        }
+    }
+    return 0;
+}
+HS_API int hostsim_env_map_texels(hostsim_ctx *c, uint32_t *out, size_t capacity, int out_wh[2]) {
+    if (!c->have_scene || c->sc.env.env_map == 0xffffffffu) {
+        g_err = "hostsim_env_map_texels: the uploaded scene has no environment map";
+        return 1;
+    }
+    const uint32_t handle = c->sc.env.env_map;
+    const rayhip_texture &t = c->sc.textures[c->sc.tex_table[handle >> 28] + (handle & 0x00ffffffu)];
+    out_wh[0] = int(t.width[0]), out_wh[1] = int(t.height[0]);
+    const size_t n = size_t(t.width[0]) * size_t(t.height[0]);
+    if (n > capacity) {
+        g_err = "hostsim_env_map_texels: buffer too small";
+        return 1;
+    }
+    memcpy(out, c->sc.texels + t.offset[0], n * sizeof(uint32_t));
+    return 0;
+}
+
 HS_API int hostsim_scene_upload_blob(hostsim_ctx *c, const void *blob, size_t size, rayhip_camera *out_cam) {
     rayhip_scene_desc d;
     const float *ft = nullptr;
