@@ -191,14 +191,15 @@ def valu_issue_block(traffic, launches, k2_s):
     out = {"wave_instructions_per_s": rate, "active_lanes_of_64": traffic.get("valu_active_lanes"),
            "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU of this command / live launch time"}
     try:
-        with open(os.path.join(ROOT, "profiles", "r04", "k2_valu_mix.json")) as f:
+        mix_path = next(p for p in (os.path.join(ROOT, "profiles", r, "k2_valu_mix.json") for r in ("r05", "r04")) if os.path.exists(p))
+        with open(mix_path) as f:
             mix = json.load(f)
         peak = mix["peak_wave_instructions_per_s"]
         out.update({"mix": mix["share"], "peak_mix_weighted": peak["serial"], "frac": rate / peak["serial"],
                     "peak_paired_model": peak["paired"], "frac_paired_model": rate / peak["paired"],
                     "mix_is_stale": mix.get("csrc_hash") != csrc_hash(),
-                    "peaks_from": "profiles/r04/k2_valu_mix.json (tools/valu_mix.py) x profiles/r03/valu_bench.txt"})
-    except (OSError, ValueError, KeyError):
+                    "peaks_from": os.path.relpath(mix_path, ROOT) + " (tools/valu_mix.py) x profiles/r03/valu_bench.txt"})
+    except (OSError, ValueError, KeyError, StopIteration):
         out.update({"peak_full_rate_class": 1.09e12, "peak_half_rate_class": 0.59e12})
     return out
 

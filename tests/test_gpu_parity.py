@@ -755,6 +755,35 @@ def test_random_scenes_match_the_host_build(gpu_lib, hostsim_lib, fn, seed, comp
         assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
 
 
+@pytest.mark.parametrize("seed", [10017, 7017])
+def test_the_worst_fuzz_scenes_against_the_oracle_directly(gpu_lib, seed):
+    """the two scenes of the 480-scene device fuzz of round 4 with the lowest scores against the HOST BUILD (profiles/r04/gpu_fuzz.txt:
+    random_instances 10017: 99.935 % within tolerance, 7017: 87.2 dB) against the live reference itself -- one link instead of two
+    (VERDICT round 4, weak 2): render + NLM filter as the fuzzer does, RendererRef doing the same on its own frame"""
+    from ray_amd import api, scenes
+    w, h, spp = 64, 48, 4
+    compress = bool(seed & 1)
+    ref = O.create_renderer(w, h, "REF", use_tex_compression=compress)
+    rs = ref.CreateScene()
+    scenes.random_instances(rs, seed=seed)
+    region = api.RegionContext((0, 0, w, h))
+    for _ in range(spp):
+        ref.RenderScene(rs, region)
+    ctx = hip.Context(0, gpu_lib)
+    ctx.upload_static(util.pmj())
+    ctx.resize(w, h)
+    ctx.upload_scene_blob(O.export_scene(rs))
+    ctx.render_batch(1, spp)
+    m = util.frame_metrics(ctx.readback(hip.BUF_RAW), ref.get_raw_pixels_ref())
+    print(f"random_instances {seed}: device against RendererRef after {spp} spp:", m)
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP and m["alpha_equal"], m
+    ctx.denoise_nlm(spp)
+    ref.DenoiseImage(region)
+    m = util.frame_metrics(ctx.readback(hip.BUF_RAW), ref.get_raw_pixels_ref())
+    print(f"random_instances {seed}: ... and after the NLM filter:", m)
+    assert m["frac_within"] >= 0.99 and m["psnr"] >= 60.0, m
+
+
 def test_compressed_textures_through_the_ray_api(gpu_lib, hostsim_lib):
     """settings_t::use_tex_compression = true (the reference's default): SceneHIP keeps the BCn storages and the exporter
     decodes them (host build == reference on this, tests/test_hostsim_parity.py); the GPU must agree with the host build"""
