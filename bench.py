@@ -34,13 +34,17 @@ for the secondary bounces, whole chunks for the primary rays; "a launch" is a la
 events on the context stream during the timed region (RAYHIP_FLAG_TIME_STAGES, no synchronisation).  Three byte counts,
 all per launch:
   traffic      HBM bytes that actually moved: rocprofv3 PMC FETCH_SIZE + WRITE_SIZE of this kernel, from a profiled run of
-               THIS command line (profiles/r04/k2_traffic.json, keyed by workload / spp / iterations per pass; written by
+               THIS command line (profiles/r05/k2_traffic.json, keyed by workload / spp / iterations per pass; written by
                tools/k2_traffic.py from the rocprofv3 output and stamped with a hash of ray_amd/csrc); for another pass size
                or N > 1 the profiled run of the same workload with the nearest pass size, scaled by rays per launch
                (traffic_detail.exact = false says so); traffic_detail.stale = true when the kernel sources changed since the
                profile was taken; null when the workload was never profiled
   achieved     = traffic / launch time when traffic is known (the north star's figure: "achieved HBM GB/s from rocprof
-               against the chip's memory roofline"), else the kernel's own algorithmic rate; frac = achieved / 8 TB/s
+               against the chip's memory roofline"), else the kernel's own algorithmic rate; frac = achieved / 8 TB/s, or null
+               when no counter profile of the workload is committed (an algorithmic rate is an upper bound, not a fraction)
+  traversal    (round 5) the same for K2 + K3 together -- SURVEY 8d's "traversal": the committed per-launch traffic of both kernels
+               x their launches / the time the traversal took.  K3 of bounce b runs on a second stream next to K2 of bounce b + 1,
+               so that time is the sum of the closest-hit intervals of the context stream (each ends when both launches are through)
   algorithmic  the kernel's OWN algorithmic bytes: 72+20+4 per ray + 64 per TLAS node + 64 per 4-wide node (80 per 8-wide
                node with RAYHIP_BVH_WIDTH=8) + 48 per triangle + 144 per instance, counted by the instrumented product kernel (RAYHIP_FLAG_COUNT_WIDE) on iterations
                of the same workload right after the timed region; next to it the same for the reference's BVH2 walk
@@ -208,7 +212,7 @@ def traversal_block(traffic, k2_launches, k3_launches, k2_ms, k3_ms, overlapped,
     """roofline of K2 + K3 together"""
     t_ms = k2_ms if overlapped else k2_ms + k3_ms
     out = {"kernels": "k_trace_closest_refill (both forms) + k_trace_shadow_refill", "ms_per_region": t_ms,
-           "time_is": ("closest-hit intervals of the context stream (each ends when the K2 launch AND the shadow launch beside it are through)" if overlapped
+           "time_is": ("the trace stages of the context stream (a stage ends when the K2 launch AND the shadow launch beside it are through)" if overlapped
                        else "K2 intervals + K3 intervals"),
            "algorithmic_GBps": algorithmic_bytes / 1e9 / (t_ms / 1e3) if t_ms > 0 else None,
            "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
@@ -567,7 +571,8 @@ def main():
                 # SURVEY 8d's "traversal": K2 + K3 together.  Bytes: the PMC profile's per-launch figures of both kernels x their launches (or
                 # null); time: the closest-hit intervals of the context stream, which end when BOTH the K2 launch and the K3 launch that ran
                 # next to it are through (the last K3 of a pass runs alone: its few microseconds are in the shade interval that follows)
-                "traversal": traversal_block(traffic, k2_launches, k3_launches, k2_ms, k3_ms, overlap_shadow, k2_bytes + k3_bytes),
+                "traversal": traversal_block(traffic, k2_launches, k3_launches, (stages["primary_trace"] + stages["secondary_trace"]) / 1e3 if overlap_shadow else k2_ms,
+                                             k3_ms, overlap_shadow, k2_bytes + k3_bytes),
             },
             "stage_us_per_step": {k: v / K for k, v in stages.items() if v},
             "stage_us_per_spp": {k: v / (K * SPP) for k, v in stages.items() if v},

@@ -235,6 +235,9 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
                 return 1;
             }
             launch_closest(c->rays[cur], c->ray_queue(bounce, nslots, stripes), 1);
+            if (side_pending && tm.mark(ST_STRACE, -1)) { // (K2's own interval ends here: what follows is the wait for the shadow launch beside it)
+                return 1;
+            }
             if (c->sc.visible_lights_count != 0) {
                 k_intersect_area_lights<<<gtrace, WAVE, 0, s>>>(c->sc, c->rays[cur], c->hits, c->ray_queue(bounce, nslots, stripes));
             }

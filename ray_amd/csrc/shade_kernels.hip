@@ -225,12 +225,14 @@ __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick(const Sc
 #ifndef RT_PICK_RUN
 #define RT_PICK_RUN 8
 #endif
-template <bool COMPACT>
+// DYN: chunks from the work counter (wavefront.hip.h; opt-in) -- a template parameter, not a null test, so that the default kernel is the code it
+// was before the counter existed (as a run-time pointer it cost this kernel nine more spilled registers and 14 % of its time: 64 VGPRs at 8 waves)
+template <bool COMPACT, bool DYN = false>
 __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick_refill(const SceneView sc, const ShadeParams sp, const RaySoA rays_in,
                                                                               const PointSoA points, const RayQueue queue, const RayQueue nee,
                                                                               const Layering layers, uint32_t *__restrict__ work /* dynamic chunk hand-out, may be null */) {
     const uint32_t lane = threadIdx.x;
-    ChunkWalk walk(queue.live_chunks(), work, RT_PICK_RUN);
+    ChunkWalk walk(queue.live_chunks(), DYN ? work : nullptr, RT_PICK_RUN);
     uint32_t pool_slot = 0, pool_left = 0, pool_stripe = 0; // (uniform) the chunk being handed out
     bool exhausted = false;                                  // (uniform) no chunk left to hand out
     // lane state
@@ -562,7 +564,11 @@ void launch(const ShadeLaunch &a) {
             }
             kernel<<<grid, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers, a.work);
         };
-        nee_compact ? go(k_light_pick_refill<true>) : go(k_light_pick_refill<false>);
+        if (a.work) {
+            nee_compact ? go(k_light_pick_refill<true, true>) : go(k_light_pick_refill<false, true>);
+        } else {
+            nee_compact ? go(k_light_pick_refill<true, false>) : go(k_light_pick_refill<false, false>);
+        }
     } else if (nee_compact) {
         k_light_pick<true><<<sized(k_light_pick<true>, a.expect[EXPECT_POINTS], all), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.points, a.pts, a.nee, a.layers);
     } else if (pick_apart) {
