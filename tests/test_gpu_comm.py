@@ -97,6 +97,7 @@ def test_packed_tiles_of_three_shards_on_one_gpu_assemble_the_frame(lib):
             nbytes = ctxs[r].owned_bytes(hip.REDUCE_ALL, n, r)
             assert nbytes == ctxs[0].owned_bytes(hip.REDUCE_ALL, n, r) and nbytes % (64 * 64 * 16 * 4) == 0
             buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()  # (the fill runs on torch's stream, the pack on librayhip's own: without this the zeros may land last)
             ctxs[r].export_owned(hip.REDUCE_ALL, buf.data_ptr(), nbytes)
             ctxs[0].import_owned(hip.REDUCE_ALL, r, buf.data_ptr(), nbytes)
         ctxs[0].finish_import()
