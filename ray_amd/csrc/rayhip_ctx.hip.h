@@ -639,7 +639,8 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     if (c->census_on) {
         void *hp = nullptr, *dp = nullptr;
         const size_t bytes = sizeof(uint32_t) * size_t(MAX_BOUNCE_SLOTS) * rayhip_ctx::QUEUES_PER_BOUNCE;
-        if (hipHostMalloc(&hp, bytes, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess ||
+        if (hipHostMalloc(&hp, bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || // (coherent: the device's stores are visible to the host once the event has fired)
+             hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess ||
             hipEventCreateWithFlags(&c->census_event, hipEventDisableTiming) != hipSuccess) {
             if (hp) {
                 (void)hipHostFree(hp);

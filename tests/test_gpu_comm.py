@@ -11,6 +11,8 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (FIRST: torch brings its own HIP runtime, and it must be the one that opens the device -- librayhip, loaded later,
+#               shares it; the other way round torch finds "no HIP GPUs" -- which is what this file did when it ran on its own)
 
 import util
 from ray_amd import hip, multigpu
