@@ -1,6 +1,7 @@
 """Random scenes (ray_amd.scenes.random_cornell / random_instances / random_textures) on the GPU against the host build of the same kernel
-sources (which equals the reference on these, tests/test_hostsim_parity.py).  Runs on a GPU box:
-    python tools/gpu_fuzz.py [first_seed] [count]"""
+sources (which equals the reference on these, tests/test_hostsim_parity.py) -- or, with `oracle` as the third argument, against the live
+REFERENCE itself (RendererRef from oracle/_ref doing the same render + NLM filter on its own frame: one link instead of two).  Runs on a GPU box:
+    python tools/gpu_fuzz.py [first_seed] [count] [oracle]"""
 import os
 import sys
 from functools import partial
@@ -20,11 +21,32 @@ from ray_amd import api, hip, scenes  # noqa: E402
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+    against_oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"
     gpu, host = hip.Library(), hip.Library(O.HOSTSIM_LIB, prefix="hostsim_")
     w, h, spp = 64, 48, 4
     worst = (1.0, 1e9, None)
     for seed in range(first, first + count):
         for fn in (scenes.random_cornell, scenes.random_instances, scenes.random_textures):
+            if against_oracle:
+                ref = O.create_renderer(w, h, "REF", use_tex_compression=bool(seed & 1))
+                rs = ref.CreateScene()
+                fn(rs, seed=seed)
+                region = api.RegionContext((0, 0, w, h))
+                for _ in range(spp):
+                    ref.RenderScene(rs, region)
+                ref.DenoiseImage(region)
+                ctx = hip.Context(0, gpu)
+                ctx.upload_static(util.pmj())
+                ctx.resize(w, h)
+                ctx.upload_scene_blob(O.export_scene(rs))
+                ctx.render_batch(1, spp)
+                ctx.denoise_nlm(spp)
+                m = util.frame_metrics(ctx.readback(hip.BUF_RAW), ref.get_raw_pixels_ref())
+                if (m["frac_within"], m["psnr"]) < (worst[0], worst[1]):
+                    worst = (m["frac_within"], m["psnr"], (fn.__name__, seed))
+                if m["frac_within"] < 0.99 or m["psnr"] < util.MIN_PSNR_8SPP:
+                    print("FAIL", fn.__name__, seed, m)
+                continue
             r = api.CreateRenderer(api.Settings(w, h, use_tex_compression=bool(seed & 1)), "HIP")
             s = r.CreateScene()
             fn(s, seed=seed)
@@ -46,7 +68,7 @@ def main():
                 worst = (m["frac_within"], m["psnr"], (fn.__name__, seed))
             if m["frac_within"] < util.MIN_FRACTION or m["psnr"] < util.MIN_PSNR_8SPP:
                 print("FAIL", fn.__name__, seed, m)
-    print(f"{3 * count} random scenes, GPU vs host build after render + NLM: worst fraction within tolerance {worst[0]:.5f}, "
+    print(f"{3 * count} random scenes, GPU vs {'RendererRef (the oracle, live)' if against_oracle else 'host build'} after render + NLM: worst fraction within tolerance {worst[0]:.5f}, "
           f"worst PSNR {worst[1]:.1f} dB at {worst[2]}")
 
 
