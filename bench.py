@@ -384,10 +384,29 @@ def main():
     ctx.set_shard(TILE, world, rank)
     # the exchange step: the product's collective (RCCL behind the C ABI); torch.distributed only hands the id around
     comm = None
+    comm_error = None
     if dist is not None and not emulated:
-        ids = [hip.Comm.unique_id(ctx.L) if rank == 0 else None]
+        # Every rank must end up on the same transport: a rank that cannot form the communicator (no librccl for dlopen, an RCCL that
+        # refuses the id) says so, the ranks agree by an all-reduce, and then ALL of them move the same packed tiles with torch.distributed's
+        # gather over its own RCCL instead (multigpu.exchange_frame) -- the line says which one ran ("exchange").
+        try:
+            ids = [hip.Comm.unique_id(ctx.L) if rank == 0 else None]
+        except RuntimeError as e:
+            ids, comm_error = [None], str(e)
         dist.broadcast_object_list(ids, src=0)
-        comm = hip.Comm.for_rank(ctx.L, ids[0], world, rank, ctx)
+        if ids[0] is not None:
+            try:
+                comm = hip.Comm.for_rank(ctx.L, ids[0], world, rank, ctx)
+            except RuntimeError as e:
+                comm_error = str(e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+                comm = None
+            print(f"bench.py rank {rank}: rayhip_comm unavailable ({comm_error or 'on another rank'}); the tiles go through torch.distributed",
+                  file=sys.stderr)
 
     def exchange():
         if dist is not None:
@@ -584,8 +603,10 @@ def main():
         if rank_times is not None:
             out["exchange_ms"] = rank_times["exchange_ms_rank0"]
             out["rank_render_ms"] = rank_times["render_ms"]
-            out["exchange"] = ("rayhip_comm_reduce_framebuffers: owned tiles (1/N of the frame per rank) point-to-point to rank 0 over RCCL"
-                               if not emulated else "owned tiles through host memory over gloo (ranks share a device: RCCL cannot form the communicator)")
+            out["exchange"] = ("owned tiles through host memory over gloo (ranks share a device: RCCL cannot form the communicator)" if emulated else
+                               "rayhip_comm_reduce_framebuffers: owned tiles (1/N of the frame per rank) point-to-point to rank 0 over RCCL"
+                               if comm is not None else
+                               "torch.distributed gather of the owned tiles over RCCL (rayhip_comm could not be formed: see stderr)")
         if emulated:
             out["emulated_ranks"] = True
             out["devices"] = n_dev
