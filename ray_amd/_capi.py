@@ -103,6 +103,7 @@ class TexDesc(C.Structure):  # ray_tex_desc
         ("generate_mipmaps", C.c_int32),
         ("reconstruct_z", C.c_int32),
         ("mips_count", C.c_int32),
+        ("convention", C.c_int32),
     ]
 
 
@@ -247,6 +248,7 @@ def declare(lib):
         "ray_scene_add_mesh_instance_vis": (ray_handle, [vp, ray_handle, C.POINTER(C.c_float * 16), C.c_uint]),
         "ray_scene_set_mesh_instance_transform": (None, [vp, ray_handle, C.POINTER(C.c_float * 16)]),
         "ray_scene_remove_mesh_instance": (None, [vp, ray_handle]),
+        "ray_scene_remove_mesh": (None, [vp, ray_handle]),
         "ray_scene_remove_light": (None, [vp, ray_handle]),
         "ray_scene_add_light": (ray_handle, [vp, C.POINTER(LightDesc)]),
         "ray_scene_add_camera": (ray_handle, [vp, C.POINTER(CameraDesc)]),

@@ -153,11 +153,12 @@ class SceneBase:
     # -- textures / materials ----------------------------------------------------------------------------------
     def AddTexture(self, data: np.ndarray, fmt=eTextureFormat.RGBA8888, is_srgb=True, is_normalmap=False,
                    generate_mipmaps=False, reconstruct_z=False, force_no_compression=True, size=None, mips_count=1,
-                   is_YCoCg=False) -> int:
+                   is_YCoCg=False, convention_dx=False) -> int:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         h, w = (size[1], size[0]) if size is not None else (data.shape[0], data.shape[1])  # size = (w, h): block-compressed data
         d = _capi.TexDesc()
         d.mips_count, d.is_YCoCg = int(mips_count), int(is_YCoCg)
+        d.convention = 1 if convention_dx else 0  # eTextureConvention::DX: y of a normal map inverted, block textures stored top-down
         d.format = int(fmt)
         d.data = data.ctypes.data_as(C.POINTER(C.c_uint8))
         d.data_size = data.size
@@ -216,6 +217,9 @@ class SceneBase:
     def SetMeshInstanceTransform(self, mi: int, xform):
         m = (C.c_float * 16)(*np.asarray(xform, np.float32).ravel())
         self._lib.ray_scene_set_mesh_instance_transform(self._ptr, mi, C.byref(m))
+
+    def RemoveMesh(self, mesh: int):
+        self._lib.ray_scene_remove_mesh(self._ptr, mesh)
 
     def RemoveMeshInstance(self, mi: int):
         self._lib.ray_scene_remove_mesh_instance(self._ptr, mi)

@@ -324,6 +324,7 @@ ray_handle ray_scene_add_texture(ray_scene *s, const ray_tex_desc *d) {
     t.force_no_compression = d->force_no_compression != 0, t.generate_mipmaps = d->generate_mipmaps != 0;
     t.reconstruct_z = d->reconstruct_z != 0;
     t.mips_count = d->mips_count > 0 ? d->mips_count : 1;
+    t.convention = d->convention == 1 ? Ray::eTextureConvention::DX : Ray::eTextureConvention::OGL;
     return from_handle(s->s->AddTexture(t));
 }
 
@@ -411,6 +412,7 @@ void ray_scene_set_mesh_instance_transform(ray_scene *s, ray_handle mi, const fl
     s->s->SetMeshInstanceTransform(to_handle<Ray::MeshInstanceHandle>(mi), xform);
 }
 void ray_scene_remove_mesh_instance(ray_scene *s, ray_handle mi) { s->s->RemoveMeshInstance(to_handle<Ray::MeshInstanceHandle>(mi)); }
+void ray_scene_remove_mesh(ray_scene *s, ray_handle mesh) { s->s->RemoveMesh(to_handle<Ray::MeshHandle>(mesh)); }
 void ray_scene_remove_light(ray_scene *s, ray_handle light) { s->s->RemoveLight(to_handle<Ray::LightHandle>(light)); }
 
 ray_handle ray_scene_add_light(ray_scene *s, const ray_light_desc *d) {

@@ -104,6 +104,7 @@ typedef struct ray_tex_desc { /* Ray::tex_desc_t, SceneBase.h:172-187 */
     int32_t w, h;
     int32_t is_srgb, is_normalmap, is_YCoCg, force_no_compression, generate_mipmaps, reconstruct_z;
     int32_t mips_count;         /* levels present in `data` (block-compressed formats; 0 = 1) */
+    int32_t convention;         /* Ray::eTextureConvention (SceneBase.h:147-150): 0 OGL, 1 DX (normal maps: y inverted; block textures: stored top-down) */
 } ray_tex_desc;
 
 typedef struct ray_light_desc { /* union of the six light descriptors, SceneBase.h:189-262 */
@@ -207,6 +208,7 @@ ray_handle ray_scene_add_mesh_instance(ray_scene *s, ray_handle mesh, const floa
 ray_handle ray_scene_add_mesh_instance_vis(ray_scene *s, ray_handle mesh, const float xform[16], unsigned visibility);
 void ray_scene_set_mesh_instance_transform(ray_scene *s, ray_handle mi, const float xform[16]); /* SceneBase.h:464 */
 void ray_scene_remove_mesh_instance(ray_scene *s, ray_handle mi);                             /* :472 */
+void ray_scene_remove_mesh(ray_scene *s, ray_handle mesh);                                    /* :424 (the reference's tests add every mesh twice and remove one copy: storage compaction) */
 void ray_scene_remove_light(ray_scene *s, ray_handle light);                                  /* :440 */
 ray_handle ray_scene_add_light(ray_scene *s, const ray_light_desc *d);                /* the six AddLight overloads */
 ray_handle ray_scene_add_camera(ray_scene *s, const ray_camera_desc *d);              /* SceneBase::AddCamera */
