@@ -2,7 +2,7 @@
 
     python tests/golden/make_material_matrix.py            # needs /root/reference; writes tests/golden/material_matrix.json
 
-/root/reference/tests/test_shading.cpp:359-1919 holds ninety `test_<name>` functions, every one of them a material descriptor
+/root/reference/tests/test_shading.cpp:359-1919 holds ninety `test_<name>` functions (tests/test_aux_channels.cpp a ninety-first of its own shape), every one of them a material descriptor
 (shading_node_desc_t or principled_mat_desc_t, field by field), a texture list, a scene variant (eTestScene: which lights, which camera
 extras), a sample count and a denoise / region / adaptive-sampling switch, handed to run_material_test.  The golden images those tests
 compare with cannot be reproduced here (env.bin and most textures are absent from the checkout), but the MATRIX is the
@@ -38,7 +38,7 @@ def number(text, consts):
 
 def value(text, consts):
     text = text.strip()
-    m = re.fullmatch(r"Ray::TextureHandle\{(\d+)\}", text)
+    m = re.fullmatch(r"(?:Ray::)?TextureHandle\{(\d+)\}", text)
     if m:
         return {"texture": int(m.group(1))}
     m = re.fullmatch(r"Ray::eShadingNode::(\w+)", text)
@@ -110,12 +110,34 @@ def parse(src):
     return tests
 
 
+def parse_aux(src):
+    """tests/test_aux_channels.cpp:20-72: one more material (five textures, alpha among them) on the Standard scene, 14 samples, judged on the base
+    colour, normals and depth images instead of the beauty frame"""
+    body = open(src).read()
+    consts = {m.group(1): number(m.group(2), {}) for m in re.finditer(r"\b(SampleCount|\w+_MinPSNR) = ([0-9.]+)", body)}
+    fields = {}
+    for m in re.finditer(r"^\s*mat_desc\.(\w+)(?:\[(\d)\])? = ([^;]+);", body, re.M):
+        fields[m.group(1)] = value(m.group(3), consts)
+    tex = re.search(r"const char \*textures\[\] = \{(.*?)\};", body, re.S)
+    call = re.search(r"setup_test_scene\(threads, \*scene, (-?\d+), ([0-9.]+)f, mat_desc, textures, eTestScene::(\w+)\)", body)
+    line = body[:body.index("void test_aux_channels")].count("\n") + 1
+    return {"name": "aux_channels", "function": "test_aux_channels", "line": line, "source": "tests/test_aux_channels.cpp", "desc": "principled_mat_desc_t",
+            "min_samples": int(call.group(1)), "max_samples": consts["SampleCount"], "variance_threshold": float(call.group(2)),
+            "min_psnr": min(consts["BaseColor_MinPSNR"], consts["Normals_MinPSNR"], consts["Depth_MinPSNR"]), "pix_thres": 0, "denoise": "None",
+            "partial": False, "caching": False, "scene": call.group(3), "fields": fields,
+            "textures": [os.path.basename(t) for t in re.findall(r'"([^"]+)"', tex.group(1))]}
+
+
+def parse_all(src=SRC):
+    return parse(src) + [parse_aux(os.path.join(os.path.dirname(src), "test_aux_channels.cpp"))]
+
+
 def main():
     if not os.path.exists(SRC):
         sys.exit("needs /root/reference (this container): the matrix is committed as tests/golden/material_matrix.json")
-    tests = parse(SRC)
+    tests = parse_all(SRC)
     with open(OUT, "w") as f:
-        json.dump({"source": "tests/test_shading.cpp of the reference, read by tests/golden/make_material_matrix.py", "tests": tests}, f, indent=1)
+        json.dump({"source": "tests/test_shading.cpp + tests/test_aux_channels.cpp of the reference, read by tests/golden/make_material_matrix.py", "tests": tests}, f, indent=1)
     kinds = {}
     for t in tests:
         kinds[t["scene"]] = kinds.get(t["scene"], 0) + 1

@@ -407,3 +407,38 @@ def run_entry(entry, make_context, w, h, spp_cap=None, batched=False, threads=1)
            "base_color": (ctx.readback(hip.BUF_BASE_COLOR), ref.get_aux_pixels_ref(api.eAUXBuffer.BaseColor)),
            "depth_normals": (ctx.readback(hip.BUF_DEPTH_NORMALS), ref.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals))}
     return {k: dict(util.frame_metrics(a, b), equal=bool(np.array_equal(a, b))) for k, (a, b) in got.items()}, notes
+
+
+def run_entry_through_the_api(entry, w, h, spp_cap=None):
+    """The same entry as the reference's harness drives it (run_material_test, tests/test_shading.cpp:34-212): CreateRenderer -> CreateScene ->
+    setup_test_scene -> Resize down and up -> RenderScene per region and sample -> DenoiseImage (NLM, or the sixteen UNet passes) -> get_pixels_ref,
+    once with RendererRef and once with RendererHIP -- scene construction, export and upload are the product's here (SceneHIP), not the oracle's.
+    -> ({buffer: frame_metrics}, the two raw frames)"""
+    import oracle_lib as O
+    import util
+    spp = entry["max_samples"] if spp_cap is None else min(entry["max_samples"], spp_cap)
+    rects = checkerboard(w, h) if entry["partial"] else [(0, 0, w, h)]
+    frames = []
+    for kind in ("REF", "HIP"):
+        r = O.create_renderer(w, h, "REF") if kind == "REF" else api.CreateRenderer(api.Settings(w, h), "HIP")
+        s = r.CreateScene()
+        build(s, entry)
+        r.Resize(w // 2, h // 2)  # ("test Resize robustness", test_shading.cpp:103-106)
+        r.Resize(w, h)
+        regions = [api.RegionContext(rc) for rc in rects]
+        for region in regions:
+            for _ in range(spp):
+                r.RenderScene(s, region)
+        if entry["denoise"] == "NLM":
+            for region in regions:
+                r.DenoiseImage(region)
+        elif entry["denoise"] == "UNet":
+            n = r.InitUNetFilter()
+            for region in regions:
+                for p in range(n):
+                    r.DenoiseImageUNet(p, region)
+        frames.append({"raw": r.get_raw_pixels_ref().copy(), "final": r.get_pixels_ref().copy(),
+                       "base_color": r.get_aux_pixels_ref(api.eAUXBuffer.BaseColor).copy(),
+                       "depth_normals": r.get_aux_pixels_ref(api.eAUXBuffer.DepthNormals).copy(), "keep": (r, s)})
+    ref, got = frames
+    return {k: util.frame_metrics(got[k], ref[k]) for k in ("raw", "final", "base_color", "depth_normals")}, (got["raw"], ref["raw"])

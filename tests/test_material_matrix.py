@@ -1,6 +1,6 @@
 """The reference's own material test matrix on the reference's own test meshes.
 
-tests/test_shading.cpp of the reference holds ninety material tests (Oren-Nayar, Principled diffuse / sheen / glossy / specular / anisotropic /
+tests/test_shading.cpp of the reference holds ninety material tests, tests/test_aux_channels.cpp one more (Oren-Nayar, Principled diffuse / sheen / glossy / specular / anisotropic /
 metal / plastic / tint / emission / clearcoat, refraction with and without MIS, transmission, alpha, two-sided, seven textured "complex"
 materials under every light type, depth of field, clipping, regions, adaptive sampling, ray-visibility flags).  Their golden images cannot be
 reproduced in this checkout (env.bin and most textures are absent), but the matrix itself -- descriptors, scene variants, sample
@@ -9,8 +9,8 @@ mat_test meshes by the live oracle and by this backend (tests/ref_material_scene
 
   * CPU (`-m "not gpu"`): the committed matrix equals a fresh extraction (when /root/reference is there), and a cross-section of it is BIT-EQUAL
     between the host build of the kernel sources and RendererRef -- raw, tonemapped, base colour and depth-normals (tools/material_matrix.py host
-    runs all ninety: profiles/r05/material_matrix_host.txt);
-  * GPU (`-m gpu`): all ninety through the C ABI within the stated tolerance of the oracle (tests/util.py)."""
+    runs all of them: profiles/r05/material_matrix_host.txt);
+  * GPU (`-m gpu`): all of them through the C ABI within the stated tolerance of the oracle (tests/util.py)."""
 import os
 import subprocess
 import sys
@@ -29,7 +29,7 @@ NAMES = [e["name"] for e in ENTRIES]
 CPU_SECTION = ["oren_mat1", "sheen_mat3", "aniso_mat5", "tint_mat1", "emit_mat0", "coat_mat1", "refr_mis1", "trans_mat4", "alpha_mat1", "alpha_mat4",
                "two_sided_mat", "complex_mat3", "complex_mat5_clipped", "complex_mat5_adaptive", "complex_mat5_regions", "complex_mat5_dof",
                "complex_mat5_mesh_lights", "complex_mat5_sphere_light", "complex_mat5_spot_light", "complex_mat5_dir_light", "complex_mat5_hdri_light",
-               "complex_mat7_refractive", "ray_flags"]
+               "complex_mat7_refractive", "ray_flags", "aux_channels"]
 
 
 @pytest.fixture(scope="module")
@@ -44,14 +44,14 @@ def assets():
 
 
 def test_the_committed_matrix_is_what_the_reference_says():
-    assert len(ENTRIES) == 90 and len(set(NAMES)) == 90
+    assert len(ENTRIES) == 91 and len(set(NAMES)) == 91  # (ninety of test_shading.cpp + test_aux_channels.cpp)
     assert set(CPU_SECTION) <= set(NAMES)
     src = "/root/reference/tests/test_shading.cpp"
     if not os.path.exists(src):
         pytest.skip("/root/reference is not here: the committed matrix stands")
     sys.path.insert(0, util.GOLDEN)
     import make_material_matrix
-    assert make_material_matrix.parse(src) == ENTRIES
+    assert make_material_matrix.parse_all(src) == ENTRIES
     # every scene variant of the reference's enum is in it, and every descriptor field is one the API mirror knows
     assert {e["scene"] for e in ENTRIES} == {"Standard", "Standard_NoLight", "Refraction_Plane", "Standard_MeshLights", "Two_Sided", "Standard_Clipped",
                                              "Standard_DOF0", "Standard_DOF1", "Standard_SphereLight", "Standard_InsideLight", "Standard_SpotLight",
@@ -67,6 +67,30 @@ def test_host_build_is_bit_equal_to_the_oracle(assets, name):
     m, _ = M.run_entry(entry, O.hostsim_context, 48, 48, spp_cap=(10 if name == "complex_mat5_adaptive" else 2))
     for buf in ("raw", "final", "base_color", "depth_normals"):
         assert m[buf]["equal"], (name, buf, m[buf])
+
+
+@pytest.mark.parametrize("name", ["two_sided_mat", "aux_channels", "ray_flags"])
+def test_a_scene_built_by_scene_hip_is_the_oracles_scene(assets, name):
+    """the same entry built twice -- by the oracle's scene class and by the product's (SceneHIP, no renderer and no GPU needed: scene construction
+    is host work), meshes added twice and one copy removed on both -- and the product's blob rendered by the host build: the oracle's frame, bit
+    for bit"""
+    from ray_amd import api
+    if not (O.have_hostsim() and os.path.exists(api.HIP_HOST_LIB)):
+        pytest.skip("tests/hostsim or libray_hip.so not built")
+    entry = ENTRIES[NAMES.index(name)]
+    w = h = 48
+    ref = O.create_renderer(w, h, "REF")
+    rs = ref.CreateScene()
+    M.build(rs, entry)
+    region = api.RegionContext((0, 0, w, h))
+    for _ in range(2):
+        ref.RenderScene(rs, region)
+    s = api.CreateSceneHIP()
+    M.build(s, entry)
+    assert s.triangle_count() == rs.triangle_count()
+    ctx = O.hostsim_context(w, h, api.export_scene_blob(s))
+    assert np.array_equal(util.render_frames(ctx, 2), ref.get_raw_pixels_ref())
+    assert np.array_equal(ctx.readback(hip.BUF_FINAL), ref.get_pixels_ref())
 
 
 @pytest.fixture(scope="module")
@@ -98,3 +122,29 @@ def test_device_against_the_oracle(assets, gpu_lib, name):
     for buf in ("base_color", "depth_normals"):
         assert m[buf]["frac_within"] >= util.MIN_FRACTION, (name, buf, m[buf])
     assert np.isfinite(raw["max_abs"])
+
+
+API_SECTION = ["complex_mat5_regions", "complex_mat5_adaptive", "complex_mat5_sun_light", "two_sided_mat", "complex_mat7_principled", "aux_channels",
+               "complex_mat5_unet_filter", "complex_mat6_unet_filter", "ray_flags"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", API_SECTION)
+def test_renderer_hip_as_the_reference_harness_drives_it(assets, gpu_lib, name):
+    """run_material_test's own sequence behind the Ray API on both sides (ref_material_scene.run_entry_through_the_api): the scene is built by
+    SceneHIP here, the sky of the sun-light variant baked on the device, and the three tests that end in the UNet filter run it (generated
+    weights on both sides: the network amplifies the last-bit differences of the two frames, and RendererHIP runs its f16 form -- the bar of
+    tests/test_gpu_unet.py)."""
+    from ray_amd import api
+    if not os.path.exists(api.HIP_HOST_LIB):
+        pytest.fail("ray_amd/host/_build/libray_hip.so is missing")
+    entry = ENTRIES[NAMES.index(name)]
+    m, (got, ref) = M.run_entry_through_the_api(entry, 96, 96, spp_cap=8)
+    if entry["denoise"] == "UNet":
+        err = np.abs(got[..., :3] - ref[..., :3]) / np.maximum(1.0, np.abs(ref[..., :3]))
+        assert err.max() <= 1e-1 and err.mean() <= 2e-3, (name, float(err.max()), float(err.mean()))
+        assert m["final"]["psnr"] >= 45.0, (name, m["final"])
+    else:
+        assert m["raw"]["frac_within"] >= util.MIN_FRACTION and m["raw"]["psnr"] >= util.MIN_PSNR_1SPP, (name, m["raw"])
+    for buf in ("base_color", "depth_normals"):
+        assert m[buf]["frac_within"] >= util.MIN_FRACTION, (name, buf, m[buf])
