@@ -93,6 +93,36 @@ def test_a_scene_built_by_scene_hip_is_the_oracles_scene(assets, name):
     assert np.array_equal(ctx.readback(hip.BUF_FINAL), ref.get_pixels_ref())
 
 
+TREE_FORMS = {"4-wide": {"HOSTSIM_BVH4": "1", "HOSTSIM_BVH8": "0"}, "8-wide, refined leaves": {"HOSTSIM_BVH4": "0", "HOSTSIM_BVH8": "1", "HOSTSIM_REFINE": "2"},
+              "rebuilt by the LBVH builder": {"HOSTSIM_LBVH": "4"}, "4-wide, refined leaves (the product's default)": {"HOSTSIM_BVH4": "1", "HOSTSIM_REFINE": "1"}}
+
+
+@pytest.mark.parametrize("name,form", [("complex_mat3", f) for f in TREE_FORMS] + [("ray_flags", "rebuilt by the LBVH builder"),
+                                                                                   ("ray_flags", "4-wide, refined leaves (the product's default)")])
+def test_every_tree_form_over_the_reference_meshes_is_bit_equal(assets, name, form, monkeypatch):
+    """the derived acceleration structures (quantised 4- and 8-wide nodes, leaves refined, both levels rebuilt from the triangle records by the
+    builder the device runs) over REAL asset meshes -- 77 762-triangle ball with its seams and slivers, non-uniformly scaled instances with
+    visibility masks: the oracle's frame bit for bit (the synthetic scenes of tests/test_hostsim_parity.py pin the same on generated geometry)"""
+    from ray_amd import api
+    if not O.have_hostsim():
+        pytest.skip("tests/hostsim not built")
+    for k in ("HOSTSIM_BVH4", "HOSTSIM_BVH8", "HOSTSIM_REFINE", "HOSTSIM_LBVH"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in TREE_FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    entry = ENTRIES[NAMES.index(name)]
+    w = h = 48
+    ref = O.create_renderer(w, h, "REF")
+    rs = ref.CreateScene()
+    M.build(rs, entry)
+    region = api.RegionContext((0, 0, w, h))
+    for _ in range(2):
+        ref.RenderScene(rs, region)
+    ctx = O.hostsim_context(w, h, O.export_scene(rs))
+    assert ctx.bvh_width() == (8 if form.startswith("8") else 4 if form.startswith("4") else 2)
+    assert np.array_equal(util.render_frames(ctx, 2), ref.get_raw_pixels_ref())
+
+
 @pytest.fixture(scope="module")
 def gpu_lib():
     import torch  # noqa: F401  (first: its HIP runtime opens the device)
@@ -148,3 +178,23 @@ def test_renderer_hip_as_the_reference_harness_drives_it(assets, gpu_lib, name):
         assert m["raw"]["frac_within"] >= util.MIN_FRACTION and m["raw"]["psnr"] >= util.MIN_PSNR_1SPP, (name, m["raw"])
     for buf in ("base_color", "depth_normals"):
         assert m[buf]["frac_within"] >= util.MIN_FRACTION, (name, buf, m[buf])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["complex_mat3", "ray_flags"])
+@pytest.mark.parametrize("mode,leaf_max", [("RAYHIP_REBUILD_BVH", "4"), ("RAYHIP_REFINE_LEAVES", "1")])
+def test_device_built_trees_over_the_reference_meshes(assets, gpu_lib, name, mode, leaf_max, monkeypatch):
+    """both levels rebuilt / the fat leaves refined BY THE DEVICE BUILDER (tests/test_gpu_bvh_build.py has it on generated scenes) over the
+    reference's asset meshes, against the oracle"""
+    monkeypatch.setenv(mode, leaf_max)
+    monkeypatch.delenv("RAYHIP_BVH_BUILD_ON_HOST", raising=False)
+    entry = ENTRIES[NAMES.index(name)]
+
+    def make(w, h, blob):
+        ctx = hip.Context(0, gpu_lib)
+        ctx.upload_static(util.pmj())
+        ctx.resize(w, h)
+        ctx.upload_scene_blob(blob)
+        return ctx
+    m, _ = M.run_entry(entry, make, 96, 96, spp_cap=8, batched=True, threads=max(1, min(16, os.cpu_count() or 1)))
+    assert m["raw"]["frac_within"] >= util.MIN_FRACTION and m["raw"]["psnr"] >= util.MIN_PSNR_8SPP, (name, mode, m["raw"])
