@@ -14,7 +14,6 @@ What cannot be the reference's here, and what stands in for it (every substituti
 The meshes and the textures that ARE in the checkout are staged by tests/golden/stage_ref_assets.py into tests/assets/_ref/ (git-ignored, it
 travels to the GPU box like oracle/_ref): /root/reference does not exist there."""
 import json
-import math
 import os
 import struct
 
