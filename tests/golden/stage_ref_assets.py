@@ -4,12 +4,13 @@ like oracle/_ref, because /root/reference does not exist there).
 
     python tests/golden/stage_ref_assets.py            # needs /root/reference; __graft_entry__.build() runs it when that exists
 
-Meshes (tests/test_data/meshes/mat_test/*.bin) and .dds files are byte copies of DATA files.  .tga files are decoded here once (run-length
-packets, tests/utils.cpp:116-159 + internal/TextureUtils.cpp:1753-1860 describe the layout the reference's loader produces) into the rows
-LoadTGA(flip_y = true) hands to AddTexture and stored as compressed .npz: a 2048 x 2048 run-length image takes seconds to decode in Python."""
+Everything is DATA, parsed here once and stored as the arrays the tests hand to the API, in compressed .npz containers (smaller to ship, and
+nothing to parse on the GPU box): meshes (tests/test_data/meshes/mat_test/*.bin, layout of tests/utils.cpp:72-114) -> meshes.npz with
+<name>.attrs / .indices / .groups; .dds -> the block data behind the 128-byte header + (w, h, mips, channels) (tests/utils.cpp:161-201); .tga
+-> RGB rows in the order LoadTGA(flip_y = true) hands to AddTexture (run-length packets, tests/utils.cpp:116-159 +
+internal/TextureUtils.cpp:1753-1860: a 2048 x 2048 run-length image takes seconds to decode in Python)."""
 import json
 import os
-import shutil
 import struct
 import sys
 
@@ -57,14 +58,20 @@ def decode_tga(path):
 def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (this container); on the GPU box the staged files arrive with the snapshot")
-    os.makedirs(os.path.join(OUT, "meshes"), exist_ok=True)
     os.makedirs(os.path.join(OUT, "textures"), exist_ok=True)
     staged = []
+    meshes = {}
     for name in sorted(os.listdir(os.path.join(REF, "meshes", "mat_test"))):
-        dst = os.path.join(OUT, "meshes", name)
-        if not os.path.exists(dst):
-            shutil.copyfile(os.path.join(REF, "meshes", "mat_test", name), dst)
+        with open(os.path.join(REF, "meshes", "mat_test", name), "rb") as f:
+            data = f.read()
+        n_attrs, n_idx, n_groups = struct.unpack_from("<III", data, 0)
+        stem = name[:-4]
+        meshes[stem + ".attrs"] = np.frombuffer(data, dtype=np.float32, count=n_attrs, offset=12)
+        meshes[stem + ".indices"] = np.frombuffer(data, dtype=np.uint32, count=n_idx, offset=12 + 4 * n_attrs)
+        meshes[stem + ".groups"] = np.frombuffer(data, dtype=np.uint32, count=n_groups, offset=12 + 4 * n_attrs + 4 * n_idx)
         staged.append("meshes/" + name)
+    if not os.path.exists(os.path.join(OUT, "meshes.npz")):
+        np.savez_compressed(os.path.join(OUT, "meshes.npz"), **meshes)
     with open(MATRIX) as f:
         wanted = sorted({t for e in json.load(f)["tests"] for t in e["textures"]})
     absent = []
@@ -74,9 +81,14 @@ def main():
             absent.append(name)
             continue
         if name.endswith(".dds"):
-            dst = os.path.join(OUT, "textures", name)
+            dst = os.path.join(OUT, "textures", name + ".npz")
             if not os.path.exists(dst):
-                shutil.copyfile(src, dst)
+                with open(src, "rb") as f:
+                    data = f.read()
+                h, w = struct.unpack_from("<II", data, 12)
+                mips = struct.unpack_from("<I", data, 28)[0]
+                channels = {b"DXT1": 3, b"DXT5": 4, b"ATI1": 1, b"BC4U": 1, b"ATI2": 2}[data[84:88]]
+                np.savez_compressed(dst, blocks=np.frombuffer(data, dtype=np.uint8, offset=128), shape=np.array([w, h, max(1, mips), channels]))
         else:
             dst = os.path.join(OUT, "textures", name + ".npz")
             if not os.path.exists(dst):

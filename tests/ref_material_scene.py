@@ -15,7 +15,6 @@ The meshes and the textures that ARE in the checkout are staged by tests/golden/
 travels to the GPU box like oracle/_ref): /root/reference does not exist there."""
 import json
 import os
-import struct
 
 import numpy as np
 
@@ -30,7 +29,7 @@ VIEW_TRANSFORM = {"Standard": 0, "AgX": 1, "Filmic_HighContrast": 8}  # Types.h:
 
 
 def have_assets() -> bool:
-    return os.path.exists(os.path.join(STAGED, "meshes", "model.bin"))
+    return os.path.exists(os.path.join(STAGED, "meshes.npz"))
 
 
 def matrix():
@@ -38,36 +37,33 @@ def matrix():
         return json.load(f)["tests"]
 
 
-# ---- files --------------------------------------------------------------------------------------------------------------------------
+# ---- staged files (tests/golden/stage_ref_assets.py parsed them) ----------------------------------------------------------------------------
+_MESHES = None
+
+
 def load_bin(name):
-    """tests/utils.cpp:72-114 (LoadBIN): u32 counts of attributes / indices / groups, then the three arrays"""
-    with open(os.path.join(STAGED, "meshes", name), "rb") as f:
-        data = f.read()
-    n_attrs, n_idx, n_groups = struct.unpack_from("<III", data, 0)
-    attrs = np.frombuffer(data, dtype=np.float32, count=n_attrs, offset=12)
-    idx = np.frombuffer(data, dtype=np.uint32, count=n_idx, offset=12 + 4 * n_attrs)
-    groups = np.frombuffer(data, dtype=np.uint32, count=n_groups, offset=12 + 4 * n_attrs + 4 * n_idx)
-    return attrs.reshape(-1, 8), idx, [int(g) for g in groups]
+    """what tests/utils.cpp:72-114 (LoadBIN) returns for mat_test/<name>: interleaved attributes (8 floats per vertex), indices, group ranges"""
+    global _MESHES
+    if _MESHES is None:
+        _MESHES = np.load(os.path.join(STAGED, "meshes.npz"))
+    stem = name[:-4]
+    return _MESHES[stem + ".attrs"].reshape(-1, 8), _MESHES[stem + ".indices"], [int(g) for g in _MESHES[stem + ".groups"]]
 
 
 def load_image(name):
-    """a staged .tga (decoded by the staging script into the row order LoadTGA(flip_y = true) hands to AddTexture): [h, w, 3] u8, or None"""
+    """a staged .tga in the row order LoadTGA(flip_y = true) hands to AddTexture: [h, w, 3] u8, or None when the checkout does not have the file"""
     p = os.path.join(STAGED, "textures", name + ".npz")
     return np.load(p)["rgb"] if os.path.exists(p) else None
 
 
 def load_dds(name):
-    """tests/utils.cpp:161-201 (LoadDDS): the blocks behind the 128-byte header with all their mip levels; None when the file is absent"""
-    p = os.path.join(STAGED, "textures", name)
+    """what tests/utils.cpp:161-201 (LoadDDS) returns: the blocks behind the header with all their mip levels, w, h, mips, channels; or None"""
+    p = os.path.join(STAGED, "textures", name + ".npz")
     if not os.path.exists(p):
         return None
-    with open(p, "rb") as f:
-        data = f.read()
-    h, w = struct.unpack_from("<II", data, 12)
-    mips = struct.unpack_from("<I", data, 28)[0]
-    fourcc = data[84:88]
-    channels = {b"DXT1": 3, b"DXT5": 4, b"ATI1": 1, b"BC4U": 1, b"ATI2": 2}[fourcc]
-    return np.frombuffer(data, dtype=np.uint8, offset=128), w, h, max(1, mips), channels
+    z = np.load(p)
+    w, h, mips, channels = (int(v) for v in z["shape"])
+    return z["blocks"], w, h, mips, channels
 
 
 def stand_in(name, role, res=512):
