@@ -52,6 +52,11 @@ def main():
         ctx.sync()
         times.append(time.perf_counter() - t0)
     dev = w * h * spp / min(times) / 1e6
+    ctx.clear()
+    ctx.stage_times(reset=True)
+    ctx.render_batch(1, spp, flags=hip.FLAG_TIME_STAGES)
+    ctx.sync()
+    stages = ctx.stage_times(reset=True)
     host = w * h * n_cpu / t_cpu / 1e6
     # parity of this very frame: the first 1 + n_cpu samples of both
     ctx.clear()
@@ -60,6 +65,7 @@ def main():
     m = util.frame_metrics(ctx.readback(hip.BUF_RAW), ref.get_raw_pixels_ref())
     print(f"{name} ({rs.triangle_count()} triangles in the scene's meshes; {'; '.join(notes)}), {w} x {h}:")
     print(f"  device: {spp} spp in {min(times) * 1e3:.1f} ms (best of 3: {', '.join(f'{t * 1e3:.1f}' for t in times)}) = {dev:.1f} Msamples/s")
+    print("  stages, ms per frame (stats_t counts microseconds): " + "  ".join(f"{k} {v / 1e3:.1f}" for k, v in stages.items() if v))
     print(f"  reference {kind} backend, {threads} threads: {n_cpu} spp in {t_cpu:.1f} s after a 1-spp warm-up ({t1:.2f} s) = {host:.2f} Msamples/s  -> x{dev / host:.0f}")
     print(f"  parity at {1 + n_cpu} spp against RendererRef: {m['frac_within'] * 100:.4f} % within tolerance, {m['psnr']:.1f} dB, {m['exact'] * 100:.1f} % of the pixels bit-equal")
 
