@@ -385,28 +385,40 @@ def main():
     # the exchange step: the product's collective (RCCL behind the C ABI); torch.distributed only hands the id around
     comm = None
     comm_error = None
+    comm_info = None
     if dist is not None and not emulated:
-        # Every rank must end up on the same transport: a rank that cannot form the communicator (no librccl for dlopen, an RCCL that
-        # refuses the id) says so, the ranks agree by an all-reduce, and then ALL of them move the same packed tiles with torch.distributed's
-        # gather over its own RCCL instead (multigpu.exchange_frame) -- the line says which one ran ("exchange").
-        try:
-            ids = [hip.Comm.unique_id(ctx.L) if rank == 0 else None]
-        except RuntimeError as e:
-            ids, comm_error = [None], str(e)
-        dist.broadcast_object_list(ids, src=0)
-        if ids[0] is not None:
+        # Every rank must end up on the same transport, and NO rank may enter ncclCommInitRank (collective: it returns when all ranks are in it)
+        # unless all of them will.  So: each rank probes RCCL locally (dlopen + symbols: rayhip_comm_probe; rank 0 also makes the id), the ranks
+        # agree on the outcome by an all-reduce(MIN), and only then create their rank.  A job that cannot form the product's communicator is an
+        # ERROR -- a SCALE line must never quietly measure another exchange -- unless RAY_AMD_ALLOW_FALLBACK=1 asks for torch.distributed's
+        # gather of the same packed tiles (multigpu.exchange_frame); the line's top-level "transport" says which one ran.
+        comm_error = hip.Comm.probe(ctx.L) or None
+        ids = [None]
+        if rank == 0 and comm_error is None:
             try:
-                comm = hip.Comm.for_rank(ctx.L, ids[0], world, rank, ctx)
+                ids = [hip.Comm.unique_id(ctx.L)]
             except RuntimeError as e:
                 comm_error = str(e)
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+        ok = torch.tensor([0 if comm_error else 1], dtype=torch.int32, device=f"cuda:{local_rank}")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            dist.broadcast_object_list(ids, src=0)
+            try:
+                comm = hip.Comm.for_rank(ctx.L, ids[0], world, rank, ctx)
+                comm_info = comm.info()
+            except RuntimeError as e:  # (after the collective: every rank that got here has left it)
+                comm_error = str(e)
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             if comm is not None:
                 comm.close()
                 comm = None
-            print(f"bench.py rank {rank}: rayhip_comm unavailable ({comm_error or 'on another rank'}); the tiles go through torch.distributed",
-                  file=sys.stderr)
+            why = f"bench.py rank {rank}: rayhip_comm unavailable ({comm_error or 'on another rank'})"
+            if os.environ.get("RAY_AMD_ALLOW_FALLBACK") != "1":
+                dist.destroy_process_group()
+                raise SystemExit(why + "; refusing to measure another transport (RAY_AMD_ALLOW_FALLBACK=1 moves the tiles with torch.distributed)")
+            print(why + "; RAY_AMD_ALLOW_FALLBACK=1: the tiles go through torch.distributed", file=sys.stderr)
 
     def exchange():
         if dist is not None:
@@ -606,7 +618,11 @@ def main():
             out["exchange"] = ("owned tiles through host memory over gloo (ranks share a device: RCCL cannot form the communicator)" if emulated else
                                "rayhip_comm_reduce_framebuffers: owned tiles (1/N of the frame per rank) point-to-point to rank 0 over RCCL"
                                if comm is not None else
-                               "torch.distributed gather of the owned tiles over RCCL (rayhip_comm could not be formed: see stderr)")
+                               "torch.distributed gather of the owned tiles over RCCL (rayhip_comm could not be formed, RAY_AMD_ALLOW_FALLBACK=1: see stderr)")
+            # top level, for whoever reads a SCALE record: which transport moved the tiles, what RCCL says the communicator is, every rank's time
+            out["transport"] = "gloo-host (emulated ranks)" if emulated else ("rayhip_comm/rccl" if comm is not None else "torch.distributed/rccl (fallback)")
+            out["ncclCommCount"] = comm_info["nccl_comm_count"] if comm_info else None
+            out["render_ms_per_rank"] = rank_times["render_ms"]
         if emulated:
             out["emulated_ranks"] = True
             out["devices"] = n_dev

@@ -521,6 +521,11 @@ enum {
     RAYHIP_REDUCE_ALL = 15u
 };
 RAYHIP_API int rayhip_comm_create(int ndev, const int *devices, rayhip_comm **out_comm);
+/* rayhip_comm_probe: 0 if this process can load RCCL with every symbol the exchange uses -- local, NOT collective: the ranks of a job agree on
+ * it before any of them calls rayhip_comm_create_rank (which blocks until all have).  rayhip_comm_info: out[0] = ranks, out[1] = (first) local
+ * rank, out[2] = ncclCommCount as RCCL reports it (-1: in-process form), out[3] = 1 for the in-process (peer copy) transport. */
+RAYHIP_API int rayhip_comm_probe(void);
+RAYHIP_API int rayhip_comm_info(rayhip_comm *comm, int out[4]);
 RAYHIP_API int rayhip_comm_unique_id(void *out_id, size_t size);
 RAYHIP_API int rayhip_comm_create_rank(const void *unique_id, int nranks, int rank, rayhip_ctx *ctx, rayhip_comm **out_comm);
 RAYHIP_API int rayhip_comm_bind(rayhip_comm *comm, int rank, rayhip_ctx *ctx);

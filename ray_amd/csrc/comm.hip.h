@@ -212,6 +212,24 @@ int rayhip_comm_create(int ndev, const int *devices, rayhip_comm **out) {
     return 0;
 }
 
+// Can this process form the one-process-per-GPU communicator at all?  LOCAL and non-collective (dlopen + symbol resolution): the ranks of a job
+// ask this first and agree on the answer before any of them enters ncclCommInitRank, which only returns when every rank has entered it
+// (a rank that failed before the collective left the others waiting in it).
+int rayhip_comm_probe(void) { return load_rccl(); }
+
+// What the communicator is, as the transport itself reports it: out[0] = ranks, out[1] = first local rank, out[2] = ncclCommCount of the first
+// local RCCL communicator (-1 for the in-process form, which has none), out[3] = 1 if the transport is peer copies inside one process
+int rayhip_comm_info(rayhip_comm *m, int out[4]) {
+    if (!m || !out) {
+        return fail("rayhip_comm_info: bad arguments");
+    }
+    out[0] = m->nranks, out[1] = m->local.empty() ? -1 : m->local[0], out[2] = -1, out[3] = m->in_process ? 1 : 0;
+    if (!m->in_process && !m->comms.empty() && m->comms[0]) {
+        RCCL_TRY(g_rccl.CommCount(m->comms[0], &out[2]));
+    }
+    return 0;
+}
+
 int rayhip_comm_unique_id(void *out_id, size_t size) {
     if (!out_id || size < sizeof(ncclUniqueId)) {
         return fail("rayhip_comm_unique_id needs a buffer of %zu bytes", sizeof(ncclUniqueId));

@@ -149,9 +149,21 @@ struct rayhip_ctx {
     // wavefront state, sized w*h
     DevBuf ray_planes[2][5], hit_planes[2], shadow_planes[3], deferred_planes[2], point_planes[7], nee_index;
     PointSoA points = {};
+    // round 6 (shade_split bit 4): the picks of the light pick that runs before the surface stage, by ray slot and stamped with the launch's tag;
+    // the ray's part of a next-event record (shade_launch.h)
+    DevBuf pick_plane, record_ray_planes[4];
+    RaySoA record_rays = {};
+    uint32_t shade_tag = 0;
+    uint32_t next_shade_tag() {
+        if (++shade_tag == 0u) { // (2^32 launches later: the plane may hold every old tag -- clear it and start again)
+            (void)hipMemsetAsync(pick_plane.p, 0, pick_plane.bytes, stream);
+            shade_tag = 1u;
+        }
+        return shade_tag;
+    }
     // how the shade stage is cut into launches (kernels.hip.h): bit 0 = the light pick as its own kernel, bit 1 = next-event
     // estimation and continuation as two scatter launches.  RAYHIP_SHADE_SPLIT overrides (A/B measurements).
-    int shade_split = 13; // shade_launch.h: bit 0 pick as its own kernel, bit 1 NEE / continuation as two launches, bit 2 NEE over the compacted queue of points that got a light, bit 3 the light pick with lane refill
+    int shade_split = 29; // shade_launch.h: bit 4 (round 6, the default) pick first -> surface + continuation fused -> next-event estimation over dense records; without it: bit 0 pick as its own kernel, bit 1 NEE / continuation as two launches, bit 2 NEE over the compacted queue of points that got a light, bit 3 the light pick with lane refill
     RaySoA rays[2] = {};
     HitSoA hits = {};
     ShadowSoA shadow = {};
@@ -377,6 +389,16 @@ int alloc_frame(rayhip_ctx *c, int w, int h, int layers) {
         return 1;
     }
     c->points.nee_index = c->nee_index.as<uint32_t>();
+    if (c->pick_plane.alloc(n * 16)) {
+        return 1;
+    }
+    for (int pl = 0; pl < 4; ++pl) {
+        if (c->record_ray_planes[pl].alloc(n * (pl == 3 ? 8 : 16))) {
+            return 1;
+        }
+    }
+    c->record_rays.o_pdf = nullptr, c->record_rays.d_cw = c->record_ray_planes[0].as<float4>(), c->record_rays.c_cs = c->record_ray_planes[1].as<float4>();
+    c->record_rays.ior = c->record_ray_planes[2].as<float4>(), c->record_rays.xy_depth = c->record_ray_planes[3].as<uint2>();
     if (c->sky_index.alloc(n * 4)) {
         return 1;
     }
@@ -568,7 +590,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
         c->sort_key_mode = std::max(0, std::min(3, atoi(e)));
     }
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
-        c->shade_split = atoi(e) & 15;
+        c->shade_split = atoi(e) & 31;
     }
     // The persistent ray-refill form of the closest-hit kernel (kernels_closest_refill.hip.h): lanes whose ray is finished fetch the next one
     // instead of idling until the longest walk of their wavefront ends.  RAYHIP_REFILL: 2 = for the secondary
@@ -717,6 +739,10 @@ void rayhip_ctx_destroy(rayhip_ctx *c) {
         b.release();
     }
     c->nee_index.release();
+    c->pick_plane.release();
+    for (DevBuf &b : c->record_ray_planes) {
+        b.release();
+    }
     for (auto &up : c->unet_pass) { // (the UNet's weights and its fifteen tensors -- 1.3 GB at 1080p -- were leaked)
         up.weights.release();
         up.weights_h.release();

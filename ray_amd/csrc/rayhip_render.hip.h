@@ -43,6 +43,7 @@ static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration,
     a.out_sky = c->sky_queue(bounce, nslots, stripes), a.sky_index = c->sky_index.as<uint32_t>();
     a.px = c->px, a.layers = layers, a.vw = vw, a.mix_factor = mix_factor;
     a.bounce = bounce, a.grid = gtrace, a.split = c->shade_split, a.stream = c->stream;
+    a.picks = c->pick_plane.as<float4>(), a.record_rays = c->record_rays, a.tag = c->next_shade_tag();
     if (sized) { // a pass (not a kernel-level hook): grids from the queue census, the persistent pick with a work counter
         a.expect[EXPECT_RAYS] = bounce == 0 ? uint32_t(nslots / WAVE + stripes) : c->expect_chunks(bounce, 0, nslots, stripes);
         a.expect[EXPECT_POINTS] = c->expect_chunks(bounce, 3, nslots, stripes), a.expect[EXPECT_LIT] = c->expect_chunks(bounce, 4, nslots, stripes);

@@ -58,6 +58,12 @@ namespace shade {
 #ifndef RT_SCATTER_MIN_WAVES
 #define RT_SCATTER_MIN_WAVES 4
 #endif
+// k_surface_scatter holds the ray across the surface stage and the point across the continuation: ~175 registers at its peak.  Three
+// waves (168 VGPRs, no spills) against four (128 + 130 bytes of scratch) / five: 1.24 / 1.50 / 2.21 ms per iteration (Bistro-class,
+// profiles/r06/experiments/shade_fused_variants.txt)
+#ifndef RT_FUSED_MIN_WAVES
+#define RT_FUSED_MIN_WAVES 3
+#endif
 // the two halves of the split form hold less than the combined kernel: their own budgets
 #ifndef RT_SCATTER_NEE_MIN_WAVES
 #define RT_SCATTER_NEE_MIN_WAVES 4
@@ -406,6 +412,200 @@ __global__ void __launch_bounds__(WAVE, (NEE && CONTINUE) ? RT_SCATTER_MIN_WAVES
     }
 }
 
+// ---- round 6: the stage without the queue of shade points ---------------------------------------------------------------------------
+// What the three-kernel form moves per path vertex (Bistro-class, profiles/r05/kernel_hbm_bistro.txt): k_surface writes the point (96 B),
+// the pick reads 24 B of it and writes a 16-byte pick into a 64-byte line, the next-event kernel gathers the 18 % of the points that got a
+// light through an index (16-byte reads out of 64-byte lines: 124 GB fetched for ~30 used), the continuation reads the point again with
+// 40 B of the ray -- ~880 B, and the continuation alone already runs at the rate a plain copy reaches (4.3 TB/s on bounce 0).  The stage
+// is bound by those bytes, not by its arithmetic (profiles/r06/experiments: contraction changes nothing, dropping the microfacet draws
+// 17 % of one kernel).  So the order of the parts changes:
+//   k_light_pick_first   the light pick BEFORE the surface stage.  The descent needs the position only, and that is ray.o + hit.t * ray.d
+//                        (shade_point.h: pt.P) -- the same two IEEE operations here.  Persistent, lanes refilled as in k_light_pick_refill.
+//                        A pick is written only for a ray that GOT a light (18 %), stamped with the tag of this launch: the other slots of
+//                        the plane keep whatever they held, with an older tag.
+//   k_surface_scatter    surface stage and continuation in one kernel: the point never leaves the registers.  A lane whose slot of the pick
+//                        plane carries the launch's tag appends what the next-event estimation needs -- point, pick, the ray's direction,
+//                        throughput, pixel, depth -- to a dense list (`nee` queue, coalesced stores).
+//   k_scatter<NEE only>  over that list: coalesced reads, full wavefronts.
+// ~380 B per vertex instead of ~880.  Per path vertex every stage function gets the arguments it got before (surface_stage, pick_light's
+// levels, scatter_stage<false, true>, scatter_stage<true, false>): frames are bit-identical to the three-kernel form
+// (test_shade_forms_agree_bit_for_bit); only the order of the lists differs, which no pixel sees.
+template <bool DYN>
+__global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick_first(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
+                                                                             const RayQueue queue, float4 *__restrict__ picks, const uint32_t tag,
+                                                                             const Layering layers, uint32_t *__restrict__ work) {
+    const uint32_t lane = threadIdx.x;
+    ChunkWalk walk(queue.live_chunks(), DYN ? work : nullptr, RT_PICK_RUN);
+    uint32_t pool_slot = 0, pool_left = 0; // (uniform) the chunk being handed out
+    bool exhausted = false;                // (uniform) no chunk left to hand out
+    bool busy = false;
+    uint32_t i = 0, cur = 0;
+    f3 P = {0.0f, 0.0f, 0.0f};
+    float u = 0.0f, prob = 1.0f;
+    for (;;) {
+        const int n_idle = __popcll(__ballot(!busy));
+        if (!exhausted && n_idle >= RT_PICK_REFILL_MIN) {
+            for (;;) {
+                const unsigned long long idle_mask = __ballot(!busy);
+                if (idle_mask == 0ull) {
+                    break;
+                }
+                if (pool_left == 0) {
+                    int found = 0;
+                    uint32_t next_chunk;
+                    while (!found && walk.next(next_chunk)) { // (uniform)
+                        uint32_t s, slot0, n_live;
+                        found = __builtin_amdgcn_readfirstlane(int(queue.chunk(next_chunk, s, slot0, n_live)));
+                        if (found) {
+                            pool_slot = uint32_t(__builtin_amdgcn_readfirstlane(int(slot0)));
+                            pool_left = uint32_t(__builtin_amdgcn_readfirstlane(int(n_live)));
+                        }
+                    }
+                    if (!found) {
+                        exhausted = true;
+                        break;
+                    }
+                }
+                const uint32_t rank = uint32_t(__popcll(idle_mask & ((1ull << lane) - 1ull)));
+                const uint32_t n_take = min(uint32_t(__popcll(idle_mask)), pool_left);
+                if (!busy && rank < n_take) {
+                    i = pool_slot + rank;
+                    const float4 h = hits.oi_pi_t_u[i];
+                    // a triangle was hit (misses carry v < 0, analytic emitters a negative object): everything else ends in k_surface_scatter
+                    // without asking for a light.  (A triangle whose path ends there too -- culled back face, emissive material -- gets a
+                    // pick nobody reads.)
+                    if (hits.v[i] >= 0.0f && float_as_int(h.x) >= 0) {
+                        const float4 o = rays_in.o_pdf[i], d = rays_in.d_cw[i];
+                        const uint2 xd = rays_in.xy_depth[i];
+                        const uint32_t layer = xy_layer(xd.x, layers);
+                        const ShadeParams spl = layer_params(sp, layer);
+                        P = f3{o.x, o.y, o.z} + h.z * f3{d.x, d.y, d.z}; // == ShadePoint::P (shade_point.h)
+                        u = light_pick_random(sc, spl, xy_real(xd.x, layers, layer), xd.y);
+                        prob = 1.0f, cur = 0;
+                        busy = true;
+                    }
+                }
+                pool_slot += n_take, pool_left -= n_take;
+            }
+        }
+        if (__ballot(busy) == 0ull) {
+            if (exhausted) {
+                break;
+            }
+            continue; // (every lane idle: the next round refills)
+        }
+        if (busy) { // one level of the descent (pick_light, shade_lights.h)
+            float imp[8];
+            light_node_importances(sc, cur, P, imp);
+            int chosen;
+            if (!light_level_choice(imp, u, prob, chosen)) {
+                busy = false; // nothing in this subtree can light P: no pick is written
+            } else {
+                cur = light_child_link(sc, cur, chosen);
+                if ((cur & LEAF_NODE_BIT) != 0) {
+                    picks[i] = mkfloat4(uint_as_float(cur & PRIM_INDEX_BITS), 1.0f / prob, u, uint_as_float(tag));
+                    busy = false;
+                }
+            }
+        }
+    }
+}
+
+template <bool PRIMARY, bool SKY>
+__global__ void __launch_bounds__(WAVE, RT_FUSED_MIN_WAVES) k_surface_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
+                                                                               const RayQueue in, const float4 *__restrict__ picks, const uint32_t tag,
+                                                                               const PointSoA records, const RaySoA record_rays, const RayQueue out_records,
+                                                                               const RaySoA rays_out, const RayQueue out_rays,
+                                                                               const DeferredSoA deferred_out, const RayQueue out_deferred,
+                                                                               const PixelBuffers px, const int img_w, const float mix_factor,
+                                                                               const Layering layers, uint32_t *__restrict__ sky_index, const RayQueue out_sky) {
+    const uint32_t n_live_chunks = in.live_chunks();
+    ChunkWalk walk(n_live_chunks);
+    for (uint32_t c; walk.next(c);) {
+        uint32_t stripe, slot0, n_live;
+        if (!in.chunk(c, stripe, slot0, n_live)) {
+            continue;
+        }
+        const uint32_t i = slot0 + threadIdx.x; // (the whole wavefront stays in the body for the ballots)
+        const bool active = threadIdx.x < n_live;
+        bool continues = false, defer = false, sky = false, lit = false;
+        ShadePoint pt;
+        SurfaceOut so;
+        Ray ray;
+        ShadeParams spl = sp;
+        uint32_t xy = 0;
+        float4 pick = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (active) {
+            ray = load_ray(rays_in, i, sp.plain_ior == 0u);
+            const Hit hit = load_hit(hits, i);
+            xy = ray.xy; // virtual (layered) pixel: where the pixel writes go
+            const uint32_t layer = xy_layer(xy, layers);
+            spl = layer_params(sp, layer);
+            ray.xy = xy_real(xy, layers, layer);
+            continues = surface_stage<true, SKY>(sc, spl, hit, ray, pt, so); // (emitter MIS weights: k_shade_emissive)
+            defer = so.deferred_emitter;
+            sky = SKY && so.deferred_sky;
+            if (PRIMARY) {
+                ShadeResult res;
+                res.col = continues ? f4{0.0f, 0.0f, 0.0f, 1.0f} : so.radiance;
+                res.base_color = so.base_color, res.depth_normal = so.normal_depth;
+                if (layers.count > 1) {
+                    write_primary_pixel_layered(res, xy, img_w, px.temp, px.aux_base_layers, px.aux_dn_layers);
+                } else {
+                    write_primary_pixel(res, xy, img_w, mix_factor, px.temp, px.base_color, px.depth_normals);
+                }
+            } else if (!continues) {
+                ShadeResult res;
+                res.col = so.radiance;
+                add_secondary_pixel(res, xy, img_w, px.temp);
+            }
+            if (continues && sc.light_cwnodes_count != 0) {
+                pick = picks[i];
+                lit = float_as_uint(pick.w) == tag;
+            }
+        }
+        // what the next-event estimation needs of a lit point, densely in the `nee` queue of its stripe
+        const uint32_t r_slot = out_records.alloc(stripe, lit);
+        if (lit) {
+            store_point(records, r_slot, pt, r_slot); // (its "ray slot" is the record's own: record_rays holds the ray's part)
+            records.light[r_slot] = pick;
+            record_rays.d_cw[r_slot] = mkfloat4(ray.d.x, ray.d.y, ray.d.z, ray.cone_width);
+            record_rays.c_cs[r_slot] = mkfloat4(ray.c.x, ray.c.y, ray.c.z, ray.cone_spread);
+            if (sp.plain_ior == 0u) {
+                record_rays.ior[r_slot] = mkfloat4(ray.ior[0], ray.ior[1], ray.ior[2], ray.ior[3]);
+            }
+            uint2 xd;
+            xd.x = xy, xd.y = ray.depth;
+            record_rays.xy_depth[r_slot] = xd;
+        }
+        if (SKY) { // the physical sky: paths that ended in it wait for k_shade_sky (their pixel got zeros above)
+            const uint32_t s_slot = out_sky.alloc(stripe, sky);
+            if (sky) {
+                sky_index[s_slot] = i;
+            }
+        }
+        if (__any(defer)) { // rare
+            const uint32_t d_slot = out_deferred.alloc(stripe, defer);
+            if (defer) {
+                deferred_out.a[d_slot] = mkfloat4(uint_as_float(i), uint_as_float(so.emitter_triangle), uint_as_float(pt.material), so.emitter_mix_weight);
+                deferred_out.b[d_slot] = mkfloat4(pt.base.x, pt.base.y, pt.base.z, 0.0f);
+            }
+        }
+        // the continuation, from the registers
+        Scatter sct;
+        sct.has_next = sct.has_shadow = false;
+        if (continues) {
+            ray.o = pt.P, ray.pdf = 0.0f; // (what k_scatter hands the stage: neither is read by it)
+            scatter_stage<false, true>(sc, spl, ray, pt, no_light_pick(), sct);
+            sct.next.xy = xy;
+        }
+        const uint32_t n_slot = out_rays.alloc(stripe, sct.has_next);
+        if (sct.has_next) {
+            store_ray(rays_out, n_slot, sct.next, sp.plain_ior == 0u);
+        }
+    }
+}
+
 // MIS-weighted radiance of importance-sampled emitters that secondary rays hit (shade_point.h: emissive_hit_mis_weight): a
 // light-tree walk + a spherical-triangle density per hit -- rare, but every wavefront containing one used to pay for it.
 // Runs after k_surface of the same bounce on the ray / hit buffers that kernel read; such a path ends there (k_surface booked
@@ -511,6 +711,46 @@ void launch(const ShadeLaunch &a) {
         return grid;
     };
     const int all = 1 << 30;
+    if ((a.split & 16) != 0) { // round 6: pick first, surface + continuation in one kernel, next-event estimation over dense records
+        const bool lights = a.sc.light_cwnodes_count != 0;
+        if (lights) {
+            auto go = [&](auto kernel) {
+                int grid = sized(kernel, a.expect[EXPECT_RAYS], all);
+                if (a.work) {
+                    const int resident = std::max(1, resident_blocks(reinterpret_cast<const void *>(kernel))) * std::max(1, a.dyn_mult);
+                    const uint32_t bound = a.expect[EXPECT_RAYS] != 0u ? a.expect[EXPECT_RAYS] : a.chunks;
+                    grid = int(std::max<uint32_t>(1u, std::min<uint32_t>({uint32_t(g), uint32_t(resident), std::max(bound, 1u)})));
+                }
+                kernel<<<grid, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.picks, a.tag, a.layers, a.work);
+            };
+            a.work ? go(k_light_pick_first<true>) : go(k_light_pick_first<false>);
+        }
+#define RT_FUSED(...) k_surface_scatter<__VA_ARGS__><<<sized(k_surface_scatter<__VA_ARGS__>, a.expect[EXPECT_RAYS], all), WAVE, 0, s>>>( \
+        a.sc, a.sp, a.rays_in, a.hits, a.in, a.picks, a.tag, a.points, a.record_rays, a.nee, a.rays_out, a.out_rays, a.deferred, a.out_deferred, a.px, a.vw, \
+        a.mix_factor, a.layers, a.sky_index, a.out_sky)
+        const bool sky_scene = a.sc.sky.desc != nullptr;
+        if (a.bounce == 0) {
+            if (sky_scene) {
+                RT_FUSED(true, true);
+            } else {
+                RT_FUSED(true, false);
+            }
+        } else if (sky_scene) {
+            RT_FUSED(false, true);
+        } else {
+            RT_FUSED(false, false);
+        }
+#undef RT_FUSED
+        if (sky_scene) {
+            k_shade_sky<<<sized(k_shade_sky, a.expect[EXPECT_SKY], 4096), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.sky_index, a.out_sky, a.px, a.vw, a.layers);
+        }
+        k_shade_emissive<<<sized(k_shade_emissive, a.expect[EXPECT_DEFERRED], 2048), WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.deferred, a.out_deferred, a.px, a.vw);
+        if (lights) { // the records name themselves as their ray slot: the ray's part comes from record_rays
+            k_scatter<true, false><<<sized(k_scatter<true, false>, a.expect[EXPECT_LIT], all), WAVE, 0, s>>>(
+                a.sc, a.sp, a.record_rays, a.points, a.nee, a.rays_out, a.out_rays, a.shadow, a.out_shadow, a.px, a.vw, a.layers, a.pts, a.nee);
+        }
+        return;
+    }
     const bool pick_apart = (a.split & 1) != 0 && a.sc.light_cwnodes_count != 0;
     // stage 1: what was hit (SKY: the environment is the physical sky -- narrow rays that leave the scene are queued for k_shade_sky)
 #define RT_SURFACE_ARGS a.sc, a.sp, a.rays_in, a.hits, a.in, a.points, a.pts, a.deferred, a.out_deferred, a.px, a.vw, a.mix_factor, a.layers, a.sky_index, a.out_sky

@@ -42,7 +42,14 @@ struct ShadeLaunch {
     uint32_t *work = nullptr;             // the persistent light pick: zeroed counter of the dynamic chunk hand-out (wavefront.hip.h), or null
     uint32_t chunks = 0;                  // upper bound of the chunks a queue of the pass holds (slots / 64)
     int dyn_mult = 1;                     // with `work`: blocks per resident wave slot
-    int split;        // bit 0: the light pick as its own kernel; bit 1: next-event estimation and continuation as two launches;
+    // round 6 (split bit 4): the light pick runs first and leaves its picks in a plane indexed by RAY slot, stamped with `tag` (unique per launch
+    // of the stage, never 0; the plane starts zeroed); k_surface_scatter lists what the next-event estimation needs of a lit point in the point
+    // planes + `record_rays` (direction | cone width, throughput | cone spread, ior stack, pixel | depth: the planes of a RaySoA, o_pdf unused)
+    float4 *picks = nullptr;
+    uint32_t tag = 0;
+    RaySoA record_rays = {};
+    int split;        // bit 4: pick -> surface + continuation in one kernel -> next-event estimation over dense records (shade_kernels.hip, round 6);
+                      // otherwise  bit 0: the light pick as its own kernel; bit 1: next-event estimation and continuation as two launches;
                       // bit 2 (with bit 0): next-event estimation as its own launch over the points that GOT a light, densely packed;
                       // bit 3 (with bit 0): the light pick as a persistent kernel whose lanes take the next point when theirs is through
     hipStream_t stream;

@@ -79,7 +79,7 @@ ENTRY_POINTS = (
     "scene_upload", "bake_sky", "bake_sky_blob", "scene_bvh_width", "closest_hit_form", "scene_upload_blob", "scene_update_instances", "scene_update_instances_blob", "set_filter_table", "render", "render_batch", "max_batch", "reserve_batch", "set_tonemap_lut", "denoise_nlm", "readback", "readback_device", "set_raw_device",
     "sync", "set_shard", "get_trav_counters", "get_trav_timing", "get_stage_times", "k_generate_primary_rays", "k_intersect_closest",
     "k_intersect_shadow", "k_scrambled_rand", "k_shade",
-    "comm_create", "comm_unique_id", "comm_create_rank", "comm_bind", "comm_reduce_framebuffers", "comm_destroy",
+    "comm_create", "comm_probe", "comm_info", "comm_unique_id", "comm_create_rank", "comm_bind", "comm_reduce_framebuffers", "comm_destroy",
     "unet_init", "denoise_unet", "unet_set_precision", "unet_read_tensor",
     "export_shard_device", "owned_bytes", "export_owned", "import_owned", "finish_import",
 )
@@ -151,6 +151,8 @@ class Library:
             f("export_shard_device").argtypes = [vp, C.c_int, vp]
             f("comm_create").argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
             f("comm_unique_id").argtypes = [vp, C.c_size_t]
+            f("comm_probe").argtypes = []
+            f("comm_info").argtypes = [vp, C.POINTER(C.c_int * 4)]
             f("comm_create_rank").argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
             f("comm_bind").argtypes = [vp, C.c_int, vp]
             f("comm_reduce_framebuffers").argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(Camera)]
@@ -442,6 +444,18 @@ class Comm:
             return
         devs = (C.c_int * len(devices))(*devices)
         self.L.check(self.L.fn("comm_create")(len(devices), devs, C.byref(self._h)))
+
+    @staticmethod
+    def probe(library: Library) -> str:
+        """'' if this process can load RCCL with every symbol the exchange needs, else the reason -- local, not collective"""
+        if library.fn("comm_probe")() == 0:
+            return ""
+        return (library.fn("last_error")() or b"RCCL unavailable").decode()
+
+    def info(self) -> dict:
+        out = (C.c_int * 4)()
+        self.L.check(self.L.fn("comm_info")(self._h, C.byref(out)))
+        return {"nranks": out[0], "rank": out[1], "nccl_comm_count": out[2], "in_process": bool(out[3])}
 
     @staticmethod
     def unique_id(library: Library) -> bytes:

@@ -435,7 +435,7 @@ def test_light_pick_with_lane_refill_is_bit_identical(gpu_lib, name, monkeypatch
     """the light pick as a persistent kernel whose lanes take the next point when their descent is over (k_light_pick_refill, the
     default) against the chunk-at-a-time kernel: per point the same descent, so every image is the same bits (the list of lit
     points comes out in another order, which no pixel can see)"""
-    monkeypatch.setenv("RAYHIP_SHADE_SPLIT", "5")
+    monkeypatch.setenv("RAYHIP_SHADE_SPLIT", "5")  # (against round 6's default too: the pick runs before the surface stage there)
     chunked = util.make_context(gpu_lib, name)
     monkeypatch.delenv("RAYHIP_SHADE_SPLIT")
     default = util.make_context(gpu_lib, name)
@@ -565,7 +565,7 @@ def test_shade_forms_agree_bit_for_bit(gpu_lib, name, monkeypatch):
     chosen on the device) group the same per-point arithmetic differently: frames, aux images and the kernel-level shade
     outputs must be the same bits"""
     frames = {}
-    for split in ("0", "1", "3", "5"):
+    for split in ("0", "1", "3", "5", "13", "29"):  # (29: round 6's default -- pick first, surface + continuation fused, NEE over dense records)
         monkeypatch.setenv("RAYHIP_SHADE_SPLIT", split)
         ctx = util.make_context(gpu_lib, name)
         ctx.render_batch(1, 5)
@@ -585,7 +585,7 @@ def test_sparse_lights_take_the_split_form(gpu_lib, monkeypatch):
     scenes.atrium(s, 0.02)
     blob = api.export_scene_blob(s)
     frames = {}
-    for split in ("1", "5"):
+    for split in ("1", "5", "29"):
         monkeypatch.setenv("RAYHIP_SHADE_SPLIT", split)
         ctx = hip.Context(0, gpu_lib)
         ctx.upload_static(util.pmj())
@@ -594,6 +594,7 @@ def test_sparse_lights_take_the_split_form(gpu_lib, monkeypatch):
         ctx.render_batch(1, 4)
         frames[split] = ctx.readback(hip.BUF_RAW)
     assert np.array_equal(frames["1"], frames["5"])
+    assert np.array_equal(frames["1"], frames["29"])
     assert float(frames["5"].sum()) > 0.0
 
 
