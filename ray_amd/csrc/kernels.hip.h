@@ -630,12 +630,13 @@ __global__ void __launch_bounds__(256) k_nlm_filter(const DenoiseParams p, const
 // per-triangle vertex table (shade_point.h: fill_tri_verts) from the vertex and index arrays already in HBM: one thread per
 // triangle, the same function the host build runs (IEEE operations: the same bits)
 __global__ void __launch_bounds__(256) k_fill_tri_verts(const rayhip_vertex *__restrict__ vertices, const uint32_t vertices_count,
-                                                       const uint32_t *__restrict__ vtx_indices, const uint32_t n_tris, float4 *__restrict__ tri_verts,
-                                                       float4 *__restrict__ tri_bitangents) {
+                                                       const uint32_t *__restrict__ vtx_indices, const uint32_t n_tris,
+                                                       const rayhip_tri_mat_data *__restrict__ tri_materials, const uint32_t tri_materials_count,
+                                                       float4 *__restrict__ tri_verts, float4 *__restrict__ tri_bitangents) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_tris) {
         float4 rows[TRI_VERTS_STRIDE], brows[TRI_BITANGENTS_STRIDE];
-        fill_tri_verts(vertices, vertices_count, vtx_indices, t, rows, brows);
+        fill_tri_verts(vertices, vertices_count, vtx_indices, t, tri_materials, tri_materials_count, rows, brows);
         for (int k = 0; k < TRI_VERTS_STRIDE; ++k) {
             tri_verts[size_t(t) * TRI_VERTS_STRIDE + k] = rows[k];
         }

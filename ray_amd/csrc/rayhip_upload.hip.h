@@ -464,8 +464,9 @@ int rayhip_scene_upload(rayhip_ctx *c, const rayhip_scene_desc *d_in) {
         }
         if (n_tris) {
             k_fill_tri_verts<<<(n_tris + 255) / 256, 256, 0, c->stream>>>(c->vertices.as<rayhip_vertex>(), d->vertices_count,
-                                                                          c->vtx_indices.as<uint32_t>(), n_tris, c->tri_verts.as<float4>(),
-                                                                          c->tri_bitangents.as<float4>());
+                                                                          c->vtx_indices.as<uint32_t>(), n_tris,
+                                                                          c->tri_materials.as<rayhip_tri_mat_data>(), d->tri_materials_count,
+                                                                          c->tri_verts.as<float4>(), c->tri_bitangents.as<float4>());
             HIP_TRY(hipGetLastError());
         }
     }

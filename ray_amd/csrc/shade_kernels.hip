@@ -520,10 +520,11 @@ __global__ void __launch_bounds__(WAVE, RT_FUSED_MIN_WAVES) k_surface_scatter(co
                                                                                const PixelBuffers px, const int img_w, const float mix_factor,
                                                                                const Layering layers, uint32_t *__restrict__ sky_index, const RayQueue out_sky) {
     const uint32_t n_live_chunks = in.live_chunks();
+    const uint32_t fills = in.fill_counts(); // (the input queue's fill counts, in registers: no scalar load per chunk)
     ChunkWalk walk(n_live_chunks);
     for (uint32_t c; walk.next(c);) {
         uint32_t stripe, slot0, n_live;
-        if (!in.chunk(c, stripe, slot0, n_live)) {
+        if (!in.chunk(c, fills, stripe, slot0, n_live)) {
             continue;
         }
         const uint32_t i = slot0 + threadIdx.x; // (the whole wavefront stays in the body for the ballots)
@@ -535,14 +536,17 @@ __global__ void __launch_bounds__(WAVE, RT_FUSED_MIN_WAVES) k_surface_scatter(co
         ShadeParams spl = sp;
         uint32_t xy = 0;
         float4 pick = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+        VertexRandoms ahead = {};
         if (active) {
             ray = load_ray(rays_in, i, sp.plain_ior == 0u);
             const Hit hit = load_hit(hits, i);
+            pick = picks[i]; // (with the ray, not after the surface stage: one round trip less on the wavefront's critical path)
             xy = ray.xy; // virtual (layered) pixel: where the pixel writes go
             const uint32_t layer = xy_layer(xy, layers);
             spl = layer_params(sp, layer);
             ray.xy = xy_real(xy, layers, layer);
-            continues = surface_stage<true, SKY>(sc, spl, hit, ray, pt, so); // (emitter MIS weights: k_shade_emissive)
+            ahead = vertex_randoms(path_random(sc, spl, ray.xy, ray.depth));
+            continues = surface_stage<true, SKY>(sc, spl, hit, ray, pt, so, &ahead);
             defer = so.deferred_emitter;
             sky = SKY && so.deferred_sky;
             if (PRIMARY) {
@@ -559,10 +563,7 @@ __global__ void __launch_bounds__(WAVE, RT_FUSED_MIN_WAVES) k_surface_scatter(co
                 res.col = so.radiance;
                 add_secondary_pixel(res, xy, img_w, px.temp);
             }
-            if (continues && sc.light_cwnodes_count != 0) {
-                pick = picks[i];
-                lit = float_as_uint(pick.w) == tag;
-            }
+            lit = continues && sc.light_cwnodes_count != 0 && float_as_uint(pick.w) == tag;
         }
         // what the next-event estimation needs of a lit point, densely in the `nee` queue of its stripe
         const uint32_t r_slot = out_records.alloc(stripe, lit);
@@ -596,7 +597,7 @@ __global__ void __launch_bounds__(WAVE, RT_FUSED_MIN_WAVES) k_surface_scatter(co
         sct.has_next = sct.has_shadow = false;
         if (continues) {
             ray.o = pt.P, ray.pdf = 0.0f; // (what k_scatter hands the stage: neither is read by it)
-            scatter_stage<false, true>(sc, spl, ray, pt, no_light_pick(), sct);
+            scatter_stage<false, true>(sc, spl, ray, pt, no_light_pick(), sct, &ahead);
             sct.next.xy = xy;
         }
         const uint32_t n_slot = out_rays.alloc(stripe, sct.has_next);

@@ -397,7 +397,8 @@ RT_HD void principled_continue(const ScatterFrame &fr, const ShadePoint &pt, con
 // ---- the scatter stage ------------------------------------------------------------------------------------------------------------------
 // `ray`: the ray that produced the shade point (direction, throughput, ior stack, cone, pixel, depth counters)
 template <bool NEE = true, bool CONTINUE = true>
-RT_HD void scatter_stage(const SceneView &sc, const ShadeParams &sp, const Ray &ray, const ShadePoint &pt, const LightPick &pick, Scatter &out) {
+RT_HD void scatter_stage(const SceneView &sc, const ShadeParams &sp, const Ray &ray, const ShadePoint &pt, const LightPick &pick, Scatter &out,
+                         const VertexRandoms *ahead = nullptr) {
     RT_PROF_SHADE_LANES(0)
     const PassLimits &ps = sp.ps;
     const rayhip_material &mat = sc.materials[pt.material];
@@ -438,7 +439,7 @@ RT_HD void scatter_stage(const SceneView &sc, const ShadeParams &sp, const Ray &
     shadow.o = shadow.d = f3{0.0f, 0.0f, 0.0f};
     shadow.dist = 0.0f;
 
-    const f2 u = rnd.get(RAND_DIM_BSDF);
+    const f2 u = ahead ? ahead->bsdf : rnd.get(RAND_DIM_BSDF);
     const bool budget = n_total < ps.max_total_depth;
     const float outside_ior = peek_ior_stack(ray.ior, pt.backfacing);
     switch (mat.type) {
@@ -473,7 +474,7 @@ RT_HD void scatter_stage(const SceneView &sc, const ShadeParams &sp, const Ray &
     if (CONTINUE) { // Russian roulette on the continuation's throughput once the path is past its guaranteed length
         next.c *= ray.c;
         const float brightest = fmaxf(next.c.x, fmaxf(next.c.y, next.c.z));
-        const float survive_u = rnd.get(RAND_DIM_BSDF_PICK).y;
+        const float survive_u = ahead ? ahead->bsdf_pick.y : rnd.get(RAND_DIM_BSDF_PICK).y;
         const float q = (n_total > ps.min_total_depth) ? fmaxf(0.05f, 1.0f - brightest) : 0.0f;
         if (survive_u >= q && brightest > 0.0f && next.pdf > 0.0f) {
             RT_PROF_SHADE_LANES(28)

@@ -53,6 +53,13 @@ RT_HD PathRandom path_random(const SceneView &sc, const ShadeParams &sp, const u
                       sp.iteration - 1, sc.pmj};
 }
 
+// random pairs of a path vertex a caller fetched ahead of the stages (k_surface_scatter: the two table reads per pair are then on their way while
+// the triangle rows are, instead of behind the material chain); the values are what the stages would compute themselves
+struct VertexRandoms {
+    f2 bsdf_pick, bsdf;
+};
+RT_HD VertexRandoms vertex_randoms(const PathRandom &rnd) { return VertexRandoms{rnd.get(RAND_DIM_BSDF_PICK), rnd.get(RAND_DIM_BSDF)}; }
+
 struct ShadePoint {
     f3 P;              // world position
     f3 N, B, plane_N;  // shading normal, bitangent, geometric normal (unit, world space, flipped towards the ray)
@@ -86,7 +93,8 @@ struct SurfaceOut {
 // indices to three 44-byte vertices: 3 + 33 dword loads, two dependent trips):
 //   [2k]   vertex k: position, normal.x        [2k+1]  vertex k: normal.yz, uv
 //   [6]    object-space geometric normal (unit) and the length of the edge cross product (twice the area)
-//   [7]    twice the area of the triangle in uv space, -, -, -
+//   [7]    twice the area of the triangle in uv space, the triangle's material indices (front | back << 16: tri_materials[], which would be one
+//          more gather of a 4-byte entry in its own line), -, -
 // Rows 6-7 are values every shade point of the triangle would compute from the corners with the same operations (same
 // IEEE results on host and device); the vertex bitangents, which only normal-mapped materials read, live in their own
 // table (`tri_bitangents`, 4 float4 per triangle: b0, b1, b2, -).  Pure data movement otherwise.
@@ -96,9 +104,13 @@ struct Corner {
     f2 uv;
 };
 RT_HD void fill_tri_verts(const rayhip_vertex *vertices, const uint32_t vertices_count, const uint32_t *vtx_indices, const uint32_t tri,
+                          const rayhip_tri_mat_data *tri_materials, const uint32_t tri_materials_count,
                           float4 *out /* [TRI_VERTS_STRIDE] */, float4 *out_bitangents /* [TRI_BITANGENTS_STRIDE] */) {
     for (int k = 0; k < TRI_VERTS_STRIDE; ++k) {
         out[k] = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (tri < tri_materials_count) {
+        out[7].y = uint_as_float(uint32_t(tri_materials[tri].front_mi) | (uint32_t(tri_materials[tri].back_mi) << 16));
     }
     for (int k = 0; k < TRI_BITANGENTS_STRIDE; ++k) {
         out_bitangents[k] = mkfloat4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -119,7 +131,7 @@ RT_HD void fill_tri_verts(const rayhip_vertex *vertices, const uint32_t vertices
     const f3 ng = normalize_len(cross(mk3(v[1]->p) - mk3(v[0]->p), mk3(v[2]->p) - mk3(v[0]->p)), twice_area);
     out[6] = mkfloat4(ng.x, ng.y, ng.z, twice_area);
     const float uv_area = fabsf((v[1]->t[0] - v[0]->t[0]) * (v[2]->t[1] - v[0]->t[1]) - (v[2]->t[0] - v[0]->t[0]) * (v[1]->t[1] - v[0]->t[1]));
-    out[7] = mkfloat4(uv_area, 0.0f, 0.0f, 0.0f);
+    out[7].x = uv_area;
 }
 RT_HD Corner load_corner(const float4 *t) {
     const float4 a = t[0], b = t[1];
@@ -257,7 +269,8 @@ RT_HD f4 emissive_hit_radiance(const ShadeParams &sp, const float mix_weight, co
 // DEFER_EMITTERS: leave the MIS weight of emitter hits to the caller (see SurfaceOut).
 // SKY: the environment may be the physical sky (false: the test is compiled out -- the device picks the kernel per scene).
 template <bool DEFER_EMITTERS, bool SKY = true>
-RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &hit, const Ray &ray, ShadePoint &pt, SurfaceOut &out) {
+RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &hit, const Ray &ray, ShadePoint &pt, SurfaceOut &out,
+                         const VertexRandoms *ahead = nullptr) {
     out.radiance = f4{0.0f, 0.0f, 0.0f, 0.0f};
     out.base_color = f3{0.0f, 0.0f, 0.0f};
     out.normal_depth = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -306,12 +319,13 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     pt.P = ray.o + hit.t * view;
     pt.backfacing = (hit.prim_index < 0);
     const uint32_t tri = pt.backfacing ? uint32_t(-hit.prim_index - 1) : uint32_t(hit.prim_index);
-    const rayhip_tri_mat_data sides = sc.tri_materials[tri];
     const rayhip_mesh_instance *inst = &sc.mesh_instances[hit.obj_index];
     const float4 *rows = sc.tri_verts + size_t(tri) * TRI_VERTS_STRIDE;
     const Corner c1 = load_corner(rows), c2 = load_corner(rows + 2), c3 = load_corner(rows + 4);
     const float4 plane = rows[6];
-    const float uv_area = rows[7].x;
+    const float4 row7 = rows[7];
+    const float uv_area = row7.x;
+    const rayhip_tri_mat_data sides = {uint16_t(float_as_uint(row7.y) & 0xffffu), uint16_t(float_as_uint(row7.y) >> 16)}; // == sc.tri_materials[tri]
 
     const float w1 = 1.0f - hit.u - hit.v;
     const f3 N_obj = normalize(c1.n * w1 + c2.n * hit.u + c3.n * hit.v);
@@ -338,7 +352,7 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     const float outside_ior = peek_ior_stack(ray.ior, pt.backfacing);
 
     // ---- mix nodes: one random number walks down the chain, re-stretched at every node ----
-    const f2 pick = rnd.get(RAND_DIM_BSDF_PICK);
+    const f2 pick = ahead ? ahead->bsdf_pick : rnd.get(RAND_DIM_BSDF_PICK);
     float mix_u = pick.x;
     pt.mix_weight = 1.0f;
     while (mat->type == NODE_MIX) {

@@ -71,6 +71,20 @@ struct RayQueue {
         n_live = n - j * WAVE < uint32_t(WAVE) ? n - j * WAVE : uint32_t(WAVE);
         return true;
     }
+    // the same with the fill counts held in registers (lane s: the count of stripe s, read once when the kernel starts -- a consumer's input queue
+    // does not change while it runs): no scalar load, and no wait for one, per chunk
+    __device__ __forceinline__ uint32_t fill_counts() const { return __lane_id() < stripes ? counts[__lane_id() * QUEUE_COUNTER_STRIDE] : 0u; }
+    __device__ __forceinline__ bool chunk(const uint32_t c, const uint32_t fills, uint32_t &stripe, uint32_t &slot0, uint32_t &n_live) const {
+        stripe = c % stripes;
+        const uint32_t j = c / stripes;
+        const uint32_t n = uint32_t(__builtin_amdgcn_readlane(int(fills), int(stripe)));
+        if (j * WAVE >= n) {
+            return false;
+        }
+        slot0 = (stripe * chunks_per_stripe + j) * WAVE;
+        n_live = n - j * WAVE < uint32_t(WAVE) ? n - j * WAVE : uint32_t(WAVE);
+        return true;
+    }
     __device__ __forceinline__ uint32_t alloc(const uint32_t stripe, const bool pred) const {
         return stripe * chunks_per_stripe * WAVE + wave_alloc(counts + stripe * QUEUE_COUNTER_STRIDE, pred);
     }

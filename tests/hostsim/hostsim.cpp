@@ -207,7 +207,7 @@ HS_API int hostsim_scene_upload(hostsim_ctx *c, const rayhip_scene_desc *d_in) {
     s.tri_verts.resize(size_t(d->vtx_indices_count / 3) * TRI_VERTS_STRIDE);
     s.tri_bitangents.resize(size_t(d->vtx_indices_count / 3) * TRI_BITANGENTS_STRIDE);
     for (uint32_t t = 0; t < d->vtx_indices_count / 3; ++t) {
-        fill_tri_verts(d->vertices, d->vertices_count, d->vtx_indices, t, &s.tri_verts[size_t(t) * TRI_VERTS_STRIDE],
+        fill_tri_verts(d->vertices, d->vertices_count, d->vtx_indices, t, d->tri_materials, d->tri_materials_count, &s.tri_verts[size_t(t) * TRI_VERTS_STRIDE],
                        &s.tri_bitangents[size_t(t) * TRI_BITANGENTS_STRIDE]);
     }
     s.light_tri_geom.assign(size_t(d->lights_count) * 4, mkfloat4(0.0f, 0.0f, 0.0f, 0.0f));
