@@ -79,6 +79,18 @@ WORKLOADS = {
     "bistro_1type": dict(kind="atrium", detail=4.3, one_material_type=True, w=1920, h=1080, label="synthetic Bistro-class atrium, one material type"),
     "bistro_texc": dict(kind="atrium", detail=4.3, textured=True, compressed=True, w=1920, h=1080,
                         label="synthetic Bistro-class atrium, textured, block-compressed"),
+    # round 6 -- the Bistro-class scene as BASELINE.md 4.3 (4) specifies it: 38 jittered / rotated / scaled copies of the reference's own asset mesh
+    # (tests/test_data/meshes/mat_test/model.bin, 77 762 triangles each; staged as a data file by tests/golden/stage_ref_assets.py) along a street
+    # between two facades, ~200 emissive triangles; BAKED into one mesh (one bottom-level tree over 3.0 M triangles) ...
+    "bistro_assets": dict(kind="street", copies=38, w=1920, h=1080, label="Bistro-class street: 38 baked copies of mat_test/model.bin"),
+    # ... and with the copies as mesh INSTANCES (top-level tree over 41 instances: the two-level walk is on the clock)
+    "bistro_assets_inst": dict(kind="street", copies=38, instanced=True, w=1920, h=1080,
+                               label="Bistro-class street: 38 instances of mat_test/model.bin"),
+    # the reference builder's spatial splits on the same two scenes (mesh_desc_t::allow_spatial_splits, BVHSplit.cpp:323-470): A/B only
+    "bistro_assets_sbvh": dict(kind="street", copies=38, spatial_splits=True, w=1920, h=1080,
+                               label="Bistro-class street: 38 baked copies of mat_test/model.bin, spatial splits"),
+    "bistro_assets_inst_sbvh": dict(kind="street", copies=38, instanced=True, spatial_splits=True, w=1920, h=1080,
+                                    label="Bistro-class street: 38 instances of mat_test/model.bin, spatial splits"),
     "cornell": dict(kind="cornell_basic", w=1024, h=1024, label="samples/00_basic Cornell box"),
     "principled": dict(kind="cornell_principled", w=2048, h=2048, label="samples/03_principled Cornell box"),
 }
@@ -91,6 +103,8 @@ def build_scene(scene, wl):
     if wl["kind"] == "atrium":
         return scenes.atrium(scene, wl["detail"], textured=wl.get("textured", False), compress=wl.get("compressed", False),
                              one_material_type=wl.get("one_material_type", False))
+    if wl["kind"] == "street":
+        return scenes.street_assets(scene, copies=wl["copies"], instanced=wl.get("instanced", False), spatial_splits=wl.get("spatial_splits", False))
     scenes.SCENES[wl["kind"]](scene)
     return scene.triangle_count()
 
@@ -134,7 +148,7 @@ def csrc_hash():
 
 
 def traffic_table_path():
-    for r in ("r05", "r04", "r03", "r02"):
+    for r in ("r06", "r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", r, "k2_traffic.json")
         if os.path.exists(p):
             return p
@@ -586,7 +600,7 @@ def main():
                     "bytes_per_ray": k2_bytes / scale / max(w2["rays"], 1),
                     "bvh_width": bvh_width, "wide_node_bytes": wide_node_bytes,
                     "tlas_nodes_per_ray": w2["nodes"] / max(w2["rays"], 1), "wide_nodes_per_ray": w2["nodes4"] / max(w2["rays"], 1),
-                    "tris_per_ray": w2["tris"] / max(w2["rays"], 1),
+                    "tris_per_ray": w2["tris"] / max(w2["rays"], 1), "instances_per_ray": w2["instances"] / max(w2["rays"], 1),
                     "reference_bvh2": {"bytes_per_launch": k2_bytes_ref / launches,
                                        "bytes_per_ray": k2_bytes_ref / scale / max(c2["rays"], 1),
                                        "nodes_per_ray": c2["nodes"] / max(c2["rays"], 1), "tris_per_ray": c2["tris"] / max(c2["rays"], 1),

@@ -11,6 +11,7 @@ Every builder takes an object with the SceneBase API, so the same code feeds the
 oracle.  Geometry here is data (the classic Cornell measurements / procedural math), not reference code.
 """
 import math
+import os
 from typing import Tuple
 
 import numpy as np
@@ -768,6 +769,143 @@ def atrium(scene, detail: float = 1.0, cam_overrides=None, textured: bool = Fals
     scene.set_current_cam(cam)
     scene.Finalize()
     return int(len(idx) // 3)
+
+
+# ---- the Bistro-class street on the reference's own asset mesh (SURVEY.md section 8d input 4) --------
+ASSET_MESHES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "assets", "_ref", "meshes.npz")
+
+
+def have_asset_meshes() -> bool:
+    return os.path.exists(ASSET_MESHES)
+
+
+def load_asset_mesh(stem: str):
+    """the reference's tests/test_data/meshes/mat_test/<stem>.bin as tests/golden/stage_ref_assets.py staged it (a data file: interleaved
+    position3 / normal3 / uv2, indices; loader layout tests/utils.cpp:72-114): attrs [n, 8] f32, indices u32"""
+    if not have_asset_meshes():
+        raise RuntimeError(f"{ASSET_MESHES} is not staged (tests/golden/stage_ref_assets.py, run by __graft_entry__.build() where the reference tree exists)")
+    m = np.load(ASSET_MESHES)
+    return m[stem + ".attrs"].reshape(-1, 8).astype(np.float32), m[stem + ".indices"].astype(np.uint32)
+
+
+def _rot_y(deg):
+    a = math.radians(deg)
+    return np.array([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+
+
+def _rot_x(deg):
+    a = math.radians(deg)
+    return np.array([[1.0, 0.0, 0.0], [0.0, math.cos(a), -math.sin(a)], [0.0, math.sin(a), math.cos(a)]])
+
+
+def street_assets(scene, copies: int = 38, instanced: bool = False, spatial_splits: bool = False, fast_bvh_build: bool = False,
+                  cam_overrides=None):
+    """`copies` jittered / rotated / scaled copies of mat_test/model.bin (77 762 triangles of a real asset mesh each: a material ball with
+    long thin triangles, creases and nested shells -- not a displaced grid) standing along a street between two facades, on a ground
+    plane, under ~200 emissive triangles (lamps).  copies = 38 is the ~3 M-triangle scene BASELINE.md 4.3 (4) specifies.
+    instanced = False: the copies are BAKED into one mesh (one bottom-level tree over 3 M triangles: the working set the survey asks for);
+    instanced = True:  the copies are mesh INSTANCES (four meshes -- one per material -- of 77 762 triangles, a top-level tree over
+                       `copies` + 3 instances: the two-level walk, transforms and all, is on the clock).
+    Deterministic (no RNG state): the jitter comes from the copy's index."""
+    attrs0, idx0 = load_asset_mesh("model")
+    lo, hi = attrs0[:, :3].min(0), attrs0[:, :3].max(0)
+    centre_xz = np.array([(lo[0] + hi[0]) / 2, lo[1], (lo[2] + hi[2]) / 2])
+    unit = 1.0 / float((hi - lo).max())  # the ball is ~0.11 units across: bring it to 1, then scale per copy
+    scene.SetEnvironment(env_col=(0.0, 0.0, 0.0))
+    mats = [scene.AddMaterial(PrincipledMat(base_color=(0.90, 0.75, 0.40), metallic=1.0, roughness=0.25)),
+            scene.AddMaterial(PrincipledMat(base_color=(0.55, 0.12, 0.10), roughness=0.45, specular=0.5)),
+            scene.AddMaterial(PrincipledMat(base_color=(0.15, 0.30, 0.55), roughness=0.6, specular=0.3, clearcoat=0.5)),
+            scene.AddMaterial(PrincipledMat(base_color=(0.70, 0.70, 0.72), roughness=0.8, specular=0.2))]
+    stone = scene.AddMaterial(PrincipledMat(base_color=(0.55, 0.52, 0.47), roughness=0.75, specular=0.3))
+    asphalt = scene.AddMaterial(PrincipledMat(base_color=(0.20, 0.20, 0.21), roughness=0.5, specular=0.4))
+    emit = scene.AddMaterial(ShadingNode(type=eShadingNode.Emissive, strength=25.0, base_color=(1.0, 0.93, 0.80), importance_sample=True))
+    L, W, H = 64.0, 14.0, 16.0  # street along x; facades at z = +-W/2
+
+    def placement(k):
+        """scale, rotation matrix, translation of copy k: two staggered rows along the street, sizes 1.6 .. 3.4 m, any heading, a slight lean"""
+        row, col = k % 2, k // 2
+        n_col = (copies + 1) // 2
+        x = -L / 2 + 3.0 + (col + 0.5 * row) * (L - 6.0) / max(n_col, 1)
+        z = (-1.0 if row == 0 else 1.0) * (2.2 + 1.3 * _noise(np.array([k * 0.37, 0.1, 0.7]), 3))
+        scale = 1.6 + 1.8 * float(_noise(np.array([k * 0.91, 0.5, 0.2]), 5))
+        R = _rot_y(360.0 * float(_noise(np.array([k * 0.53, 0.9, 0.4]), 7))) @ _rot_x(10.0 * (float(_noise(np.array([k * 0.77, 0.3, 0.6]), 11)) - 0.5))
+        return scale * unit, R, np.array([x, 0.0, float(z)])
+
+    env = _MeshBuilder()
+    env.add(*_grid(200, 48, _finite_normals(lambda u, v: np.stack(
+        [u * L - L / 2, 0.03 * np.sin(u * 160) * np.sin(v * 31) + 0.015 * _noise(np.stack([u, v, u * 0], -1), 1), v * W - W / 2], -1))), asphalt)
+    for side in (-1.0, 1.0):
+        def facade(u, v, side=side):
+            # window bays and cornices: a relief of boxes smoothed by sines (long, thin triangles where the relief is steep)
+            bay = 0.35 * (np.sin(u * 2 * math.pi * 16) > 0.55) * (np.sin(v * 2 * math.pi * 5) > 0.2)
+            relief = 0.12 * np.sin(u * 130) * np.cos(v * 47) + bay
+            x = u * L - L / 2 if side < 0 else L / 2 - u * L
+            return np.stack([x, v * H, side * (W / 2 + relief)], -1)
+        env.add(*_grid(260, 64, _finite_normals(facade)), stone)
+    for end in (-1.0, 1.0):  # the street's ends are closed by plain walls
+        def wall(u, v, end=end):
+            z = u * W - W / 2 if end > 0 else W / 2 - u * W
+            return np.stack([end * L / 2 + 0 * u, v * H, z], -1)
+        env.add(*_grid(24, 24, _finite_normals(wall)), stone)
+    lamps = _MeshBuilder()
+    n_lamps = 25
+    for k in range(n_lamps):  # 25 lamps x (2 x 2 quads x 2 triangles) = 200 emissive triangles, hanging over the middle of the street
+        x0 = -L / 2 + 2.0 + k * (L - 4.0) / (n_lamps - 1)
+        z0 = 1.5 * math.sin(k * 1.7)
+
+        def lamp(u, v, x0=x0, z0=z0):
+            return np.stack([x0 + (u - 0.5) * 0.9, 0 * u + 7.5 + 0.4 * math.sin(k * 0.9), z0 + (v - 0.5) * 0.5], -1)
+        a, i = _grid(2, 2, lambda u, v, f=lamp: (f(u, v), np.broadcast_to(np.array([0.0, -1.0, 0.0]), (*u.shape, 3))), flip=True)
+        lamps.add(a, i, emit, back=0xFFFFFFFF)
+
+    n_tris = 0
+    if instanced:
+        P0 = (attrs0[:, :3] - centre_xz).astype(np.float32)
+        base = np.concatenate([P0, attrs0[:, 3:]], axis=-1)
+        meshes = [scene.AddMesh(base, idx0, [(m, None, 0, len(idx0))], allow_spatial_splits=spatial_splits, use_fast_bvh_build=fast_bvh_build)
+                  for m in mats]
+        for k in range(copies):
+            sc_k, R, t = placement(k)
+            M = np.eye(4)
+            M[:3, :3] = R * sc_k
+            M[:3, 3] = t
+            scene.AddMeshInstance(meshes[k % len(mats)], M.T.astype(np.float32))  # (column-major, as the reference takes it)
+        n_tris += len(mats) * len(idx0) // 3
+        a, i, g = env.finish()
+        scene.AddMeshInstance(scene.AddMesh(a, i, g, allow_spatial_splits=spatial_splits, use_fast_bvh_build=fast_bvh_build))
+        n_tris += len(i) // 3
+        a, i, g = lamps.finish()
+        scene.AddMeshInstance(scene.AddMesh(a, i, g))
+        n_tris += len(i) // 3
+    else:
+        mb = _MeshBuilder()
+        for k in range(copies):
+            sc_k, R, t = placement(k)
+            P = (attrs0[:, :3] - centre_xz) @ (R * sc_k).T + t
+            N = attrs0[:, 3:6] @ R.T  # (uniform scale: normals rotate)
+            mb.add(np.concatenate([P, N, attrs0[:, 6:8]], axis=-1).astype(np.float32), idx0, mats[k % len(mats)])
+        for src in (env, lamps):
+            for a, i, (front, back, _, _) in zip(src.attrs, src.idx, src.groups):
+                mb.add(a, i - _group_base(src, a), front, back=back)
+        a, i, g = mb.finish()
+        scene.AddMeshInstance(scene.AddMesh(a, i, g, allow_spatial_splits=spatial_splits, use_fast_bvh_build=fast_bvh_build))
+        n_tris += len(i) // 3
+    kw = dict(type=0, origin=(-L / 2 + 3.0, 1.7, 0.4), fwd=_unit((1.0, 0.06, -0.03)), fov=60.0)
+    kw.update(cam_overrides or {})
+    cam = scene.AddCamera(**kw)
+    scene.set_current_cam(cam)
+    scene.Finalize()
+    return int(n_tris)
+
+
+def _group_base(builder, attrs):
+    """first vertex a part of `builder` was given (its indices were rebased by that much in _MeshBuilder.add)"""
+    nv = 0
+    for a in builder.attrs:
+        if a is attrs:
+            return nv
+        nv += len(a)
+    raise KeyError
 
 
 def cornell_needles(scene, spatial_splits: bool = False, fast_bvh_build: bool = False, seed: int = 5, **cam_overrides):
