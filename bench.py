@@ -623,6 +623,11 @@ def main():
             "stage_us_per_spp": {k: v / (K * SPP) for k, v in stages.items() if v},
             "scene_build_s": info["build_s"],
         }
+        # RendererBase::stats_t is a partition of the pass (exclusive intervals of the context stream, include/rayhip.h): the stage entries may not
+        # add up to more than the step (they did in round 5, when the shadow launch beside K2 was booked with its elapsed time)
+        out["stage_sum_over_step"] = sum(out["stage_us_per_step"].values()) / 1e3 / out["ms_per_step"]
+        if out["stage_sum_over_step"] > 1.02:
+            raise SystemExit(f"bench.py: the stage times add up to {out['stage_sum_over_step']:.3f} x the step: rayhip_get_stage_times is not a partition")
         out["render_ms"] = t_render * 1e3 / K   # per frame: clear + the SPP iterations, stream drained
         if dist is None:
             out["readback_ms"] = t_out * 1e3 / K  # per frame: the finished frame to (page-locked) host memory

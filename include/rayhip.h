@@ -553,7 +553,11 @@ RAYHIP_API int rayhip_sync(rayhip_ctx *ctx);
  * [0] closest-hit kernel (K2), [1] shadow any-hit kernel (K3) */
 RAYHIP_API int rayhip_get_trav_counters(rayhip_ctx *ctx, rayhip_trav_counters out[2], int reset);
 /* per-stage GPU time (us) accumulated by renders that passed stats != NULL or RAYHIP_FLAG_TIME_STAGES; this is
- * what RendererBase::GetStats (RendererBase.h:245) returns for the HIP backend.  Synchronises the stream. */
+ * what RendererBase::GetStats (RendererBase.h:245) returns for the HIP backend.  Synchronises the stream.
+ * The stages are EXCLUSIVE intervals of the context's stream and add up to the time of the pass (the reference's GPU backends report
+ * per-stage timestamps the same way, RendererVK.cpp:452-487).  The shadow launch of bounce b runs on a second stream beside the closest-hit
+ * launch of bounce b + 1 (RAYHIP_OVERLAP_SHADOW): its stage entry is the time the pass waited for it AFTER that closest-hit launch ended;
+ * the part that ran beside the trace is inside the trace stage (its own elapsed time: rayhip_get_trav_timing, kernel 1). */
 RAYHIP_API int rayhip_get_stage_times(rayhip_ctx *ctx, rayhip_stats *out, int reset);
 /* GPU time (ms, HIP events on the context stream) and launch count of the closest-hit traversal kernel
  * and the shadow kernel, accumulated over renders that passed stats != NULL or RAYHIP_FLAG_TIME_STAGES; [0]=K2 [1]=K3 */

@@ -153,6 +153,7 @@ struct rayhip_ctx {
     // the ray's part of a next-event record (shade_launch.h)
     DevBuf pick_plane, record_ray_planes[4];
     RaySoA record_rays = {};
+    bool pick_lds = true; // RAYHIP_PICK_LDS=0: the light pick reads every row of the light table from memory (shade_kernels.hip)
     uint32_t shade_tag = 0;
     uint32_t next_shade_tag() {
         if (++shade_tag == 0u) { // (2^32 launches later: the plane may hold every old tag -- clear it and start again)
@@ -591,6 +592,9 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     }
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
         c->shade_split = atoi(e) & 31;
+    }
+    if (const char *e = getenv("RAYHIP_PICK_LDS")) {
+        c->pick_lds = atoi(e) != 0;
     }
     // The persistent ray-refill form of the closest-hit kernel (kernels_closest_refill.hip.h): lanes whose ray is finished fetch the next one
     // instead of idling until the longest walk of their wavefront ends.  RAYHIP_REFILL: 2 = for the secondary

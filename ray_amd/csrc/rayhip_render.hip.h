@@ -44,6 +44,7 @@ static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration,
     a.px = c->px, a.layers = layers, a.vw = vw, a.mix_factor = mix_factor;
     a.bounce = bounce, a.grid = gtrace, a.split = c->shade_split, a.stream = c->stream;
     a.picks = c->pick_plane.as<float4>(), a.record_rays = c->record_rays, a.tag = c->next_shade_tag();
+    a.pick_lds = c->pick_lds;
     if (sized) { // a pass (not a kernel-level hook): grids from the queue census, the persistent pick with a work counter
         a.expect[EXPECT_RAYS] = bounce == 0 ? uint32_t(nslots / WAVE + stripes) : c->expect_chunks(bounce, 0, nslots, stripes);
         a.expect[EXPECT_POINTS] = c->expect_chunks(bounce, 3, nslots, stripes), a.expect[EXPECT_LIT] = c->expect_chunks(bounce, 4, nslots, stripes);
@@ -215,6 +216,19 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     }
     int cur = 0;
     bool side_pending = false; // a K3 launch on the second stream that the main stream has not waited for yet
+    bool side_forked = false;  // anything was sent to the second stream in this pass
+    // every error exit below leaves through here: a shadow launch still running on the second stream would race with the next pass's queue
+    // clears and shade launches on the shadow planes, the pixel buffer and the counters -- drain it (error path: blocking is fine)
+    struct SideDrain {
+        rayhip_ctx *c;
+        const bool *forked, *pending;
+        bool armed = true;
+        ~SideDrain() {
+            if (armed && *forked && *pending && c->stream2) {
+                (void)hipStreamSynchronize(c->stream2);
+            }
+        }
+    } side_drain{c, &side_forked, &side_pending};
     for (int bounce = 0; bounce <= max_depth; ++bounce) {
         bounce_now = bounce;
         if (bounce > 0) {
@@ -236,7 +250,11 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
                 return 1;
             }
             launch_closest(c->rays[cur], c->ray_queue(bounce, nslots, stripes), 1);
-            if (side_pending && tm.mark(ST_STRACE, -1)) { // (K2's own interval ends here: what follows is the wait for the shadow launch beside it)
+            // K2's own interval ends here.  What follows -- until the shadow launch of the bounce before, which ran beside K2, is through -- is what
+            // the frame spends on shadow rays beyond the trace: that wait is the shadow stage's entry in RendererBase::stats_t, so that the stages
+            // PARTITION the frame again (the reference's GPU backends report exclusive intervals: RendererVK.cpp:452-487, RendererBase.h:230-244;
+            // round 5 booked K3's whole elapsed time, which overlaps the trace interval: the fields summed to 1.45 x the frame)
+            if (side_pending && tm.mark(bounce - 1 == 0 ? ST_PSHADOW : ST_SSHADOW, -1)) {
                 return 1;
             }
             if (c->sc.visible_lights_count != 0) {
@@ -259,6 +277,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         if (side) {
             HIP_TRY(hipEventRecord(c->fork_event, s));
             HIP_TRY(hipStreamWaitEvent(ss, c->fork_event, 0));
+            side_forked = side_pending = true; // (from here on an error exit has to drain the second stream)
             if (tm.on) {
                 side_t0 = tm.stamp(ss);
             }
@@ -300,7 +319,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
             if (tm.on) {
                 const long side_t1 = tm.stamp(ss);
                 if (side_t0 >= 0 && side_t1 >= 0) {
-                    c->pending2.push_back({size_t(side_t0), size_t(side_t1), bounce == 0 ? ST_PSHADOW : ST_SSHADOW, 1});
+                    c->pending2.push_back({size_t(side_t0), size_t(side_t1), -1, 1}); // (elapsed time -> rayhip_get_trav_timing only: not a stage)
                 }
             }
             HIP_TRY(hipEventRecord(c->join_event, ss));
@@ -308,7 +327,10 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         }
         cur ^= 1;
     }
-    if (side_pending) {
+    if (side_pending) { // the last shadow launch has nothing beside it: all of it is the shadow stage's
+        if (tm.mark(max_depth == 0 ? ST_PSHADOW : ST_SSHADOW, -1)) {
+            return 1;
+        }
         HIP_TRY(hipStreamWaitEvent(s, c->join_event, 0));
         side_pending = false;
     }

@@ -45,12 +45,12 @@ int rayhip_bake_sky(rayhip_ctx *c, const rayhip_scene_desc *d, int w, int h, uin
     if (d->struct_size != sizeof(rayhip_scene_desc)) {
         return fail("rayhip_scene_desc::struct_size is %u, this library's struct has %zu bytes", d->struct_size, sizeof(rayhip_scene_desc));
     }
+    if (d->lights_count != 0 && d->lights == nullptr) { // (before validate_sky: it looks at lights[sky_dir_lights[i]])
+        return fail("rayhip_bake_sky: lights is null");
+    }
     std::string why;
     if (!(d->env.sky_map_spread_angle > 0.0f) || !rayhip_validate::validate_sky(*d, why)) {
         return fail("rayhip_bake_sky: %s", why.empty() ? "the description holds no physical sky (env.sky_map_spread_angle > 0, sky, tables, textures)" : why.c_str());
-    }
-    if (d->lights_count != 0 && d->lights == nullptr) {
-        return fail("rayhip_bake_sky: lights is null");
     }
     DevBuf desc, tlut, mlut, dirs, weather, noise, curl, moon, cirrus, lights, out;
     DevBuf *all[] = {&desc, &tlut, &mlut, &dirs, &weather, &noise, &curl, &moon, &cirrus, &lights, &out};

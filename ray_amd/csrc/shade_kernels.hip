@@ -430,12 +430,37 @@ __global__ void __launch_bounds__(WAVE, (NEE && CONTINUE) ? RT_SCATTER_MIN_WAVES
 // ~380 B per vertex instead of ~880.  Per path vertex every stage function gets the arguments it got before (surface_stage, pick_light's
 // levels, scatter_stage<false, true>, scatter_stage<true, false>): frames are bit-identical to the three-kernel form
 // (test_shade_forms_agree_bit_for_bit); only the order of the lists differs, which no pixel sees.
-template <bool DYN>
-__global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick_first(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
+// LDS_TREE: the wavefronts of a block (PICK_BLOCK_WAVES) share a copy of the light table (`lds_nodes` = all of its nodes) in LDS.  A level of the descent reads
+// 24 float4 rows per lane (eight children x 48 bytes): 2.07 M wavefronts x ~2.5 levels x 24 loads x 16 cycles of the CU's vector-memory path is
+// what the kernel's time was made of (profiles/r06/experiments/pick_first_counters.txt: 53 % of the wave cycles waiting, the vector ALU a third
+// busy); the table of a scene with a few hundred lights is a few kilobytes.  A table that does not fit is read from memory as before (the
+// launcher picks the form; a kernel with both paths spills).
+// (7 waves: 72 registers, no spills; 8 spill 3-8 dwords: 16.4 against 16.8 ms per frame)
+#ifndef RT_PICK_LDS_MIN_WAVES
+#define RT_PICK_LDS_MIN_WAVES 7
+#endif
+#ifndef RT_PICK_BLOCK_WAVES
+#define RT_PICK_BLOCK_WAVES 8
+#endif
+constexpr int PICK_BLOCK_WAVES = RT_PICK_BLOCK_WAVES;
+// eight wavefronts per block: four blocks (32 wavefronts, 8 per SIMD) per CU share the 160 KB -- 93 nodes x 416 B = 38 688 B per block (the
+// Bistro-class atrium has 41 nodes for 96 emitters, the asset street 73 for 200)
+constexpr uint32_t PICK_LDS_MAX_NODES = (160u * 1024u / (32u / uint32_t(PICK_BLOCK_WAVES)) - 2048u) / (uint32_t(LIGHT_CHILDREN_STRIDE) * 16u);
+template <bool DYN, bool LDS_TREE = false>
+__global__ void __launch_bounds__(LDS_TREE ? PICK_BLOCK_WAVES *WAVE : WAVE, LDS_TREE ? RT_PICK_LDS_MIN_WAVES : RT_PICK_MIN_WAVES) k_light_pick_first(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
                                                                              const RayQueue queue, float4 *__restrict__ picks, const uint32_t tag,
-                                                                             const Layering layers, uint32_t *__restrict__ work) {
-    const uint32_t lane = threadIdx.x;
-    ChunkWalk walk(queue.live_chunks(), DYN ? work : nullptr, RT_PICK_RUN);
+                                                                             const Layering layers, uint32_t *__restrict__ work, const uint32_t lds_nodes) {
+    extern __shared__ float4 s_tree[];
+    if (LDS_TREE) {
+        const uint32_t n_rows = lds_nodes * uint32_t(LIGHT_CHILDREN_STRIDE);
+        for (uint32_t r = threadIdx.x; r < n_rows; r += blockDim.x) {
+            s_tree[r] = sc.light_children[r];
+        }
+        __syncthreads();
+    }
+    const uint32_t lane = LDS_TREE ? (threadIdx.x & uint32_t(WAVE - 1)) : threadIdx.x;
+    const uint32_t waves = LDS_TREE ? uint32_t(PICK_BLOCK_WAVES) : 1u;
+    ChunkWalk walk(queue.live_chunks(), DYN ? work : nullptr, RT_PICK_RUN, blockIdx.x * waves + (LDS_TREE ? threadIdx.x / WAVE : 0u), gridDim.x * waves);
     uint32_t pool_slot = 0, pool_left = 0; // (uniform) the chunk being handed out
     bool exhausted = false;                // (uniform) no chunk left to hand out
     bool busy = false;
@@ -496,12 +521,16 @@ __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick_first(co
         }
         if (busy) { // one level of the descent (pick_light, shade_lights.h)
             float imp[8];
-            light_node_importances(sc, cur, P, imp);
+            if (LDS_TREE) {
+                light_node_importances_rows(s_tree + cur * uint32_t(LIGHT_CHILDREN_STRIDE), P, imp);
+            } else {
+                light_node_importances(sc, cur, P, imp);
+            }
             int chosen;
             if (!light_level_choice(imp, u, prob, chosen)) {
                 busy = false; // nothing in this subtree can light P: no pick is written
             } else {
-                cur = light_child_link(sc, cur, chosen);
+                cur = LDS_TREE ? light_child_link_rows(s_tree + cur * uint32_t(LIGHT_CHILDREN_STRIDE), chosen) : light_child_link(sc, cur, chosen);
                 if ((cur & LEAF_NODE_BIT) != 0) {
                     picks[i] = mkfloat4(uint_as_float(cur & PRIM_INDEX_BITS), 1.0f / prob, u, uint_as_float(tag));
                     busy = false;
@@ -510,6 +539,12 @@ __global__ void __launch_bounds__(WAVE, RT_PICK_MIN_WAVES) k_light_pick_first(co
         }
     }
 }
+
+// (Round 6 also tried the pick with the NEXT rays staged in registers -- lane L holds element L of a chunk whose loads are in flight and of one
+// whose positions and random numbers are computed, a finished lane takes the next ready element through a lane permutation, no memory access
+// on the refill path: 16.8 ms per frame against 16.3, at 80-100 registers.  The refill rounds are not what the kernel waits for; with the table
+// in LDS it is bound by the eight importance evaluations of a level -- nine quarter-rate reciprocals / square roots each.
+// profiles/r06/experiments/pick_lds_staged.txt; the kernel was removed.)
 
 template <bool PRIMARY, bool SKY>
 __global__ void __launch_bounds__(WAVE, RT_FUSED_MIN_WAVES) k_surface_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
@@ -715,16 +750,23 @@ void launch(const ShadeLaunch &a) {
     if ((a.split & 16) != 0) { // round 6: pick first, surface + continuation in one kernel, next-event estimation over dense records
         const bool lights = a.sc.light_cwnodes_count != 0;
         if (lights) {
-            auto go = [&](auto kernel) {
-                int grid = sized(kernel, a.expect[EXPECT_RAYS], all);
+            const uint32_t lds_nodes = (a.pick_lds && a.sc.light_cwnodes_count <= PICK_LDS_MAX_NODES) ? a.sc.light_cwnodes_count : 0u;
+            auto go = [&](auto kernel, auto kernel_wave) {
+                // (grids in wavefronts, from the one-wavefront form: the LDS form launches a quarter as many blocks of four)
+                int grid = sized(kernel_wave, a.expect[EXPECT_RAYS], all);
                 if (a.work) {
-                    const int resident = std::max(1, resident_blocks(reinterpret_cast<const void *>(kernel))) * std::max(1, a.dyn_mult);
+                    const int resident = std::max(1, resident_blocks(reinterpret_cast<const void *>(kernel_wave))) * std::max(1, a.dyn_mult);
                     const uint32_t bound = a.expect[EXPECT_RAYS] != 0u ? a.expect[EXPECT_RAYS] : a.chunks;
                     grid = int(std::max<uint32_t>(1u, std::min<uint32_t>({uint32_t(g), uint32_t(resident), std::max(bound, 1u)})));
                 }
-                kernel<<<grid, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.picks, a.tag, a.layers, a.work);
+                if (lds_nodes != 0u) {
+                    kernel<<<(grid + PICK_BLOCK_WAVES - 1) / PICK_BLOCK_WAVES, PICK_BLOCK_WAVES * WAVE, size_t(lds_nodes) * LIGHT_CHILDREN_STRIDE * sizeof(float4), s>>>(
+                        a.sc, a.sp, a.rays_in, a.hits, a.in, a.picks, a.tag, a.layers, a.work, lds_nodes);
+                } else {
+                    kernel_wave<<<grid, WAVE, 0, s>>>(a.sc, a.sp, a.rays_in, a.hits, a.in, a.picks, a.tag, a.layers, a.work, 0u);
+                }
             };
-            a.work ? go(k_light_pick_first<true>) : go(k_light_pick_first<false>);
+            a.work ? go(k_light_pick_first<true, true>, k_light_pick_first<true, false>) : go(k_light_pick_first<false, true>, k_light_pick_first<false, false>);
         }
 #define RT_FUSED(...) k_surface_scatter<__VA_ARGS__><<<sized(k_surface_scatter<__VA_ARGS__>, a.expect[EXPECT_RAYS], all), WAVE, 0, s>>>( \
         a.sc, a.sp, a.rays_in, a.hits, a.in, a.picks, a.tag, a.points, a.record_rays, a.nee, a.rays_out, a.out_rays, a.deferred, a.out_deferred, a.px, a.vw, \

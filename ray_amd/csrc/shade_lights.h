@@ -259,6 +259,14 @@ RT_HD void fill_light_children(const rayhip_light_cwbvh_node &n, float4 *out /* 
         out[2 + 0 * 8 + i] = c.axis_extent, out[2 + 1 * 8 + i] = c.centre_valid, out[2 + 2 * 8 + i] = c.cosines;
     }
 }
+// the same two accessors on the rows of ONE node wherever they are (k_light_pick_first keeps the top of the table in LDS)
+RT_HD LightChild load_light_child_rows(const float4 *node_rows, const int i) {
+    const float4 *t = node_rows + 2;
+    LightChild c;
+    c.axis_extent = t[0 * 8 + i], c.centre_valid = t[1 * 8 + i], c.cosines = t[2 * 8 + i];
+    return c;
+}
+RT_HD uint32_t light_child_link_rows(const float4 *node_rows, const int i) { return reinterpret_cast<const uint32_t *>(node_rows)[i]; }
 RT_HD LightChild load_light_child(const SceneView &sc, const uint32_t node, const int i) {
     const float4 *t = sc.light_children + size_t(node) * LIGHT_CHILDREN_STRIDE + 2;
     LightChild c;
@@ -321,6 +329,15 @@ RT_HD void light_node_importances(const SceneView &sc, const uint32_t node, cons
     LightChild c[8];
     for (int i = 0; i < 8; ++i) {
         c[i] = load_light_child(sc, node, i);
+    }
+    for (int i = 0; i < 8; ++i) {
+        imp[i] = light_child_importance(c[i], P);
+    }
+}
+RT_HD void light_node_importances_rows(const float4 *node_rows, const f3 P, float imp[8]) {
+    LightChild c[8];
+    for (int i = 0; i < 8; ++i) {
+        c[i] = load_light_child_rows(node_rows, i);
     }
     for (int i = 0; i < 8; ++i) {
         imp[i] = light_child_importance(c[i], P);

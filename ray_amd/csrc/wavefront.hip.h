@@ -123,25 +123,28 @@ struct ChunkWalk {
     uint32_t base, n, grid, x, local;
     uint32_t *work;
     uint32_t run, run_next, run_left;
-    __device__ __forceinline__ explicit ChunkWalk(const uint32_t n_chunks, uint32_t *work_counter = nullptr, const uint32_t run_length = 1u)
-        : base(0), n(n_chunks), work(work_counter), run(run_length), run_next(0), run_left(0) {
-        const bool remap = RT_XCD_CHUNKS != 0 && gridDim.x >= 8u && work_counter == nullptr;
-        grid = remap ? (gridDim.x & ~7u) : gridDim.x; // (up to seven surplus blocks of a grid that is not a multiple of 8 idle)
-        x = remap ? (blockIdx.x & 7u) : 0u;
-        local = remap ? (blockIdx.x >> 3) : blockIdx.x;
-        if (remap && blockIdx.x >= grid) {
+    // `walker` of `walkers`: who takes chunks -- a block by default (one wavefront per block); a kernel with several wavefronts per block passes
+    // its wavefront's number among all of the grid
+    __device__ __forceinline__ explicit ChunkWalk(const uint32_t n_chunks, uint32_t *work_counter = nullptr, const uint32_t run_length = 1u,
+                                                  const uint32_t walker = blockIdx.x, const uint32_t walkers = gridDim.x)
+        : base(0), n(n_chunks), work(work_counter), run(run_length), run_next(0), run_left(0), me(walker), all(walkers) {
+        const bool remap = RT_XCD_CHUNKS != 0 && all >= 8u && work_counter == nullptr;
+        grid = remap ? (all & ~7u) : all; // (up to seven surplus blocks of a grid that is not a multiple of 8 idle)
+        x = remap ? (me & 7u) : 0u;
+        local = remap ? (me >> 3) : me;
+        if (remap && me >= grid) {
             base = n;
         }
         parts = remap ? 8u : 1u;
     }
-    uint32_t parts;
+    uint32_t parts, me, all;
     // the next chunk of this block (wave-uniform); false when there is none left
     __device__ __forceinline__ bool next(uint32_t &c) {
         if (work != nullptr) {
             if (base == 0u) { // the first chunk of a block is its own
                 base = 1u;
-                c = blockIdx.x;
-                if (c >= n || gridDim.x >= n) { // (nothing, or nothing beyond the first chunks: no atomic from this block)
+                c = me;
+                if (c >= n || all >= n) { // (nothing, or nothing beyond the first chunks: no atomic from this block)
                     base = 2u;
                 }
                 return c < n;
@@ -158,7 +161,7 @@ struct ChunkWalk {
             if (__lane_id() == 0u) {
                 v = atomicAdd(work, run);
             }
-            c = gridDim.x + uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
+            c = all + uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
             if (c >= n) {
                 base = 2u;
                 return false;

@@ -115,6 +115,29 @@ class Scene final : public Cpu::Scene {
             return;
         }
         std::unique_lock<std::shared_timed_mutex> lock(mtx_);
+        // The bake comes FIRST, before anything of the scene is changed for it: the reference's host bake cannot fail at this point, the device's
+        // can (out of memory, a lost device), and a throw must leave the scene as it was -- not with the old sky texture freed and still named by
+        // physical_sky_texture_, the environment light erased and env_ half rewritten.
+        const int res[] = {env_.envmap_resolution, env_.envmap_resolution / 2};
+        std::vector<color_rgba8_t> rgbe_pixels(size_t(res[0]) * size_t(res[1]));
+        static_assert(sizeof(color_rgba8_t) == sizeof(uint32_t), "RGBE texels are four bytes");
+        {
+            dir_lights_.clear();
+            for (auto it = lights_.cbegin(); it != lights_.cend(); ++it) {
+                if (it->type == LIGHT_TYPE_DIR) {
+                    dir_lights_.push_back(it.index());
+                }
+            }
+            const float spread_before = env_.sky_map_spread_angle;
+            env_.sky_map_spread_angle = 2 * PI / float(env_.envmap_resolution); // (the exported description says "a physical sky" through it)
+            FlatScene sky_only;
+            SceneAccess::ExportSkyForBake(*this, sky_only);
+            if (!sky_baker_(sky_only.desc, res[0], res[1], reinterpret_cast<uint32_t *>(rgbe_pixels.data()))) {
+                env_.sky_map_spread_angle = spread_before;
+                throw std::runtime_error(std::string("SceneHIP::Finalize: the sky bake failed on the device: ") + rayhip_last_error());
+            }
+            sky_baked_on_ = "device";
+        }
         if (env_map_light_ != InvalidLightHandle) {
             lights_.Erase(env_map_light_._block);
         }
@@ -125,26 +148,11 @@ class Scene final : public Cpu::Scene {
         if (env_.back_map == env_.env_map) {
             env_.back_map_rotation = 0.0f;
         }
-        env_.sky_map_spread_angle = 2 * PI / float(env_.envmap_resolution);
-        { // PrepareSkyEnvMap_nolock
+        { // PrepareSkyEnvMap_nolock, with the texels that are already there
             if (physical_sky_texture_ != InvalidTextureHandle) {
                 tex_storages_[physical_sky_texture_._index >> 24]->Free(physical_sky_texture_._index & 0x00ffffff);
+                physical_sky_texture_ = InvalidTextureHandle;
             }
-            dir_lights_.clear();
-            for (auto it = lights_.cbegin(); it != lights_.cend(); ++it) {
-                if (it->type == LIGHT_TYPE_DIR) {
-                    dir_lights_.push_back(it.index());
-                }
-            }
-            const int res[] = {env_.envmap_resolution, env_.envmap_resolution / 2};
-            std::vector<color_rgba8_t> rgbe_pixels(size_t(res[0]) * size_t(res[1]));
-            static_assert(sizeof(color_rgba8_t) == sizeof(uint32_t), "RGBE texels are four bytes");
-            FlatScene sky_only;
-            SceneAccess::ExportSkyForBake(*this, sky_only);
-            if (!sky_baker_(sky_only.desc, res[0], res[1], reinterpret_cast<uint32_t *>(rgbe_pixels.data()))) {
-                throw std::runtime_error(std::string("SceneHIP::Finalize: the sky bake failed on the device: ") + rayhip_last_error());
-            }
-            sky_baked_on_ = "device";
             const int index = tex_storage_rgba_.Allocate(rgbe_pixels, res, false);
             physical_sky_texture_._index = (uint32_t(0) << 28) | uint32_t(index);
             env_.env_map = physical_sky_texture_._index;

@@ -922,6 +922,29 @@ def test_renderer_hip_camera_switch(gpu_lib, hostsim_lib):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
 
 
+def test_stage_times_partition_the_pass(gpu_lib):
+    """RendererBase::stats_t of the HIP backend: the eleven stage entries are exclusive intervals of the pass and add up to its time (the
+    reference's GPU backends report per-stage timestamps, RendererVK.cpp:452-487) -- also with the shadow launch of a bounce running on the
+    second stream beside the closest-hit launch of the next one, whose elapsed time must not be booked twice"""
+    import time
+    ctx = util.make_context(gpu_lib, "cornell_lights", w=512, h=512)
+    ctx.reserve_batch(16)
+    ctx.render_batch(1, 16)  # (set-up: buffers, first launches)
+    ctx.sync()
+    ctx.stage_times(reset=True)
+    t0 = time.perf_counter()
+    for k in range(4):
+        ctx.render_batch(17 + 16 * k, 16, flags=hip.FLAG_TIME_STAGES)
+    ctx.sync()
+    wall_us = (time.perf_counter() - t0) * 1e6
+    st = ctx.stage_times(reset=True)
+    total = sum(st.values())
+    assert st["primary_trace"] > 0 and st["secondary_shade"] > 0 and st["secondary_shadow"] > 0, st
+    # every interval lies inside the timed region (<= wall, with 2 % for the clocks) and the passes fill most of it (launch gaps aside)
+    assert total <= 1.02 * wall_us, (total, wall_us, st)
+    assert total >= 0.80 * wall_us, (total, wall_us, st)
+
+
 def test_renderer_hip_clear_resize_stats(gpu_lib, hostsim_lib):
     """RendererHIP::Clear / Resize / GetStats / ResetStats behind the Ray API (with iterations pending in the batch queue
     when they are called): pixels against the host build (which equals the reference on this sequence,
