@@ -223,6 +223,22 @@ struct rayhip_ctx {
         const double rays = double(census[size_t(b) * QUEUES_PER_BOUNCE + size_t(q)]) * double(slots) * 1.25;
         return uint32_t(std::min<double>(double(slots / WAVE + stripes), rays / WAVE + double(stripes))) + 1u;
     }
+    // Which form of the shade stage a pass takes (round 6).  The form without the point queue (shade_split bit 4) lists a next-event record per LIT
+    // point -- 148 bytes written and read again -- where the three-kernel form reads the point it stored anyway: with a fifth of the points lit
+    // (the atria, the street) it wins 6-10 % of the frame, with every point lit (the Cornell boxes) it loses 8-9 %
+    // (profiles/r06/experiments/shade_forms_by_workload.txt).  Both are bit-identical, so the choice is made per pass from the census of the pass
+    // before: lit points / rays over all bounces; unknown (first pass of a scene): the new form.  RAYHIP_SHADE_SPLIT pins a form.
+    bool shade_form_auto = true;
+    int shade_split_for_pass() const {
+        if (!shade_form_auto || (shade_split & 16) == 0 || !census_valid) {
+            return shade_split;
+        }
+        double lit = 0.0, rays = 0.0;
+        for (int b = 0; b < census_bounces; ++b) {
+            lit += double(census[size_t(b) * QUEUES_PER_BOUNCE + 4u]), rays += double(census[size_t(b) * QUEUES_PER_BOUNCE + 0u]);
+        }
+        return (rays > 0.0 && lit >= 0.5 * rays) ? (shade_split & ~16) : shade_split;
+    }
     DevBuf stack_spill;   // per-wave overflow slabs of the traversal stack
     // Round 5: the shadow rays of bounce b (K3: reads the shadow-ray planes, adds to the per-iteration pixel buffer) and the closest-hit launch of
     // bounce b + 1 (K2: reads the ray planes, writes the hit planes) touch disjoint state, so K3 goes to a second, low-priority stream and fills
@@ -592,6 +608,7 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     }
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
         c->shade_split = atoi(e) & 31;
+        c->shade_form_auto = false;
     }
     if (const char *e = getenv("RAYHIP_PICK_LDS")) {
         c->pick_lds = atoi(e) != 0;

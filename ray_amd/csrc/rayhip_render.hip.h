@@ -30,7 +30,7 @@ static int ensure_pass(rayhip_ctx *c, const int rect[4], int n) {
 // other ray buffer, shadow rays into shadow queue `bounce`, radiance into the per-iteration pixel buffer.  One place for
 // rayhip_render and the kernel-level hook rayhip_k_shade.
 static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration, int bounce, int cur, size_t nslots, uint32_t stripes,
-                         int gtrace, int vw, float mix_factor, const Layering &layers, bool plain_ior = false, bool sized = false) {
+                         int gtrace, int vw, float mix_factor, const Layering &layers, bool plain_ior = false, bool sized = false, int split = -1) {
     ShadeLaunch a;
     a.sc = c->sc;
     a.sp = make_shade_params(cam, iteration, bounce);
@@ -42,7 +42,7 @@ static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration,
     a.out_deferred = c->deferred_queue(bounce, nslots, stripes), a.nee = c->nee_queue(bounce, nslots, stripes);
     a.out_sky = c->sky_queue(bounce, nslots, stripes), a.sky_index = c->sky_index.as<uint32_t>();
     a.px = c->px, a.layers = layers, a.vw = vw, a.mix_factor = mix_factor;
-    a.bounce = bounce, a.grid = gtrace, a.split = c->shade_split, a.stream = c->stream;
+    a.bounce = bounce, a.grid = gtrace, a.split = split >= 0 ? split : c->shade_split, a.stream = c->stream;
     a.picks = c->pick_plane.as<float4>(), a.record_rays = c->record_rays, a.tag = c->next_shade_tag();
     a.pick_lds = c->pick_lds;
     if (sized) { // a pass (not a kernel-level hook): grids from the queue census, the persistent pick with a work counter
@@ -214,6 +214,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
     if (c->sc.tlas_root != 0xffffffffu) {
         launch_closest(c->rays[0], c->ray_queue(0, nslots, stripes), 0);
     }
+    const int shade_form = c->shade_split_for_pass(); // (one form for the whole pass: rayhip_ctx.hip.h)
     int cur = 0;
     bool side_pending = false; // a K3 launch on the second stream that the main stream has not waited for yet
     bool side_forked = false;  // anything was sent to the second stream in this pass
@@ -268,7 +269,7 @@ static int render_pass(rayhip_ctx *c, const rayhip_camera *cam, const int rect[4
         if (tm.mark(bounce == 0 ? ST_PSHADE : ST_SSHADE, -1)) {
             return 1;
         }
-        launch_shade(c, *cam, iteration, bounce, cur, nslots, stripes, gtrace, vw, mix_factor, layers, c->plain_ior, true);
+        launch_shade(c, *cam, iteration, bounce, cur, nslots, stripes, gtrace, vw, mix_factor, layers, c->plain_ior, true, shade_form);
         // K3 of this bounce: on the second stream, next to the closest-hit launch of the next bounce (rayhip_ctx: stream2), when it is the flat
         // persistent form and nothing is being counted
         const bool side = c->overlap_shadow && c->wide == 4 && c->shadow_refill && !count && !count_wide;
