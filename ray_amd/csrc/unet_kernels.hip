@@ -309,6 +309,7 @@ hipError_t launch_conv(const ConvParams &p, const int n_tiles, hipStream_t strea
 // swizzle_h) so that the operand reads (one ds_read_b128 each) are conflict-free.  The weights arrive from HBM already in that order (rayhip_unet_init), the patch is
 // swizzled by its stagers.  Channel counts that are odd multiples of 16 (the 16-channel image tensor, 48, 80, 112) leave the upper half of their
 // last chunk zero.  Staging is software-pipelined through registers like the f32 form's.
+constexpr float H_MAX = 65504.0f; // largest finite half: what the f16 tensors saturate at
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
@@ -494,7 +495,7 @@ template <int NT, int ROWS> __global__ void __launch_bounds__(256, 2) k_conv3x3_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float mine = fmaxf(fmaxf(acc[rp][nt][i], 0.0f), fmaxf(acc[rp + 1][nt][i], 0.0f));
-                    v[i] = _Float16(fmaxf(mine, __shfl_xor(mine, 1)));
+                    v[i] = _Float16(fminf(fmaxf(mine, __shfl_xor(mine, 1)), H_MAX)); // (saturating: an activation beyond the half range stays finite)
                 }
                 if ((m & 1) == 0 && x < xe && y < ye && nt * 16 < p.out_ch) {
                     *reinterpret_cast<h4 *>(out_h + (ptrdiff_t(y / 2) * p.out_stride + (x / 2)) * p.out_ch + nt * 16 + 4 * kq) = v;
@@ -512,8 +513,9 @@ template <int NT, int ROWS> __global__ void __launch_bounds__(256, 2) k_conv3x3_
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (nt * 16 < p.out_ch) {
-                    *reinterpret_cast<h4 *>(o + nt * 16) = h4{_Float16(fmaxf(0.0f, acc[rr][nt][0])), _Float16(fmaxf(0.0f, acc[rr][nt][1])),
-                                                             _Float16(fmaxf(0.0f, acc[rr][nt][2])), _Float16(fmaxf(0.0f, acc[rr][nt][3]))};
+                    // ReLU and saturation at the largest half in one clamp: an activation beyond 65504 stays finite
+                    *reinterpret_cast<h4 *>(o + nt * 16) = h4{_Float16(fminf(fmaxf(0.0f, acc[rr][nt][0]), H_MAX)), _Float16(fminf(fmaxf(0.0f, acc[rr][nt][1]), H_MAX)),
+                                                             _Float16(fminf(fmaxf(0.0f, acc[rr][nt][2]), H_MAX)), _Float16(fminf(fmaxf(0.0f, acc[rr][nt][3]), H_MAX))};
                 }
             }
         }

@@ -57,6 +57,11 @@ def main():
     ctx.render_batch(1, spp, flags=hip.FLAG_TIME_STAGES)
     ctx.sync()
     stages = ctx.stage_times(reset=True)
+    # visit census of the product's walk on this scene (the counting form of the kernels: two more iterations)
+    ctx.trav_counters(reset=True)
+    for it in (spp + 1, spp + 2):
+        ctx.render(it, flags=hip.FLAG_COUNT_WIDE)
+    c2, c3 = ctx.trav_counters(reset=True)
     host = w * h * n_cpu / t_cpu / 1e6
     # parity of this very frame: the first 1 + n_cpu samples of both
     ctx.clear()
@@ -66,6 +71,10 @@ def main():
     print(f"{name} ({rs.triangle_count()} triangles in the scene's meshes; {'; '.join(notes)}), {w} x {h}:")
     print(f"  device: {spp} spp in {min(times) * 1e3:.1f} ms (best of 3: {', '.join(f'{t * 1e3:.1f}' for t in times)}) = {dev:.1f} Msamples/s")
     print("  stages, ms per frame (stats_t counts microseconds): " + "  ".join(f"{k} {v / 1e3:.1f}" for k, v in stages.items() if v))
+    r2, r3 = max(c2["rays"], 1), max(c3["rays"], 1)
+    print(f"  census: {c2['rays'] / (2 * w * h):.2f} closest-hit rays per sample, per ray {c2['nodes'] / r2:.2f} top-level nodes, {c2['instances'] / r2:.2f} instances entered, "
+          f"{c2['nodes4'] / r2:.2f} wide nodes, {c2['tris'] / r2:.2f} triangle tests; {c3['rays'] / (2 * w * h):.2f} shadow rays per sample, per ray {c3['nodes'] / r3:.2f} top-level nodes, "
+          f"{c3['instances'] / r3:.2f} instances, {c3['nodes4'] / r3:.2f} wide nodes, {c3['tris'] / r3:.2f} triangle tests")
     print(f"  reference {kind} backend, {threads} threads: {n_cpu} spp in {t_cpu:.1f} s after a 1-spp warm-up ({t1:.2f} s) = {host:.2f} Msamples/s  -> x{dev / host:.0f}")
     print(f"  parity at {1 + n_cpu} spp against RendererRef: {m['frac_within'] * 100:.4f} % within tolerance, {m['psnr']:.1f} dB, {m['exact'] * 100:.1f} % of the pixels bit-equal")
 
