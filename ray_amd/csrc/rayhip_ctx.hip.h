@@ -153,6 +153,7 @@ struct rayhip_ctx {
     // the ray's part of a next-event record (shade_launch.h)
     DevBuf pick_plane, record_ray_planes[4];
     RaySoA record_rays = {};
+    bool notex_kernels = true; // RAYHIP_NOTEX_KERNELS=0: scenes without textures take the general k_surface_scatter too
     bool pick_lds = true; // RAYHIP_PICK_LDS=0: the light pick reads every row of the light table from memory (shade_kernels.hip)
     uint32_t shade_tag = 0;
     uint32_t next_shade_tag() {
@@ -609,6 +610,9 @@ int rayhip_ctx_create(int device, rayhip_ctx **out_ctx) {
     if (const char *e = getenv("RAYHIP_SHADE_SPLIT")) {
         c->shade_split = atoi(e) & 31;
         c->shade_form_auto = false;
+    }
+    if (const char *e = getenv("RAYHIP_NOTEX_KERNELS")) {
+        c->notex_kernels = atoi(e) != 0;
     }
     if (const char *e = getenv("RAYHIP_PICK_LDS")) {
         c->pick_lds = atoi(e) != 0;

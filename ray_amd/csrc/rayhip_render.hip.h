@@ -45,6 +45,7 @@ static void launch_shade(rayhip_ctx *c, const rayhip_camera &cam, int iteration,
     a.bounce = bounce, a.grid = gtrace, a.split = split >= 0 ? split : c->shade_split, a.stream = c->stream;
     a.picks = c->pick_plane.as<float4>(), a.record_rays = c->record_rays, a.tag = c->next_shade_tag();
     a.pick_lds = c->pick_lds;
+    a.no_textures = c->textures_count == 0 && c->notex_kernels;
     if (sized) { // a pass (not a kernel-level hook): grids from the queue census, the persistent pick with a work counter
         a.expect[EXPECT_RAYS] = bounce == 0 ? uint32_t(nslots / WAVE + stripes) : c->expect_chunks(bounce, 0, nslots, stripes);
         a.expect[EXPECT_POINTS] = c->expect_chunks(bounce, 3, nslots, stripes), a.expect[EXPECT_LIT] = c->expect_chunks(bounce, 4, nslots, stripes);

@@ -546,8 +546,12 @@ __global__ void __launch_bounds__(LDS_TREE ? PICK_BLOCK_WAVES *WAVE : WAVE, LDS_
 // in LDS it is bound by the eight importance evaluations of a level -- nine quarter-rate reciprocals / square roots each.
 // profiles/r06/experiments/pick_lds_staged.txt; the kernel was removed.)
 
-template <bool PRIMARY, bool SKY>
-__global__ void __launch_bounds__(WAVE, RT_FUSED_MIN_WAVES) k_surface_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
+// TEX = false: the scene holds no texture (ShadeLaunch::no_textures): the surface stage without its lookups, RT_FUSED_NOTEX_MIN_WAVES
+#ifndef RT_FUSED_NOTEX_MIN_WAVES
+#define RT_FUSED_NOTEX_MIN_WAVES 3
+#endif
+template <bool PRIMARY, bool SKY, bool TEX = true>
+__global__ void __launch_bounds__(WAVE, TEX ? RT_FUSED_MIN_WAVES : RT_FUSED_NOTEX_MIN_WAVES) k_surface_scatter(const SceneView sc, const ShadeParams sp, const RaySoA rays_in, const HitSoA hits,
                                                                                const RayQueue in, const float4 *__restrict__ picks, const uint32_t tag,
                                                                                const PointSoA records, const RaySoA record_rays, const RayQueue out_records,
                                                                                const RaySoA rays_out, const RayQueue out_rays,
@@ -581,7 +585,7 @@ __global__ void __launch_bounds__(WAVE, RT_FUSED_MIN_WAVES) k_surface_scatter(co
             spl = layer_params(sp, layer);
             ray.xy = xy_real(xy, layers, layer);
             ahead = vertex_randoms(path_random(sc, spl, ray.xy, ray.depth));
-            continues = surface_stage<true, SKY>(sc, spl, hit, ray, pt, so, &ahead);
+            continues = surface_stage<true, SKY, TEX>(sc, spl, hit, ray, pt, so, &ahead);
             defer = so.deferred_emitter;
             sky = SKY && so.deferred_sky;
             if (PRIMARY) {
@@ -775,11 +779,15 @@ void launch(const ShadeLaunch &a) {
         if (a.bounce == 0) {
             if (sky_scene) {
                 RT_FUSED(true, true);
+            } else if (a.no_textures) {
+                RT_FUSED(true, false, false);
             } else {
                 RT_FUSED(true, false);
             }
         } else if (sky_scene) {
             RT_FUSED(false, true);
+        } else if (a.no_textures) {
+            RT_FUSED(false, false, false);
         } else {
             RT_FUSED(false, false);
         }

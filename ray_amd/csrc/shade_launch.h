@@ -45,6 +45,7 @@ struct ShadeLaunch {
     // round 6 (split bit 4): the light pick runs first and leaves its picks in a plane indexed by RAY slot, stamped with `tag` (unique per launch
     // of the stage, never 0; the plane starts zeroed); k_surface_scatter lists what the next-event estimation needs of a lit point in the point
     // planes + `record_rays` (direction | cone width, throughput | cone spread, ior stack, pixel | depth: the planes of a RaySoA, o_pdf unused)
+    bool no_textures = false; // the uploaded scene holds no texture at all: k_surface_scatter without the lookups (shade_point.h: TEX)
     bool pick_lds = true; // k_light_pick_first keeps the top of the light table in LDS (RAYHIP_PICK_LDS=0: every row from memory)
     float4 *picks = nullptr;
     uint32_t tag = 0;

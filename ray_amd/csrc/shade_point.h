@@ -149,14 +149,15 @@ RT_HD f3 clamp_radiance_sum(f3 c, const float limit) {
 
 // ---- terminal: the ray left the scene (ShadeRef.cpp:1030-1066) ----------------------------------------------------------------
 // `inv_pick_prob` < 0: no MIS against next-event estimation (the path could not have continued)
-template <class Jitter>
+// TEX = false: the scene has no texture at all (no environment map either) -- the lookups are compiled out (see surface_stage)
+template <bool TEX = true, class Jitter>
 RT_HD f4 environment_radiance(const SceneView &sc, const Ray &ray, const float inv_pick_prob, Jitter &&jitter) {
     const rayhip_environment &env = sc.env;
     const bool indirect = is_indirect(ray.depth);
     const uint32_t map = indirect ? env.env_map : env.back_map;
     const float rotation = indirect ? env.env_map_rotation : env.back_map_rotation;
     f4 c = {1.0f, 1.0f, 1.0f, 1.0f};
-    if (map != 0xffffffff) {
+    if (TEX && map != 0xffffffff) {
         c = mk4(latlong_rgbe(sc, map, ray.d, rotation, jitter()), 1.0f);
     }
     if (env.light_index != 0xffffffff && inv_pick_prob >= 0.0f && indirect) {
@@ -268,7 +269,9 @@ RT_HD f4 emissive_hit_radiance(const ShadeParams &sp, const float mix_weight, co
 // Returns true when `pt` was filled (the path continues through stages 2 and 3), false when the path ends with out.radiance.
 // DEFER_EMITTERS: leave the MIS weight of emitter hits to the caller (see SurfaceOut).
 // SKY: the environment may be the physical sky (false: the test is compiled out -- the device picks the kernel per scene).
-template <bool DEFER_EMITTERS, bool SKY = true>
+// TEX (round 6): false when the uploaded scene holds NO texture (SceneView::tex_flags / textures_count: decided at upload, exact) -- every texture
+// lookup of the stage is compiled out, which is worth 20 registers to k_surface_scatter (175 -> 153 at its peak).
+template <bool DEFER_EMITTERS, bool SKY = true, bool TEX = true>
 RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &hit, const Ray &ray, ShadePoint &pt, SurfaceOut &out,
                          const VertexRandoms *ahead = nullptr) {
     out.radiance = f4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -298,7 +301,7 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
             return false;
         }
         const float inv_pick_prob = (get_total_depth(ray.depth) < sp.ps.max_total_depth) ? safe_div_pos(1.0f, hit.u) : -1.0f;
-        f4 c = environment_radiance(sc, ray, inv_pick_prob, tex_jitter);
+        f4 c = environment_radiance<TEX>(sc, ray, inv_pick_prob, tex_jitter);
         c *= mk4(ray.c.x, ray.c.y, ray.c.z, 0.0f);
         const float sum = hsum(c);
         if (sum > sp.limits[0]) {
@@ -357,7 +360,7 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     pt.mix_weight = 1.0f;
     while (mat->type == NODE_MIX) {
         float k = mat->tangent_rotation_or_strength;
-        if (mat->textures[BASE_TEXTURE] != 0xffffffff) {
+        if (TEX && mat->textures[BASE_TEXTURE] != 0xffffffff) {
             k *= sample_color(sc, mat->textures[BASE_TEXTURE], uv, 0, tex_jitter()).x;
         }
         const float eta = pt.backfacing ? safe_div_pos(outside_ior, mat->ior) : safe_div_pos(mat->ior, outside_ior);
@@ -378,7 +381,7 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     pt.material = uint32_t(mat - sc.materials);
 
     // ---- normal map, bent back above the horizon of the view direction ----
-    if (mat->textures[NORMALS_TEXTURE] != 0xffffffff) {
+    if (TEX && mat->textures[NORMALS_TEXTURE] != 0xffffffff) {
         f4 nm = sample_bilinear(sc, mat->textures[NORMALS_TEXTURE], uv, 0, tex_jitter());
         nm = nm * 2.0f;
         nm = {nm.x - 1.0f, nm.y - 1.0f, nm.z - 1.0f, nm.w - 1.0f};
@@ -420,7 +423,7 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
 
     // ---- texture-modulated parameters ----
     pt.base = mk3(mat->base_color);
-    if (mat->textures[BASE_TEXTURE] != 0xffffffff) {
+    if (TEX && mat->textures[BASE_TEXTURE] != 0xffffffff) {
         const uint32_t tex = mat->textures[BASE_TEXTURE];
         pt.base *= xyz(sample_color(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter()));
     }
@@ -428,7 +431,7 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     out.normal_depth = mk4(N, hit.t);
 
     pt.roughness = float(mat->roughness_unorm) / 65535.0f;
-    if (mat->textures[ROUGH_TEXTURE] != 0xffffffff) {
+    if (TEX && mat->textures[ROUGH_TEXTURE] != 0xffffffff) {
         const uint32_t tex = mat->textures[ROUGH_TEXTURE];
         const float r = sample_bilinear(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter()).x;
         f4 splat = {r, r, r, r};
@@ -440,12 +443,12 @@ RT_HD bool surface_stage(const SceneView &sc, const ShadeParams &sp, const Hit &
     pt.metallic = pt.specular = 0.0f;
     if (mat->type == NODE_PRINCIPLED) {
         pt.metallic = float(mat->metallic_unorm) / 65535.0f;
-        if (mat->textures[METALLIC_TEXTURE] != 0xffffffff) {
+        if (TEX && mat->textures[METALLIC_TEXTURE] != 0xffffffff) {
             const uint32_t tex = mat->textures[METALLIC_TEXTURE];
             pt.metallic *= sample_bilinear(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter()).x;
         }
         pt.specular = float(mat->specular_unorm) / 65535.0f;
-        if (mat->textures[SPECULAR_TEXTURE] != 0xffffffff) {
+        if (TEX && mat->textures[SPECULAR_TEXTURE] != 0xffffffff) {
             const uint32_t tex = mat->textures[SPECULAR_TEXTURE];
             f4 s = sample_bilinear(sc, tex, uv, int(get_texture_lod(sc, tex, lod_lambda)), tex_jitter());
             if (tex & TEX_SRGB_BIT) {
