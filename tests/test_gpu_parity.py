@@ -575,6 +575,26 @@ def test_shade_forms_agree_bit_for_bit(gpu_lib, name, monkeypatch):
             assert np.array_equal(a, b), (name, split)
 
 
+@pytest.mark.parametrize("name", ["cornell_lights", "cornell_env"])
+def test_light_pick_from_memory_and_from_lds_agree(gpu_lib, name, monkeypatch):
+    """round 6's form pinned (RAYHIP_SHADE_SPLIT=29): k_light_pick_first with the light table in LDS (the default while it fits) against the
+    same kernel reading the table from memory (RAYHIP_PICK_LDS=0: the path of scenes whose table does not fit) -- the same descent per ray"""
+    monkeypatch.setenv("RAYHIP_SHADE_SPLIT", "29")
+    frames = {}
+    for lds in ("1", "0"):
+        monkeypatch.setenv("RAYHIP_PICK_LDS", lds)
+        ctx = util.make_context(gpu_lib, name)
+        ctx.render_batch(1, 6)
+        ctx.render(7)
+        frames[lds] = (ctx.readback(hip.BUF_RAW), ctx.readback(hip.BUF_VARIANCE))
+    for a, b in zip(frames["1"], frames["0"]):
+        assert np.array_equal(a, b), name
+    g = util.golden_ref(name)
+    monkeypatch.delenv("RAYHIP_PICK_LDS")
+    m = util.frame_metrics(util.render_frames(util.make_context(gpu_lib, name), 8), g["raw_spp8"])
+    assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
+
+
 def test_sparse_lights_take_the_split_form(gpu_lib, monkeypatch):
     """a scene where most shade points end their light-tree descent without a light (small emitters facing away from most
     of the scene): the device picks the split form; same frame as the combined kernel"""

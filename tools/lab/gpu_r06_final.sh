@@ -61,5 +61,9 @@ import json; d=json.load(open('$OUT/bench_2ranks_emulated.json')); print('2 rank
 RAY_AMD_FORCE_DIST=1 timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_force_dist_1rank.json 2> $OUT/b3.err; echo "force-dist exit $?"
 python3 -c "
 import json; d=json.load(open('$OUT/bench_force_dist_1rank.json')); print('1 rank through the N>1 path', round(d['value'],1), d.get('transport'), d.get('ncclCommCount'), d.get('exchange'))"
+# random scenes on the final tree, DIRECTLY against the live reference: the form the census picks, and round 6's form pinned
+timeout 1200 python tools/gpu_fuzz.py 14000 60 oracle 2>&1 | grep -v amdgpu.ids | tail -2 > $OUT/gpu_fuzz.txt
+RAYHIP_SHADE_SPLIT=29 timeout 1200 python tools/gpu_fuzz.py 15000 60 oracle 2>&1 | grep -v amdgpu.ids | tail -2 >> $OUT/gpu_fuzz.txt
+cat $OUT/gpu_fuzz.txt | cut -c1-250
 timeout 900 python tools/material_ball_bench.py complex_mat5 64 > $OUT/material_ball_bench.txt 2>&1; tail -5 $OUT/material_ball_bench.txt | cut -c1-300
 find $OUT -name '*.csv' -size +2M -delete; find $OUT -name '*.db' -delete; du -sh $OUT
