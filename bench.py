@@ -209,7 +209,7 @@ def valu_issue_block(traffic, launches, k2_s):
     out = {"wave_instructions_per_s": rate, "active_lanes_of_64": traffic.get("valu_active_lanes"),
            "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU of this command / live launch time"}
     try:
-        mix_path = next(p for p in (os.path.join(ROOT, "profiles", r, "k2_valu_mix.json") for r in ("r05", "r04")) if os.path.exists(p))
+        mix_path = next(p for p in (os.path.join(ROOT, "profiles", r, "k2_valu_mix.json") for r in ("r06", "r05", "r04")) if os.path.exists(p))
         with open(mix_path) as f:
             mix = json.load(f)
         peak = mix["peak_wave_instructions_per_s"]
