@@ -595,6 +595,26 @@ def test_light_pick_from_memory_and_from_lds_agree(gpu_lib, name, monkeypatch):
     assert m["frac_within"] >= util.MIN_FRACTION and m["psnr"] >= util.MIN_PSNR_8SPP, m
 
 
+@pytest.mark.parametrize("name", ["cornell_lights", "cornell_principled"])
+def test_the_form_chosen_from_the_census_changes_nothing(gpu_lib, name, monkeypatch):
+    """default settings: the first pass of a scene takes round 6's form, later passes the form the queue census of the pass before asks for (every
+    point of these scenes is lit: the three-kernel form) -- three passes of a context left to itself against both forms pinned"""
+    frames = {}
+    for split in (None, "13", "29"):
+        if split is None:
+            monkeypatch.delenv("RAYHIP_SHADE_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("RAYHIP_SHADE_SPLIT", split)
+        ctx = util.make_context(gpu_lib, name)
+        for first in (1, 5, 9):
+            ctx.render_batch(first, 4)
+            ctx.sync()  # (the census of a pass has arrived when the next one starts)
+        frames[split] = (ctx.readback(hip.BUF_RAW), ctx.readback(hip.BUF_VARIANCE))
+    for split in ("13", "29"):
+        for a, b in zip(frames[None], frames[split]):
+            assert np.array_equal(a, b), (name, split)
+
+
 def test_sparse_lights_take_the_split_form(gpu_lib, monkeypatch):
     """a scene where most shade points end their light-tree descent without a light (small emitters facing away from most
     of the scene): the device picks the split form; same frame as the combined kernel"""

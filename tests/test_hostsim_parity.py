@@ -379,6 +379,29 @@ def test_atrium_against_live_reference(lib, wide, monkeypatch):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("instanced", [False, True])
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_asset_street_against_live_reference(lib, instanced, wide, monkeypatch):
+    """the Bistro-class street of bench.py's `bistro_assets` / `bistro_assets_inst` workloads (copies of the reference's own mat_test/model.bin
+    along a street) with two copies: baked into one mesh / as instances under a top-level tree; host build of the kernel
+    sources against the live reference bit for bit, BVH2 and 4-wide walks"""
+    from functools import partial
+    from ray_amd import scenes
+
+    if not scenes.have_asset_meshes():
+        pytest.skip("tests/assets/_ref/meshes.npz not staged (needs the reference tree: tests/golden/stage_ref_assets.py)")
+    monkeypatch.setenv("HOSTSIM_BVH4", wide)
+    monkeypatch.setenv("HOSTSIM_BVH8", "0")
+    monkeypatch.setenv("HOSTSIM_REFINE", "0")
+    w, h, spp = 96, 54, 2
+    r, s = O.render_ref(partial(scenes.street_assets, copies=2, instanced=instanced), w, h, spp)
+    assert s.triangle_count() > 100000
+    ctx = O.hostsim_context(w, h, O.export_scene(s))
+    assert np.array_equal(util.render_frames(ctx, spp), r.get_raw_pixels_ref())
+    assert float(r.get_raw_pixels_ref()[..., :3].sum()) > 0.0
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("seed", list(range(1, 13)))
 def test_random_scenes_against_live_reference(lib, seed):
     """a small fuzzer: materials (all node types, Mix trees, every Principled parameter), lights (all types, delta and
